@@ -1,0 +1,128 @@
+"""Deterministic synthetic weights and inputs (numpy only).
+
+There are no checkpoints in the build container or on the GPU box, so every
+test, fixture and benchmark regenerates its weights from a seed.  The state
+dict names and shapes are exactly those of the reference modules
+(`modules/backbones/wavenet.py:22-31,56-72`, `modules/backbones/lynxnet.py:52-62,
+71-74,104-124`), so the same dict loads with `strict=True` into the reference
+`WaveNet` / `LYNXNet`, into this package's shims and into the numpy oracle.
+
+`output_projection.weight` is zero-initialised by the reference
+(`wavenet.py:73`, `lynxnet.py:126`); here it gets fan-in scaled normals like
+every other layer, otherwise the network output would be its bias only.
+"""
+from __future__ import annotations
+
+import hashlib
+from collections import OrderedDict
+
+import numpy as np
+
+
+def wavenet_param_shapes(in_dims, n_feats, num_layers=20, num_channels=256, hidden_size=256):
+    c, m, h = num_channels, in_dims * n_feats, hidden_size
+    shapes = OrderedDict()
+    shapes["input_projection.weight"] = (c, m, 1)
+    shapes["input_projection.bias"] = (c,)
+    shapes["mlp.0.weight"] = (4 * c, c)
+    shapes["mlp.0.bias"] = (4 * c,)
+    shapes["mlp.2.weight"] = (c, 4 * c)
+    shapes["mlp.2.bias"] = (c,)
+    for l in range(num_layers):
+        p = f"residual_layers.{l}."
+        shapes[p + "dilated_conv.weight"] = (2 * c, c, 3)
+        shapes[p + "dilated_conv.bias"] = (2 * c,)
+        shapes[p + "diffusion_projection.weight"] = (c, c)
+        shapes[p + "diffusion_projection.bias"] = (c,)
+        shapes[p + "conditioner_projection.weight"] = (2 * c, h, 1)
+        shapes[p + "conditioner_projection.bias"] = (2 * c,)
+        shapes[p + "output_projection.weight"] = (2 * c, c, 1)
+        shapes[p + "output_projection.bias"] = (2 * c,)
+    shapes["skip_projection.weight"] = (c, c, 1)
+    shapes["skip_projection.bias"] = (c,)
+    shapes["output_projection.weight"] = (m, c, 1)
+    shapes["output_projection.bias"] = (m,)
+    return shapes
+
+
+def lynxnet_param_shapes(in_dims, n_feats, num_layers=6, num_channels=512, expansion_factor=2,
+                         kernel_size=31, activation="PReLU", hidden_size=256):
+    c, m, h = num_channels, in_dims * n_feats, hidden_size
+    inner = c * expansion_factor
+    shapes = OrderedDict()
+    shapes["input_projection.weight"] = (c, m, 1)
+    shapes["input_projection.bias"] = (c,)
+    shapes["diffusion_embedding.1.weight"] = (4 * c, c)
+    shapes["diffusion_embedding.1.bias"] = (4 * c,)
+    shapes["diffusion_embedding.3.weight"] = (c, 4 * c)
+    shapes["diffusion_embedding.3.bias"] = (c,)
+    for l in range(num_layers):
+        p = f"residual_layers.{l}."
+        shapes[p + "diffusion_projection.weight"] = (c, c, 1)
+        shapes[p + "diffusion_projection.bias"] = (c,)
+        shapes[p + "conditioner_projection.weight"] = (c, h, 1)
+        shapes[p + "conditioner_projection.bias"] = (c,)
+        shapes[p + "convmodule.net.0.weight"] = (c,)
+        shapes[p + "convmodule.net.0.bias"] = (c,)
+        shapes[p + "convmodule.net.2.weight"] = (2 * inner, c, 1)
+        shapes[p + "convmodule.net.2.bias"] = (2 * inner,)
+        shapes[p + "convmodule.net.4.weight"] = (inner, 1, kernel_size)
+        shapes[p + "convmodule.net.4.bias"] = (inner,)
+        if activation == "PReLU":
+            shapes[p + "convmodule.net.5.weight"] = (inner,)
+        shapes[p + "convmodule.net.6.weight"] = (c, inner, 1)
+        shapes[p + "convmodule.net.6.bias"] = (c,)
+    shapes["norm.weight"] = (c,)
+    shapes["norm.bias"] = (c,)
+    shapes["output_projection.weight"] = (m, c, 1)
+    shapes["output_projection.bias"] = (m,)
+    return shapes
+
+
+def backbone_param_shapes(kind, in_dims, n_feats, hidden_size=256, **args):
+    if kind == "wavenet":
+        return wavenet_param_shapes(in_dims, n_feats, num_layers=args.get("num_layers", 20),
+                                    num_channels=args.get("num_channels", 256), hidden_size=hidden_size)
+    if kind == "lynxnet":
+        return lynxnet_param_shapes(in_dims, n_feats, num_layers=args.get("num_layers", 6),
+                                    num_channels=args.get("num_channels", 512),
+                                    expansion_factor=args.get("expansion_factor", 2),
+                                    kernel_size=args.get("kernel_size", 31),
+                                    activation=args.get("activation", "PReLU") or "PReLU",
+                                    hidden_size=hidden_size)
+    raise KeyError(kind)
+
+
+def synth_state_dict(shapes, seed=42):
+    """name -> float32 ndarray.  Fan-in scaled normals for matrices, N(0, 0.1) biases,
+    LayerNorm gains around 1, PReLU slopes around 0.25."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = OrderedDict()
+    for name, shape in shapes.items():
+        z = rng.standard_normal(shape, dtype=np.float32)
+        leaf = name.rsplit(".", 1)[-1]
+        is_ln = name.startswith("norm.") or ".convmodule.net.0." in name
+        if is_ln and leaf == "weight":
+            w = 1.0 + 0.1 * z
+        elif ".convmodule.net.5." in name:
+            w = 0.25 + 0.05 * z
+        elif leaf == "bias":
+            w = 0.1 * z
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            w = z / np.sqrt(np.float32(fan_in))
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out
+
+
+def state_dict_digest(sd):
+    h = hashlib.sha256()
+    for name, arr in sd.items():
+        h.update(name.encode())
+        h.update(np.ascontiguousarray(arr, dtype=np.float32).tobytes())
+    return h.hexdigest()
+
+
+def synth_normal(shape, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.standard_normal(shape, dtype=np.float32)

@@ -1,0 +1,417 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the imported reference.
+
+Runs ONLY in the build container (it needs /root/reference, which never travels
+to the GPU box).  It stubs the one missing third-party import (`lightning`,
+pulled in by utils/training_utils.py but never executed on this path), imports
+the reference's own `build_backbone`, `GaussianDiffusion`, `RectifiedFlow`,
+`PitchDiffusion`, `MultiVarianceDiffusion`, `NoiseScheduleVP`, loads
+deterministic synthetic weights (diffsinger_amd/synth.py) with strict=True and
+records inputs' seeds and the reference outputs as small .npz files.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixtures are data (seeds, shapes, reference outputs); no reference source is
+stored.  `torch.randn` is patched while the reference samplers run so that x_T
+and the ancestral-DDPM step noise are the injected, seed-derived tensors that
+the oracle and the HIP path are later fed.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+
+def _install_lightning_stub():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+    stub("lightning")
+    stub("lightning.pytorch", LightningModule=_Dummy, Trainer=_Dummy, Callback=_Dummy)
+    stub("lightning.fabric")
+    stub("lightning.fabric.loggers")
+    stub("lightning.fabric.loggers.tensorboard", _TENSORBOARD_AVAILABLE=False)
+    stub("lightning.pytorch.callbacks", ModelCheckpoint=_Dummy, TQDMProgressBar=_Dummy)
+    stub("lightning.pytorch.loggers", TensorBoardLogger=_Dummy)
+    stub("lightning.pytorch.utilities")
+    stub("lightning.pytorch.utilities.rank_zero", rank_zero_info=print,
+         rank_zero_only=lambda f: f, rank_zero_debug=print)
+
+
+_install_lightning_stub()
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from utils.hparams import hparams  # noqa: E402  (reference)
+from modules.backbones import build_backbone  # noqa: E402  (reference)
+from modules.commons.common_layers import SinusoidalPosEmb  # noqa: E402  (reference)
+from modules.core import ddpm as ref_ddpm  # noqa: E402  (reference)
+from modules.core import reflow as ref_reflow  # noqa: E402  (reference)
+from inference import dpm_solver_pytorch as ref_dpm  # noqa: E402  (reference)
+from inference import uni_pc as ref_unipc  # noqa: E402  (reference)
+
+from diffsinger_amd import synth  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+BASE_HP = dict(hidden_size=256, schedule_type="linear", use_shallow_diffusion=False,
+               diff_speedup=10, diff_accelerator="ddim", infer=False,
+               sampling_algorithm="euler", sampling_steps=20)
+
+
+def set_hp(**kw):
+    hparams.clear()
+    hparams.update(BASE_HP)
+    hparams.update(kw)
+
+
+def to_t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def load_synth(module, kind, in_dims, n_feats, args, seed):
+    shapes = synth.backbone_param_shapes(kind, in_dims, n_feats, hidden_size=hparams["hidden_size"], **args)
+    sd = synth.synth_state_dict(shapes, seed=seed)
+    module.load_state_dict({k: to_t(v) for k, v in sd.items()}, strict=True)
+    module.eval()
+    return synth.state_dict_digest(sd)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+class InjectRandn:
+    """Replace torch.randn by a queue of seed-derived tensors for the duration of a block."""
+
+    def __init__(self, seed0):
+        self.seed = seed0
+        self.seeds = []
+
+    def __enter__(self):
+        self._orig = torch.randn
+
+        def fake(*size, **kw):
+            if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+                size = tuple(size[0])
+            arr = synth.synth_normal(tuple(int(s) for s in size), self.seed)
+            self.seeds.append(self.seed)
+            self.seed += 1
+            return to_t(arr)
+
+        torch.randn = fake
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn = self._orig
+
+
+# ----------------------------------------------------------------------------
+def g1_posemb():
+    out = {}
+    for dim in (256, 192, 512):
+        emb = SinusoidalPosEmb(dim)
+        out[f"long_{dim}"] = emb(torch.tensor([0, 1, 499, 999])).numpy()
+        out[f"float_{dim}"] = emb(torch.tensor([0.0, 499.5, 980.0200195, 0.001], dtype=torch.float32)).numpy()
+    out["t_long"] = np.array([0, 1, 499, 999], dtype=np.int64)
+    out["t_float"] = np.array([0.0, 499.5, 980.0200195, 0.001], dtype=np.float32)
+    save("g1_posemb", **out)
+
+
+WAVENET_CASES = [
+    # name, in_dims, n_feats, args, weight seed, [(B, T, t values or None, t kind)], intermediates layers
+    ("wn_acoustic", 128, 1, dict(num_layers=20, num_channels=256, dilation_cycle_length=4), 42,
+     [(1, 1, "long"), (1, 7, "float"), (1, 96, "long"), (2, 130, "float")], (0, 3, 19)),
+    ("wn_pitch", 64, 1, dict(num_layers=20, num_channels=256, dilation_cycle_length=5), 43,
+     [(1, 7, "long"), (1, 40, "float")], ()),
+    ("wn_multivar", 24, 2, dict(num_layers=10, num_channels=192, dilation_cycle_length=4), 44,
+     [(2, 50, "long"), (3, 33, "one")], ()),
+    ("wn_small", 32, 1, dict(num_layers=4, num_channels=64, dilation_cycle_length=2), 45,
+     [(2, 50, "float")], ()),
+]
+
+LYNX_CASES = [
+    ("lx_default", 128, 1, dict(num_layers=6, num_channels=512, expansion_factor=2, kernel_size=31,
+                                activation="PReLU", strong_cond=False), 52,
+     [(1, 96, "long"), (2, 20, "one")]),
+    ("lx_acoustic1024", 128, 1, dict(num_layers=6, num_channels=1024, expansion_factor=2, kernel_size=31,
+                                     activation="PReLU", strong_cond=True), 53,
+     [(1, 40, "float")]),
+    ("lx_silu", 64, 1, dict(num_layers=2, num_channels=128, expansion_factor=2, kernel_size=31,
+                            activation="SiLU", strong_cond=False), 54, [(2, 45, "float")]),
+    ("lx_relu", 24, 2, dict(num_layers=2, num_channels=128, expansion_factor=1, kernel_size=7,
+                            activation="ReLU", strong_cond=True), 55, [(2, 45, "long")]),
+]
+
+
+def make_t(kind, bsz, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if kind == "long":
+        return rng.integers(0, 1000, size=(bsz,)).astype(np.int64)
+    if kind == "float":
+        return (rng.random(size=(bsz,), dtype=np.float32) * np.float32(999.0)).astype(np.float32)
+    if kind == "one":       # reflow-style [1] tensor broadcast over the batch
+        return (rng.random(size=(1,), dtype=np.float32) * np.float32(1000.0)).astype(np.float32)
+    raise KeyError(kind)
+
+
+def g2_g3_backbones():
+    set_hp()
+    for name, in_dims, n_feats, args, wseed, cases, inter_layers in WAVENET_CASES:
+        net = build_backbone(in_dims, n_feats, "wavenet", args)
+        digest = load_synth(net, "wavenet", in_dims, n_feats, args, wseed)
+        out = {"digest": np.array(digest), "weight_seed": np.array(wseed)}
+        for ci, (bsz, t_len, tkind) in enumerate(cases):
+            xs, cs, ts = 1000 + 10 * ci, 1001 + 10 * ci, 1002 + 10 * ci
+            x = synth.synth_normal((bsz, n_feats, in_dims, t_len), xs)
+            cond = synth.synth_normal((bsz, hparams["hidden_size"], t_len), cs)
+            t = make_t(tkind, bsz, ts)
+            hooks, inter = [], {}
+            if inter_layers and t_len == 96:
+                for l in inter_layers:
+                    def hook(mod, inp, outp, l=l):
+                        inter[f"c{ci}_x_after_{l}"] = outp[0].detach().numpy().copy()
+                        inter[f"c{ci}_skip_{l}"] = outp[1].detach().numpy().copy()
+                    hooks.append(net.residual_layers[l].register_forward_hook(hook))
+            with torch.no_grad():
+                y = net(to_t(x), to_t(t), to_t(cond)).numpy()
+            for h in hooks:
+                h.remove()
+            out[f"c{ci}_meta"] = np.array([bsz, t_len, xs, cs, ts], dtype=np.int64)
+            out[f"c{ci}_tkind"] = np.array(tkind)
+            out[f"c{ci}_t"] = t
+            out[f"c{ci}_out"] = y
+            out.update(inter)
+        save("g2_" + name, **out)
+
+    for name, in_dims, n_feats, args, wseed, cases in LYNX_CASES:
+        net = build_backbone(in_dims, n_feats, "lynxnet", args)
+        digest = load_synth(net, "lynxnet", in_dims, n_feats, args, wseed)
+        out = {"digest": np.array(digest), "weight_seed": np.array(wseed)}
+        for ci, (bsz, t_len, tkind) in enumerate(cases):
+            xs, cs, ts = 2000 + 10 * ci, 2001 + 10 * ci, 2002 + 10 * ci
+            x = synth.synth_normal((bsz, n_feats, in_dims, t_len), xs)
+            cond = synth.synth_normal((bsz, hparams["hidden_size"], t_len), cs)
+            t = make_t(tkind, bsz, ts)
+            with torch.no_grad():
+                y = net(to_t(x), to_t(t), to_t(cond)).numpy()
+            out[f"c{ci}_meta"] = np.array([bsz, t_len, xs, cs, ts], dtype=np.int64)
+            out[f"c{ci}_tkind"] = np.array(tkind)
+            out[f"c{ci}_t"] = t
+            out[f"c{ci}_out"] = y
+        save("g3_" + name, **out)
+
+
+def g4_schedules():
+    set_hp()
+    d = ref_ddpm.GaussianDiffusion(
+        32, 1, timesteps=1000, k_step=1000, backbone_type="wavenet",
+        backbone_args=dict(num_layers=1, num_channels=16, dilation_cycle_length=1),
+        spec_min=[-12.0], spec_max=[0.0])
+    out = {}
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+              "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+              "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+              "posterior_mean_coef2"):
+        out[k] = getattr(d, k).numpy()
+    for tag, n_keep, steps in (("full", 1000, 50), ("full20", 1000, 20), ("shallow", 400, 20)):
+        ns = ref_dpm.NoiseScheduleVP(schedule="discrete", betas=d.betas[:n_keep])
+        nu = ref_unipc.NoiseScheduleVP(schedule="discrete", betas=d.betas[:n_keep])
+        solver = ref_dpm.DPM_Solver(lambda x, t: x, ns, algorithm_type="dpmsolver++")
+        ts = solver.get_time_steps("time_uniform", ns.T, 1.0 / ns.total_N, steps, "cpu")
+        out[f"{tag}_log_alpha_array"] = ns.log_alpha_array.numpy()[0]
+        out[f"{tag}_t_array"] = ns.t_array.numpy()[0]
+        out[f"{tag}_unipc_log_alpha_array"] = nu.log_alpha_array.numpy()[0]
+        out[f"{tag}_timesteps"] = ts.numpy()
+        out[f"{tag}_lambda"] = torch.cat([ns.marginal_lambda(t) for t in ts]).numpy()
+        out[f"{tag}_alpha"] = torch.cat([ns.marginal_alpha(t) for t in ts]).numpy()
+        out[f"{tag}_sigma"] = torch.cat([ns.marginal_std(t) for t in ts]).numpy()
+        out[f"{tag}_model_t"] = torch.stack([(t - 1.0 / ns.total_N) * ns.total_N for t in ts]).numpy()
+    # cosine beta schedule buffers too
+    set_hp(schedule_type="cosine")
+    dc = ref_ddpm.GaussianDiffusion(
+        32, 1, timesteps=1000, k_step=1000, backbone_type="wavenet",
+        backbone_args=dict(num_layers=1, num_channels=16, dilation_cycle_length=1),
+        spec_min=[-12.0], spec_max=[0.0])
+    out["cosine_betas"] = dc.betas.numpy()
+    out["cosine_alphas_cumprod"] = dc.alphas_cumprod.numpy()
+    save("g4_schedules", **out)
+
+
+SAMPLER_NET = dict(in_dims=32, n_feats=1, args=dict(num_layers=4, num_channels=64, dilation_cycle_length=2),
+                   wseed=45)
+
+
+def _build_gd(in_dims, n_feats, args, wseed, k_step=1000, btype="wavenet", spec_min=(-12.0,), spec_max=(0.0,)):
+    d = ref_ddpm.GaussianDiffusion(in_dims, n_feats, timesteps=1000, k_step=k_step, backbone_type=btype,
+                                   backbone_args=args, spec_min=list(spec_min), spec_max=list(spec_max))
+    load_synth(d.denoise_fn, btype, in_dims, n_feats, args, wseed)
+    return d
+
+
+def g5_samplers():
+    out = {}
+    sn = SAMPLER_NET
+    t_len, hsz = 50, 256
+
+    def run_gd(tag, bsz, hp, k_step=1000, shallow=False, noise_seed=3000):
+        set_hp(use_shallow_diffusion=shallow, **hp)
+        d = _build_gd(sn["in_dims"], sn["n_feats"], sn["args"], sn["wseed"], k_step=k_step)
+        cond = synth.synth_normal((bsz, t_len, hsz), noise_seed + 500)
+        src = None
+        if shallow:
+            # a plausible mel in [spec_min, spec_max]
+            src = (synth.synth_normal((bsz, t_len, sn["in_dims"]), noise_seed + 501) * 1.5 - 6.0).astype(np.float32)
+        with InjectRandn(noise_seed) as inj, torch.no_grad():
+            y = d(to_t(cond), src_spec=None if src is None else to_t(src), infer=True).numpy()
+        out[f"{tag}_out"] = y
+        out[f"{tag}_meta"] = np.array([bsz, t_len, noise_seed, len(inj.seeds), k_step, int(shallow)], dtype=np.int64)
+        print(f"  {tag}: randn calls={len(inj.seeds)} out={y.shape} absmax={np.abs(y).max():.3f}")
+
+    run_gd("ddim10", 2, dict(diff_accelerator="ddim", diff_speedup=10, K_step_infer=1000))
+    run_gd("ddim100", 2, dict(diff_accelerator="ddim", diff_speedup=100, K_step_infer=1000))
+    run_gd("pndm20", 1, dict(diff_accelerator="pndm", diff_speedup=20, K_step_infer=1000))
+    run_gd("dpm20", 2, dict(diff_accelerator="dpm-solver", diff_speedup=50, K_step_infer=1000))
+    run_gd("dpm50", 1, dict(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000))
+    run_gd("dpm5", 1, dict(diff_accelerator="dpm-solver", diff_speedup=200, K_step_infer=1000))
+    run_gd("unipc20", 2, dict(diff_accelerator="unipc", diff_speedup=50, K_step_infer=1000))
+    run_gd("unipc50", 1, dict(diff_accelerator="unipc", diff_speedup=20, K_step_infer=1000))
+    run_gd("ddpm_shallow20", 2, dict(diff_accelerator="ddim", diff_speedup=1, K_step_infer=20),
+           k_step=400, shallow=True)
+    run_gd("dpm_shallow", 2, dict(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=400),
+           k_step=400, shallow=True)
+    run_gd("ddim_shallow", 2, dict(diff_accelerator="ddim", diff_speedup=10, K_step_infer=200),
+           k_step=400, shallow=True)
+
+    def run_rf(tag, bsz, algo, steps, t_start=0.0, shallow=False, noise_seed=4000):
+        set_hp(use_shallow_diffusion=shallow, sampling_algorithm=algo, sampling_steps=steps,
+               T_start_infer=t_start)
+        r = ref_reflow.RectifiedFlow(sn["in_dims"], sn["n_feats"], t_start=t_start, time_scale_factor=1000,
+                                     backbone_type="wavenet", backbone_args=sn["args"],
+                                     spec_min=[-12.0], spec_max=[0.0])
+        load_synth(r.velocity_fn, "wavenet", sn["in_dims"], sn["n_feats"], sn["args"], sn["wseed"])
+        cond = synth.synth_normal((bsz, t_len, hsz), noise_seed + 500)
+        src = None
+        if shallow:
+            src = (synth.synth_normal((bsz, t_len, sn["in_dims"]), noise_seed + 501) * 1.5 - 6.0).astype(np.float32)
+        with InjectRandn(noise_seed) as inj, torch.no_grad():
+            y = r(to_t(cond), src_spec=None if src is None else to_t(src), infer=True).numpy()
+        out[f"{tag}_out"] = y
+        out[f"{tag}_meta"] = np.array([bsz, t_len, noise_seed, len(inj.seeds), steps, int(shallow)], dtype=np.int64)
+        out[f"{tag}_tstart"] = np.array(t_start, dtype=np.float64)
+        print(f"  {tag}: randn calls={len(inj.seeds)} out={y.shape} absmax={np.abs(y).max():.3f}")
+
+    run_rf("rf_euler20", 2, "euler", 20)
+    run_rf("rf_rk2_20", 2, "rk2", 20)
+    run_rf("rf_rk4_20", 2, "rk4", 20)
+    run_rf("rf_rk5_20", 1, "rk5", 20)
+    run_rf("rf_euler_shallow", 2, "euler", 20, t_start=0.4, shallow=True)
+    save("g5_samplers", **out)
+
+    # one full-size acoustic WaveNet run: DPM-Solver++ 1000 -> 20, T=64, B=1
+    set_hp(diff_accelerator="dpm-solver", diff_speedup=50, K_step_infer=1000)
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    d = _build_gd(128, 1, args, 42)
+    cond = synth.synth_normal((1, 64, 256), 3600)
+    with InjectRandn(3100) as inj, torch.no_grad():
+        y = d(to_t(cond), infer=True).numpy()
+    save("g5_full_dpm20", out=y, meta=np.array([1, 64, 3100, len(inj.seeds), 3600], dtype=np.int64))
+
+    # LYNXNet (acoustic.yaml-like, smaller) under DDIM and reflow euler
+    largs = dict(num_layers=3, num_channels=256, expansion_factor=2, kernel_size=31,
+                 activation="PReLU", strong_cond=True)
+    set_hp(diff_accelerator="ddim", diff_speedup=50, K_step_infer=1000)
+    d = _build_gd(128, 1, largs, 56, btype="lynxnet")
+    cond = synth.synth_normal((2, 40, 256), 3700)
+    with InjectRandn(3200) as inj, torch.no_grad():
+        y = d(to_t(cond), infer=True).numpy()
+    set_hp(sampling_algorithm="euler", sampling_steps=10)
+    r = ref_reflow.RectifiedFlow(128, 1, t_start=0.0, time_scale_factor=1000, backbone_type="lynxnet",
+                                 backbone_args=largs, spec_min=[-12.0], spec_max=[0.0])
+    load_synth(r.velocity_fn, "lynxnet", 128, 1, largs, 56)
+    with InjectRandn(3300) as inj2, torch.no_grad():
+        y2 = r(to_t(cond), infer=True).numpy()
+    save("g5_lynx", ddim20_out=y, rf_euler10_out=y2,
+         meta=np.array([2, 40, 3200, 3300, 3700, 56], dtype=np.int64))
+
+
+def g6_wrappers():
+    out = {}
+    set_hp()
+    args = dict(num_layers=1, num_channels=16, dilation_cycle_length=1)
+    rng = np.random.Generator(np.random.PCG64(7))
+    # plain GaussianDiffusion norm/denorm with per-bin spec_min/max
+    smin = (-12.0 + rng.random(32)).tolist()
+    smax = (0.0 + rng.random(32)).tolist()
+    d = ref_ddpm.GaussianDiffusion(32, 1, backbone_type="wavenet", backbone_args=args,
+                                   spec_min=smin, spec_max=smax)
+    mel = (rng.standard_normal((2, 9, 32)) * 3 - 6).astype(np.float32)
+    out["gd_smin"], out["gd_smax"], out["gd_mel"] = np.array(smin, np.float32), np.array(smax, np.float32), mel
+    out["gd_norm"] = d.norm_spec(to_t(mel)).numpy()
+    out["gd_denorm"] = d.denorm_spec(to_t(mel)).numpy()
+    # PitchDiffusion
+    p = ref_ddpm.PitchDiffusion(vmin=-8.0, vmax=8.0, cmin=-12.0, cmax=12.0, repeat_bins=64,
+                                backbone_type="wavenet", backbone_args=args)
+    pitch = (rng.standard_normal((2, 11)) * 8).astype(np.float32)
+    out["pitch_in"] = pitch
+    out["pitch_norm"] = p.norm_spec(to_t(pitch)).numpy()
+    xr = rng.standard_normal((2, 11, 64)).astype(np.float32) * 2
+    out["pitch_x"] = xr
+    out["pitch_denorm"] = p.denorm_spec(to_t(xr)).numpy()
+    # MultiVarianceDiffusion, F = 2 and F = 1
+    ranges, clamps = [(-96.0, -12.0), (-96.0, -20.0)], [(-96.0, 0.0), None]
+    m = ref_ddpm.MultiVarianceDiffusion(ranges=ranges, clamps=clamps, repeat_bins=24,
+                                        backbone_type="wavenet", backbone_args=args)
+    v0 = (rng.standard_normal((2, 11)) * 40 - 50).astype(np.float32)
+    v1 = (rng.standard_normal((2, 11)) * 40 - 50).astype(np.float32)
+    out["mv_in0"], out["mv_in1"] = v0, v1
+    out["mv_norm"] = m.norm_spec([to_t(v0), to_t(v1)]).numpy()
+    xm = rng.standard_normal((2, 2, 11, 24)).astype(np.float32) * 2
+    out["mv_x"] = xm
+    den = m.denorm_spec(to_t(xm))
+    out["mv_denorm0"], out["mv_denorm1"] = den[0].numpy(), den[1].numpy()
+    m1 = ref_ddpm.MultiVarianceDiffusion(ranges=[(-96.0, -12.0)], clamps=[(-96.0, 0.0)], repeat_bins=48,
+                                         backbone_type="wavenet", backbone_args=args)
+    out["mv1_norm"] = m1.norm_spec([to_t(v0)]).numpy()
+    xm1 = rng.standard_normal((2, 11, 48)).astype(np.float32) * 2
+    out["mv1_x"] = xm1
+    out["mv1_denorm0"] = m1.denorm_spec(to_t(xm1))[0].numpy()
+    # reflow twins share the maps; pin one
+    set_hp()
+    pr = ref_reflow.PitchRectifiedFlow(vmin=-8.0, vmax=8.0, cmin=-12.0, cmax=12.0, repeat_bins=64,
+                                       backbone_type="wavenet", backbone_args=args)
+    out["rf_pitch_norm"] = pr.norm_spec(to_t(pitch)).numpy()
+    out["rf_pitch_denorm"] = pr.denorm_spec(to_t(xr)).numpy()
+    save("g6_wrappers", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6"]
+    if "g1" in which:
+        g1_posemb()
+    if "g23" in which:
+        g2_g3_backbones()
+    if "g4" in which:
+        g4_schedules()
+    if "g5" in which:
+        g5_samplers()
+    if "g6" in which:
+        g6_wrappers()

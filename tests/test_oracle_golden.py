@@ -1,0 +1,293 @@
+"""The numpy oracle against the golden fixtures generated from the imported reference
+(tests/golden/make_golden.py).  This is what pins the oracle: SURVEY.md section 8(c), G1-G6.
+
+Tolerances are stated per test.  Reference = torch 2.10 CPU (oneDNN) fp32; oracle = numpy fp32
+(OpenBLAS); both accumulate in fp32 in different orders, so agreement is to a few 1e-6 relative
+for one backbone evaluation and degrades with the number of solver steps.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from diffsinger_amd import synth
+from oracle import backbones as ob
+from oracle import diffusion as od
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def synth_params(kind, in_dims, n_feats, args, seed, hidden=256):
+    shapes = synth.backbone_param_shapes(kind, in_dims, n_feats, hidden_size=hidden, **args)
+    return synth.synth_state_dict(shapes, seed=seed)
+
+
+# --------------------------------------------------------------------------- G1
+def test_g1_sinusoidal_pos_emb():
+    g = load("g1_posemb")
+    for dim in (256, 192, 512):
+        got_l = ob.sinusoidal_pos_emb(g["t_long"], dim)
+        got_f = ob.sinusoidal_pos_emb(g["t_float"], dim)
+        # arguments reach ~1e3 rad; one ulp of the fp32 frequency table moves sin() by ~6e-5
+        np.testing.assert_allclose(got_l, g[f"long_{dim}"], atol=2e-4, rtol=0)
+        np.testing.assert_allclose(got_f, g[f"float_{dim}"], atol=2e-4, rtol=0)
+
+
+# --------------------------------------------------------------------------- G2
+WN = {
+    "wn_acoustic": (128, 1, dict(num_layers=20, num_channels=256, dilation_cycle_length=4)),
+    "wn_pitch": (64, 1, dict(num_layers=20, num_channels=256, dilation_cycle_length=5)),
+    "wn_multivar": (24, 2, dict(num_layers=10, num_channels=192, dilation_cycle_length=4)),
+    "wn_small": (32, 1, dict(num_layers=4, num_channels=64, dilation_cycle_length=2)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WN))
+def test_g2_wavenet_single_nfe(name):
+    in_dims, n_feats, args = WN[name]
+    g = load("g2_" + name)
+    params = synth_params("wavenet", in_dims, n_feats, args, int(g["weight_seed"]))
+    assert synth.state_dict_digest(params) == str(g["digest"])
+    ci = 0
+    while f"c{ci}_meta" in g:
+        bsz, t_len, xs, cs, _ = (int(v) for v in g[f"c{ci}_meta"])
+        x = synth.synth_normal((bsz, n_feats, in_dims, t_len), xs)
+        cond = synth.synth_normal((bsz, 256, t_len), cs)
+        t = g[f"c{ci}_t"]
+        want_inter = f"c{ci}_x_after_0" in g
+        res = ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=args["dilation_cycle_length"],
+                                 return_intermediates=want_inter)
+        out, inter = res if want_inter else (res, {})
+        assert out.shape == g[f"c{ci}_out"].shape
+        # tolerance: 2e-5 of the output range for one 20-layer evaluation
+        assert rel_err(out, g[f"c{ci}_out"]) < 2e-5, (name, ci)
+        for k, v in inter.items():
+            if f"c{ci}_{k}" in g:
+                assert rel_err(v, g[f"c{ci}_{k}"]) < 2e-5, (name, ci, k)
+        ci += 1
+    assert ci > 0
+
+
+# --------------------------------------------------------------------------- G3
+LX = {
+    "lx_default": (128, 1, dict(num_layers=6, num_channels=512, expansion_factor=2, kernel_size=31,
+                                activation="PReLU", strong_cond=False)),
+    "lx_acoustic1024": (128, 1, dict(num_layers=6, num_channels=1024, expansion_factor=2, kernel_size=31,
+                                     activation="PReLU", strong_cond=True)),
+    "lx_silu": (64, 1, dict(num_layers=2, num_channels=128, expansion_factor=2, kernel_size=31,
+                            activation="SiLU", strong_cond=False)),
+    "lx_relu": (24, 2, dict(num_layers=2, num_channels=128, expansion_factor=1, kernel_size=7,
+                            activation="ReLU", strong_cond=True)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(LX))
+def test_g3_lynxnet_single_nfe(name):
+    in_dims, n_feats, args = LX[name]
+    g = load("g3_" + name)
+    params = synth_params("lynxnet", in_dims, n_feats, args, int(g["weight_seed"]))
+    assert synth.state_dict_digest(params) == str(g["digest"])
+    ci = 0
+    while f"c{ci}_meta" in g:
+        bsz, t_len, xs, cs, _ = (int(v) for v in g[f"c{ci}_meta"])
+        x = synth.synth_normal((bsz, n_feats, in_dims, t_len), xs)
+        cond = synth.synth_normal((bsz, 256, t_len), cs)
+        out = ob.lynxnet_forward(params, x, g[f"c{ci}_t"], cond, activation=args["activation"],
+                                 strong_cond=args["strong_cond"])
+        assert rel_err(out, g[f"c{ci}_out"]) < 2e-5, (name, ci)
+        ci += 1
+    assert ci > 0
+
+
+# --------------------------------------------------------------------------- G4
+def _dummy_gd(**kw):
+    return od.GaussianDiffusion(None, 32, 1, spec_min=[-12.0], spec_max=[0.0], **kw)
+
+
+def test_g4_ddpm_buffers():
+    g = load("g4_schedules")
+    d = _dummy_gd()
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+              "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+              "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+              "posterior_mean_coef2"):
+        np.testing.assert_array_equal(getattr(d, k), g[k], err_msg=k)       # float64 numpy -> fp32: bit-exact
+    dc = _dummy_gd(schedule_type="cosine")
+    np.testing.assert_array_equal(dc.betas, g["cosine_betas"])
+    np.testing.assert_array_equal(dc.alphas_cumprod, g["cosine_alphas_cumprod"])
+
+
+@pytest.mark.parametrize("tag,n_keep,steps", [("full", 1000, 50), ("full20", 1000, 20), ("shallow", 400, 20)])
+def test_g4_noise_schedule_vp(tag, n_keep, steps):
+    g = load("g4_schedules")
+    d = _dummy_gd()
+    ns = od.NoiseScheduleVP(d.betas[:n_keep], clip=True)
+    nu = od.NoiseScheduleVP(d.betas[:n_keep], clip=False)
+    # cumsum order differs between torch and numpy: a few ulp on values of magnitude <= 2.6
+    np.testing.assert_allclose(ns.log_alpha_array, g[f"{tag}_log_alpha_array"], rtol=2e-6, atol=0)
+    np.testing.assert_allclose(nu.log_alpha_array, g[f"{tag}_unipc_log_alpha_array"], rtol=2e-6, atol=0)
+    np.testing.assert_allclose(ns.t_array, g[f"{tag}_t_array"], rtol=2e-7, atol=0)
+    ts = od.torch_linspace_f32(1.0, 1.0 / ns.total_N, steps + 1)
+    np.testing.assert_allclose(ts, g[f"{tag}_timesteps"], rtol=2e-7, atol=1e-9)
+    lam = np.array([ns.marginal_lambda(t) for t in ts])
+    alpha = np.array([ns.marginal_alpha(t) for t in ts])
+    sigma = np.array([ns.marginal_std(t) for t in ts])
+    mt = np.array([ns.model_time(t) for t in ts])
+    np.testing.assert_allclose(alpha, g[f"{tag}_alpha"], rtol=3e-6)
+    # sigma / lambda are ill-conditioned in fp32 near t -> 0 (1 - exp(2 log_alpha) with log_alpha ~ -5e-5):
+    # the reference itself is only good to ~1e-3 relative there, so is any fp32 restatement.
+    np.testing.assert_allclose(sigma, g[f"{tag}_sigma"], rtol=2e-3)
+    np.testing.assert_allclose(lam, g[f"{tag}_lambda"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(mt, g[f"{tag}_model_t"], rtol=0, atol=1e-3)
+
+
+# --------------------------------------------------------------------------- G5
+SN_ARGS = dict(num_layers=4, num_channels=64, dilation_cycle_length=2)
+
+
+def _sampler_net():
+    params = synth_params("wavenet", 32, 1, SN_ARGS, 45)
+    return lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=2)
+
+
+GD_CASES = {
+    # tag: (hp, k_step, shallow, tolerance relative to the output range)
+    "ddim10": (dict(diff_accelerator="ddim", diff_speedup=10, K_step_infer=1000), 1000, False, 2e-4),
+    "ddim100": (dict(diff_accelerator="ddim", diff_speedup=100, K_step_infer=1000), 1000, False, 1e-4),
+    "pndm20": (dict(diff_accelerator="pndm", diff_speedup=20, K_step_infer=1000), 1000, False, 2e-4),
+    "dpm20": (dict(diff_accelerator="dpm-solver", diff_speedup=50, K_step_infer=1000), 1000, False, 2e-4),
+    "dpm50": (dict(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000), 1000, False, 2e-4),
+    "dpm5": (dict(diff_accelerator="dpm-solver", diff_speedup=200, K_step_infer=1000), 1000, False, 1e-4),
+    "unipc20": (dict(diff_accelerator="unipc", diff_speedup=50, K_step_infer=1000), 1000, False, 2e-4),
+    "unipc50": (dict(diff_accelerator="unipc", diff_speedup=20, K_step_infer=1000), 1000, False, 2e-4),
+    "ddpm_shallow20": (dict(diff_accelerator="ddim", diff_speedup=1, K_step_infer=20), 400, True, 1e-4),
+    "dpm_shallow": (dict(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=400), 400, True, 2e-4),
+    "ddim_shallow": (dict(diff_accelerator="ddim", diff_speedup=10, K_step_infer=200), 400, True, 1e-4),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(GD_CASES))
+def test_g5_gaussian_diffusion_samplers(tag):
+    hp, k_step, shallow, tol = GD_CASES[tag]
+    g = load("g5_samplers")
+    bsz, t_len, nseed, n_randn, _, _ = (int(v) for v in g[f"{tag}_meta"])
+    d = od.GaussianDiffusion(_sampler_net(), 32, 1, timesteps=1000, k_step=k_step, spec_min=[-12.0],
+                             spec_max=[0.0], use_shallow_diffusion=shallow)
+    cond = synth.synth_normal((bsz, t_len, 256), nseed + 500)
+    src = None
+    if shallow:
+        src = (synth.synth_normal((bsz, t_len, 32), nseed + 501) * 1.5 - 6.0).astype(np.float32)
+    noise = synth.synth_normal((bsz, 1, 32, t_len), nseed)
+    step_noise = [synth.synth_normal((bsz, 1, 32, t_len), nseed + 1 + i) for i in range(n_randn - 1)]
+    out = d.forward(cond, noise, src_spec=src, step_noise=step_noise, **hp)
+    assert out.shape == g[f"{tag}_out"].shape
+    assert rel_err(out, g[f"{tag}_out"]) < tol, tag
+
+
+RF_CASES = {
+    "rf_euler20": ("euler", 20, 0.0, False, 5e-5),
+    "rf_rk2_20": ("rk2", 20, 0.0, False, 5e-5),
+    "rf_rk4_20": ("rk4", 20, 0.0, False, 5e-5),
+    "rf_rk5_20": ("rk5", 20, 0.0, False, 5e-5),
+    "rf_euler_shallow": ("euler", 20, 0.4, True, 5e-5),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(RF_CASES))
+def test_g5_rectified_flow_samplers(tag):
+    algo, steps, t_start, shallow, tol = RF_CASES[tag]
+    g = load("g5_samplers")
+    bsz, t_len, nseed, _, _, _ = (int(v) for v in g[f"{tag}_meta"])
+    r = od.RectifiedFlow(_sampler_net(), 32, 1, t_start=t_start, time_scale_factor=1000, spec_min=[-12.0],
+                         spec_max=[0.0], use_shallow_diffusion=shallow)
+    cond = synth.synth_normal((bsz, t_len, 256), nseed + 500)
+    src = None
+    if shallow:
+        src = (synth.synth_normal((bsz, t_len, 32), nseed + 501) * 1.5 - 6.0).astype(np.float32)
+    noise = synth.synth_normal((bsz, 1, 32, t_len), nseed)
+    out = r.forward(cond, noise, src_spec=src, T_start_infer=t_start, sampling_algorithm=algo,
+                    sampling_steps=steps)
+    assert rel_err(out, g[f"{tag}_out"]) < tol, tag
+
+
+def test_g5_full_size_wavenet_dpm20():
+    g = load("g5_full_dpm20")
+    bsz, t_len, nseed, _, cseed = (int(v) for v in g["meta"])
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    params = synth_params("wavenet", 128, 1, args, 42)
+    fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=4)
+    d = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
+    out = d.forward(synth.synth_normal((bsz, t_len, 256), cseed), synth.synth_normal((bsz, 1, 128, t_len), nseed),
+                    diff_accelerator="dpm-solver", diff_speedup=50, K_step_infer=1000)
+    assert rel_err(out, g["out"]) < 2e-4
+
+
+def test_g5_lynxnet_samplers():
+    g = load("g5_lynx")
+    bsz, t_len, s_ddim, s_rf, cseed, wseed = (int(v) for v in g["meta"])
+    largs = dict(num_layers=3, num_channels=256, expansion_factor=2, kernel_size=31,
+                 activation="PReLU", strong_cond=True)
+    params = synth_params("lynxnet", 128, 1, largs, wseed)
+    fn = lambda x, t, c: ob.lynxnet_forward(params, x, t, c, activation="PReLU", strong_cond=True)
+    cond = synth.synth_normal((bsz, t_len, 256), cseed)
+    d = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
+    out = d.forward(cond, synth.synth_normal((bsz, 1, 128, t_len), s_ddim),
+                    diff_accelerator="ddim", diff_speedup=50, K_step_infer=1000)
+    assert rel_err(out, g["ddim20_out"]) < 2e-4
+    r = od.RectifiedFlow(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
+    out2 = r.forward(cond, synth.synth_normal((bsz, 1, 128, t_len), s_rf),
+                     sampling_algorithm="euler", sampling_steps=10)
+    assert rel_err(out2, g["rf_euler10_out"]) < 5e-5
+
+
+def test_unsupported_algorithms_raise():
+    d = od.GaussianDiffusion(_sampler_net(), 32, 1, spec_min=[-12.0], spec_max=[0.0])
+    x = np.zeros((1, 1, 32, 4), np.float32)
+    c = np.zeros((1, 256, 4), np.float32)
+    with pytest.raises(ValueError):
+        d.inference(c, x, diff_speedup=10, diff_accelerator="nope")
+    with pytest.raises(AssertionError):
+        d.inference(c, x, diff_speedup=7, diff_accelerator="ddim")
+    r = od.RectifiedFlow(_sampler_net(), 32, 1, spec_min=[-12.0], spec_max=[0.0])
+    with pytest.raises(ValueError):
+        r.inference(c, x, sampling_algorithm="nope")
+
+
+# --------------------------------------------------------------------------- G6
+def test_g6_norm_denorm_wrappers():
+    g = load("g6_wrappers")
+    d = od.GaussianDiffusion(None, 32, 1, spec_min=g["gd_smin"].tolist(), spec_max=g["gd_smax"].tolist())
+    np.testing.assert_allclose(d.norm_spec(g["gd_mel"]), g["gd_norm"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(d.denorm_spec(g["gd_mel"]), g["gd_denorm"], rtol=1e-6, atol=1e-5)
+
+    nf, smin, smax = od.repetitive_spec_ranges(-8.0, 8.0)
+    p = od.GaussianDiffusion(None, 64, nf, spec_min=smin, spec_max=smax)
+    np.testing.assert_allclose(od.pitch_norm(p, g["pitch_in"], 64, -12.0, 12.0), g["pitch_norm"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(od.pitch_denorm(p, g["pitch_x"], -12.0, 12.0), g["pitch_denorm"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(od.pitch_norm(p, g["pitch_in"], 64, -12.0, 12.0), g["rf_pitch_norm"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(od.pitch_denorm(p, g["pitch_x"], -12.0, 12.0), g["rf_pitch_denorm"], rtol=1e-5, atol=1e-5)
+
+    ranges, clamps = [(-96.0, -12.0), (-96.0, -20.0)], [(-96.0, 0.0), None]
+    nf, smin, smax = od.repetitive_spec_ranges([r[0] for r in ranges], [r[1] for r in ranges])
+    m = od.GaussianDiffusion(None, 24, nf, spec_min=smin, spec_max=smax)
+    np.testing.assert_allclose(od.multivar_norm(m, [g["mv_in0"], g["mv_in1"]], 24, clamps), g["mv_norm"],
+                               rtol=1e-6, atol=1e-6)
+    den = od.multivar_denorm(m, g["mv_x"], clamps)
+    np.testing.assert_allclose(den[0], g["mv_denorm0"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(den[1], g["mv_denorm1"], rtol=1e-5, atol=1e-4)
+
+    nf, smin, smax = od.repetitive_spec_ranges(-96.0, -12.0)
+    m1 = od.GaussianDiffusion(None, 48, nf, spec_min=smin, spec_max=smax)
+    np.testing.assert_allclose(od.multivar_norm(m1, [g["mv_in0"]], 48, [(-96.0, 0.0)]), g["mv1_norm"],
+                               rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(od.multivar_denorm(m1, g["mv1_x"], [(-96.0, 0.0)])[0], g["mv1_denorm0"],
+                               rtol=1e-5, atol=1e-4)
