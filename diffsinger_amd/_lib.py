@@ -1,0 +1,139 @@
+"""ctypes binding of libdsdenoise.so (include/dsdenoise.h).
+
+There is exactly one compute path: the HIP library.  If it is missing or does not load, importing
+this module raises - there is no eager / CPU fallback to fall through to.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdsdenoise.so")
+
+DSD_MAX_TERMS = 8
+DSD_MAX_OUT = 3
+DSD_SRC_MODEL = -1
+DSD_SRC_NOISE_BASE = -1000
+DSD_SAMPLE_GRAPH = 1
+DSD_SAMPLE_TRANSPOSE = 2
+BACKBONE_IDS = {"wavenet": 0, "lynxnet": 1}
+ACT_IDS = {"PReLU": 0, "SiLU": 1, "ReLU": 2}
+
+EXPORTS = [
+    "dsd_api_version", "dsd_create", "dsd_destroy", "dsd_last_error", "dsd_load_weight",
+    "dsd_finalize_weights", "dsd_prepare_cond", "dsd_denoise", "dsd_sample", "dsd_get_stats",
+    "dsd_kernel_timing", "dsd_kernel_timing_read",
+]
+
+
+class DsdConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "backbone", "in_dims", "n_feats", "num_layers", "num_channels", "hidden_size",
+        "dilation_cycle_length", "expansion_factor", "kernel_size", "activation", "strong_cond", "device")]
+
+
+class DsdTerm(C.Structure):
+    _fields_ = [("src", C.c_int32), ("coef", C.c_float)]
+
+
+class DsdLincomb(C.Structure):
+    _fields_ = [("dst", C.c_int32), ("n_terms", C.c_int32), ("terms", DsdTerm * DSD_MAX_TERMS)]
+
+
+class DsdEval(C.Structure):
+    _fields_ = [("x_buf", C.c_int32), ("t", C.c_float), ("n_out", C.c_int32), ("out", DsdLincomb * DSD_MAX_OUT)]
+
+
+class DsdProgram(C.Structure):
+    _fields_ = [("n_bufs", C.c_int32), ("result_buf", C.c_int32), ("n_evals", C.c_int32),
+                ("n_noise", C.c_int32), ("evals", C.POINTER(DsdEval))]
+
+
+class DsdStats(C.Structure):
+    _fields_ = [("weight_bytes", C.c_int64), ("workspace_bytes", C.c_int64),
+                ("flops_per_frame_nfe", C.c_int64), ("bytes_per_frame_nfe", C.c_int64),
+                ("kernels_per_nfe", C.c_int32), ("graphs_cached", C.c_int32)]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m diffsinger_amd.build_native` "
+            "(hipcc --offload-arch=gfx950). diffsinger_amd has no CPU or eager fallback.")
+    # torch ships its own libamdhip64.so.7; importing torch first makes the dynamic loader bind this
+    # library to the SAME HIP runtime instance that owns torch's device memory and streams.
+    import torch  # noqa: F401
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError(f"could not load {LIB_PATH}: {e}") from e
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.dsd_api_version.restype = C.c_int
+    lib.dsd_create.argtypes = [C.POINTER(DsdConfig), C.POINTER(vp)]
+    lib.dsd_destroy.argtypes = [vp]
+    lib.dsd_destroy.restype = None
+    lib.dsd_last_error.argtypes = [vp]
+    lib.dsd_last_error.restype = C.c_char_p
+    lib.dsd_load_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(i64), i32, i32]
+    lib.dsd_finalize_weights.argtypes = [vp]
+    lib.dsd_prepare_cond.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp]
+    lib.dsd_denoise.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.dsd_sample.argtypes = [vp, C.POINTER(DsdProgram), vp, vp, vp, vp, vp, C.c_uint32, vp]
+    lib.dsd_get_stats.argtypes = [vp, C.POINTER(DsdStats)]
+    lib.dsd_kernel_timing.argtypes = [vp, i32]
+    lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
+    for name in EXPORTS:
+        getattr(lib, name)
+    if lib.dsd_api_version() != 1:
+        raise NativeLibraryError("libdsdenoise.so API version mismatch")
+    return lib
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _load()
+    return _LIB
+
+
+def check(handle, rc, what):
+    if rc == 0:
+        return
+    msg = lib().dsd_last_error(handle).decode("utf-8", "replace")
+    raise NativeLibraryError(f"{what} failed ({rc}): {msg}")
+
+
+def program_to_c(prog):
+    """schedule.Program -> (DsdProgram, keepalive)."""
+    n = len(prog.evals)
+    arr = (DsdEval * max(n, 1))()
+    for i, ev in enumerate(prog.evals):
+        ce = arr[i]
+        ce.x_buf = ev.x_buf
+        ce.t = float(ev.t)
+        if not (1 <= len(ev.outs) <= DSD_MAX_OUT):
+            raise ValueError(f"eval {i}: {len(ev.outs)} outputs")
+        ce.n_out = len(ev.outs)
+        for o, (dst, terms) in enumerate(ev.outs):
+            if not (1 <= len(terms) <= DSD_MAX_TERMS):
+                raise ValueError(f"eval {i} out {o}: {len(terms)} terms")
+            ce.out[o].dst = dst
+            ce.out[o].n_terms = len(terms)
+            for k, (src, coef) in enumerate(terms):
+                ce.out[o].terms[k].src = src
+                ce.out[o].terms[k].coef = float(coef)
+    p = DsdProgram()
+    p.n_bufs = prog.n_bufs
+    p.result_buf = prog.result_buf
+    p.n_evals = n
+    p.n_noise = prog.n_noise
+    p.evals = C.cast(arr, C.POINTER(DsdEval))
+    return p, arr

@@ -1,0 +1,963 @@
+// libdsdenoise C-ABI (include/dsdenoise.h): handle, weight re-layout, workspace, backbone launch
+// sequences (WaveNet / LYNXNet), sampling-program executor and hipGraph cache.  gfx950 only.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dsdenoise.h"
+#include "dsd_internal.h"
+
+using namespace dsd;
+
+namespace {
+
+std::string g_create_error = "";
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+// one packed GEMM operand set on the device
+struct PackedGemm {
+    size_t a_off = 0;     // float offset into the weight blob
+    size_t bias_off = 0;  // float offset, or SIZE_MAX
+    int M = 0;            // real rows
+    int K = 0;            // padded input channels
+    int Kreal = 0;
+    int taps = 1;
+    int pairC = 0;        // > 0: paired packing with this many pairs
+};
+
+struct GraphEntry {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+}  // namespace
+
+struct dsd_handle {
+    dsd_config cfg;
+    std::string err;
+    std::map<std::string, HostTensor> raw;
+    bool finalized = false;
+
+    // packed weights
+    std::vector<float> blob_host;
+    float* blob = nullptr;
+    size_t blob_floats = 0;
+    PackedGemm g_inproj, g_emb0, g_emb1, g_dproj, g_cp, g_tail1, g_out;
+    std::vector<PackedGemm> g_conv, g_outp;          // WaveNet per layer
+    std::vector<PackedGemm> g_pw1, g_pw2;            // LYNXNet per layer
+    std::vector<size_t> dw_w, dw_b, dw_prelu;        // LYNXNet depthwise params (float offsets)
+    size_t freqs_off = 0;
+    int emb_act = ACT_MISH;
+
+    // workspace for (B, T)
+    int B = 0, T = 0, Ts = 0;
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+    float *cond_i = nullptr, *cp = nullptr, *xh = nullptr, *z = nullptr, *skip = nullptr, *hbuf = nullptr;
+    float *xin = nullptr, *ubuf = nullptr, *vbuf = nullptr, *stats = nullptr;
+    float *io_in = nullptr, *io_out = nullptr;
+    bool cond_ready = false;
+    // sampler state buffers
+    float* state = nullptr;
+    int state_nbufs = 0;
+    size_t state_buf_floats = 0;
+    // step-embedding tables (columns = steps or batch items)
+    float* emb_arena = nullptr;
+    int emb_cols = 0, Ns = 0;
+    float *t_dev = nullptr, *E = nullptr, *Hd = nullptr, *E2 = nullptr, *D = nullptr;
+    std::vector<float> t_host;
+
+    std::map<std::string, GraphEntry> graphs;
+
+    // timing of the dominant kernel
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(dsd_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_OK(h, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(h, DSD_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline int C_of(const dsd_handle* h) { return h->cfg.num_channels; }
+inline int FM_of(const dsd_handle* h) { return h->cfg.in_dims * h->cfg.n_feats; }
+inline int L_of(const dsd_handle* h) { return h->cfg.num_layers; }
+inline int inner_of(const dsd_handle* h) { return h->cfg.num_channels * h->cfg.expansion_factor; }
+inline bool is_wavenet(const dsd_handle* h) { return h->cfg.backbone == DSD_BACKBONE_WAVENET; }
+inline int cp_rows(const dsd_handle* h) { return is_wavenet(h) ? 2 * C_of(h) : C_of(h); }
+
+// ------------------------------------------------------------------------------------------
+// expected parameters (reference state_dict names and shapes)
+// ------------------------------------------------------------------------------------------
+std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params(const dsd_config& c) {
+    std::vector<std::pair<std::string, std::vector<int64_t>>> v;
+    const int64_t C = c.num_channels, M = (int64_t)c.in_dims * c.n_feats, H = c.hidden_size;
+    auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
+    add("input_projection.weight", {C, M, 1});
+    add("input_projection.bias", {C});
+    if (c.backbone == DSD_BACKBONE_WAVENET) {
+        add("mlp.0.weight", {4 * C, C});
+        add("mlp.0.bias", {4 * C});
+        add("mlp.2.weight", {C, 4 * C});
+        add("mlp.2.bias", {C});
+        for (int l = 0; l < c.num_layers; ++l) {
+            const std::string p = "residual_layers." + std::to_string(l) + ".";
+            add(p + "dilated_conv.weight", {2 * C, C, 3});
+            add(p + "dilated_conv.bias", {2 * C});
+            add(p + "diffusion_projection.weight", {C, C});
+            add(p + "diffusion_projection.bias", {C});
+            add(p + "conditioner_projection.weight", {2 * C, H, 1});
+            add(p + "conditioner_projection.bias", {2 * C});
+            add(p + "output_projection.weight", {2 * C, C, 1});
+            add(p + "output_projection.bias", {2 * C});
+        }
+        add("skip_projection.weight", {C, C, 1});
+        add("skip_projection.bias", {C});
+    } else {
+        const int64_t inner = C * c.expansion_factor;
+        add("diffusion_embedding.1.weight", {4 * C, C});
+        add("diffusion_embedding.1.bias", {4 * C});
+        add("diffusion_embedding.3.weight", {C, 4 * C});
+        add("diffusion_embedding.3.bias", {C});
+        for (int l = 0; l < c.num_layers; ++l) {
+            const std::string p = "residual_layers." + std::to_string(l) + ".";
+            add(p + "diffusion_projection.weight", {C, C, 1});
+            add(p + "diffusion_projection.bias", {C});
+            add(p + "conditioner_projection.weight", {C, H, 1});
+            add(p + "conditioner_projection.bias", {C});
+            add(p + "convmodule.net.0.weight", {C});
+            add(p + "convmodule.net.0.bias", {C});
+            add(p + "convmodule.net.2.weight", {2 * inner, C, 1});
+            add(p + "convmodule.net.2.bias", {2 * inner});
+            add(p + "convmodule.net.4.weight", {inner, 1, (int64_t)c.kernel_size});
+            add(p + "convmodule.net.4.bias", {inner});
+            if (c.activation == DSD_ACT_PRELU) add(p + "convmodule.net.5.weight", {inner});
+            add(p + "convmodule.net.6.weight", {C, inner, 1});
+            add(p + "convmodule.net.6.bias", {C});
+        }
+        add("norm.weight", {C});
+        add("norm.bias", {C});
+    }
+    add("output_projection.weight", {M, C, 1});
+    add("output_projection.bias", {M});
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing into MFMA 16x16x4 fragment order:  [mblk][tap*K16 + k16][lane][j]
+//   = W[rowmap(mblk*16 + (lane & 15))][k = k16*16 + j*4 + (lane >> 4)][tap]
+// ------------------------------------------------------------------------------------------
+using WGet = std::function<double(int row, int k, int tap)>;
+
+size_t blob_reserve(dsd_handle* h, size_t n) {
+    size_t off = (h->blob_host.size() + 63) / 64 * 64;
+    h->blob_host.resize(off + n, 0.f);
+    return off;
+}
+
+PackedGemm pack_gemm(dsd_handle* h, int M, int Kreal, int taps, int pairC, const WGet& w,
+                     const std::function<double(int)>* bias) {
+    PackedGemm g;
+    g.M = M;
+    g.Kreal = Kreal;
+    g.K = round_up(Kreal, 16);
+    g.taps = taps;
+    g.pairC = pairC;
+    const int K16 = g.K / 16;
+    const int ntile = pairC > 0 ? (pairC + 31) / 32 : (M + 63) / 64;
+    const int mblks = ntile * 4;
+    g.a_off = blob_reserve(h, (size_t)mblks * taps * K16 * 256);
+    float* dst = h->blob_host.data() + g.a_off;
+    for (int mblk = 0; mblk < mblks; ++mblk)
+        for (int kk = 0; kk < taps * K16; ++kk) {
+            const int tap = kk / K16, k16 = kk % K16;
+            float* blk = dst + ((size_t)mblk * taps * K16 + kk) * 256;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int pr = mblk * 16 + (lane & 15);
+                    const int k = k16 * 16 + j * 4 + (lane >> 4);
+                    int orig;
+                    if (pairC > 0) {
+                        const int tile = pr / 64, within = pr % 64;
+                        const int wm = within / 32, mb = (within % 32) / 16, r = within % 16;
+                        const int ch = (tile * 2 + wm) * 16 + r;
+                        orig = ch < pairC ? mb * pairC + ch : -1;
+                    } else {
+                        orig = pr < M ? pr : -1;
+                    }
+                    blk[lane * 4 + j] = (orig >= 0 && k < Kreal) ? (float)w(orig, k, tap) : 0.f;
+                }
+        }
+    g.bias_off = SIZE_MAX;
+    if (bias) {
+        g.bias_off = blob_reserve(h, (size_t)M);
+        for (int i = 0; i < M; ++i) h->blob_host[g.bias_off + i] = (float)(*bias)(i);
+    }
+    return g;
+}
+
+const HostTensor& W(dsd_handle* h, const std::string& n) { return h->raw.at(n); }
+
+int build_packed(dsd_handle* h) {
+    const dsd_config& c = h->cfg;
+    const int C = c.num_channels, M = FM_of(h), H = c.hidden_size, L = c.num_layers;
+    h->blob_host.clear();
+    // frequency table of SinusoidalPosEmb (common_layers.py:275-276)
+    h->freqs_off = blob_reserve(h, (size_t)C / 2);
+    if (h->raw.count("diffusion_embedding.freqs")) {
+        const auto& f = W(h, "diffusion_embedding.freqs").data;
+        for (int i = 0; i < C / 2; ++i) h->blob_host[h->freqs_off + i] = f[i];
+    } else {
+        const int half = C / 2;
+        const float step = -(float)(log(10000.0) / (half - 1));
+        for (int i = 0; i < half; ++i) h->blob_host[h->freqs_off + i] = expf((float)i * step);
+    }
+    auto conv1 = [&](const std::string& name) {   // Conv1d k=1 / Linear weight [M, K(,1)]
+        const HostTensor* t = &W(h, name);
+        const int64_t K = t->shape[1];
+        return WGet([t, K](int r, int k, int) { return (double)t->data[(size_t)r * K + k]; });
+    };
+    auto bias_of = [&](const std::string& name) {
+        const HostTensor* t = &W(h, name);
+        return std::function<double(int)>([t](int i) { return (double)t->data[i]; });
+    };
+    {
+        auto b = bias_of("input_projection.bias");
+        h->g_inproj = pack_gemm(h, C, M, 1, 0, conv1("input_projection.weight"), &b);
+    }
+    const bool wn = is_wavenet(h);
+    const std::string e0 = wn ? "mlp.0" : "diffusion_embedding.1";
+    const std::string e1 = wn ? "mlp.2" : "diffusion_embedding.3";
+    h->emb_act = wn ? ACT_MISH : ACT_GELU;
+    {
+        auto b0 = bias_of(e0 + ".bias");
+        h->g_emb0 = pack_gemm(h, 4 * C, C, 1, 0, conv1(e0 + ".weight"), &b0);
+        auto b1 = bias_of(e1 + ".bias");
+        h->g_emb1 = pack_gemm(h, C, 4 * C, 1, 0, conv1(e1 + ".weight"), &b1);
+    }
+    // all layers' diffusion_projection as ONE [L*C x C] GEMM over the step table
+    {
+        std::vector<const HostTensor*> ws(L), bs(L);
+        for (int l = 0; l < L; ++l) {
+            ws[l] = &W(h, "residual_layers." + std::to_string(l) + ".diffusion_projection.weight");
+            bs[l] = &W(h, "residual_layers." + std::to_string(l) + ".diffusion_projection.bias");
+        }
+        WGet w = [ws, C](int r, int k, int) { return (double)ws[r / C]->data[(size_t)(r % C) * C + k]; };
+        std::function<double(int)> b = [bs, C](int i) { return (double)bs[i / C]->data[i % C]; };
+        h->g_dproj = pack_gemm(h, L * C, C, 1, 0, w, &b);
+    }
+    // all layers' conditioner_projection as ONE [L*R x H] GEMM over cond (R = 2C WaveNet, C LYNXNet);
+    // WaveNet: the dilated conv bias is folded in here (both are added before the gate, wavenet.py:38)
+    {
+        const int R = cp_rows(h);
+        std::vector<const HostTensor*> ws(L), bs(L), b2(L, nullptr);
+        for (int l = 0; l < L; ++l) {
+            const std::string p = "residual_layers." + std::to_string(l) + ".";
+            ws[l] = &W(h, p + "conditioner_projection.weight");
+            bs[l] = &W(h, p + "conditioner_projection.bias");
+            if (wn) b2[l] = &W(h, p + "dilated_conv.bias");
+        }
+        WGet w = [ws, R, H](int r, int k, int) { return (double)ws[r / R]->data[(size_t)(r % R) * H + k]; };
+        std::function<double(int)> b = [bs, b2, R](int i) {
+            double v = bs[i / R]->data[i % R];
+            if (b2[i / R]) v += b2[i / R]->data[i % R];
+            return v;
+        };
+        h->g_cp = pack_gemm(h, L * R, H, 1, 0, w, &b);
+    }
+    if (wn) {
+        h->g_conv.resize(L);
+        h->g_outp.resize(L);
+        for (int l = 0; l < L; ++l) {
+            const std::string p = "residual_layers." + std::to_string(l) + ".";
+            const HostTensor* t = &W(h, p + "dilated_conv.weight");    // [2C, C, 3]
+            WGet w = [t, C](int r, int k, int tap) { return (double)t->data[((size_t)r * C + k) * 3 + tap]; };
+            h->g_conv[l] = pack_gemm(h, 2 * C, C, 3, C, w, nullptr);
+            auto b = bias_of(p + "output_projection.bias");
+            h->g_outp[l] = pack_gemm(h, 2 * C, C, 1, 0, conv1(p + "output_projection.weight"), &b);
+        }
+        auto b1 = bias_of("skip_projection.bias");
+        h->g_tail1 = pack_gemm(h, C, C, 1, 0, conv1("skip_projection.weight"), &b1);
+        auto b2 = bias_of("output_projection.bias");
+        h->g_out = pack_gemm(h, M, C, 1, 0, conv1("output_projection.weight"), &b2);
+    } else {
+        const int inner = inner_of(h), ks = c.kernel_size;
+        h->g_pw1.resize(L);
+        h->g_pw2.resize(L);
+        h->dw_w.resize(L);
+        h->dw_b.resize(L);
+        h->dw_prelu.assign(L, SIZE_MAX);
+        // LayerNorm affine folded into the following 1x1 conv:  W (g*n + beta) + b = (W diag g) n + (W beta + b)
+        auto fold_ln = [&](const std::string& wname, const std::string& bname, const std::string& gname,
+                           const std::string& betaname, int rows, int pairC) {
+            const HostTensor* w = &W(h, wname);
+            const HostTensor* bb = &W(h, bname);
+            const HostTensor* g = &W(h, gname);
+            const HostTensor* be = &W(h, betaname);
+            WGet wf = [w, g, C](int r, int k, int) { return (double)w->data[(size_t)r * C + k] * (double)g->data[k]; };
+            std::function<double(int)> bf = [w, bb, be, C](int r) {
+                double s = bb->data[r];
+                for (int k = 0; k < C; ++k) s += (double)w->data[(size_t)r * C + k] * (double)be->data[k];
+                return s;
+            };
+            return pack_gemm(h, rows, C, 1, pairC, wf, &bf);
+        };
+        for (int l = 0; l < L; ++l) {
+            const std::string p = "residual_layers." + std::to_string(l) + ".convmodule.net.";
+            h->g_pw1[l] = fold_ln(p + "2.weight", p + "2.bias", p + "0.weight", p + "0.bias", 2 * inner, inner);
+            auto b = bias_of(p + "6.bias");
+            h->g_pw2[l] = pack_gemm(h, C, inner, 1, 0, conv1(p + "6.weight"), &b);
+            const auto& dw = W(h, p + "4.weight").data;
+            h->dw_w[l] = blob_reserve(h, (size_t)inner * ks);
+            memcpy(h->blob_host.data() + h->dw_w[l], dw.data(), sizeof(float) * inner * ks);
+            const auto& db = W(h, p + "4.bias").data;
+            h->dw_b[l] = blob_reserve(h, (size_t)inner);
+            memcpy(h->blob_host.data() + h->dw_b[l], db.data(), sizeof(float) * inner);
+            if (c.activation == DSD_ACT_PRELU) {
+                const auto& pr = W(h, p + "5.weight").data;
+                h->dw_prelu[l] = blob_reserve(h, (size_t)inner);
+                memcpy(h->blob_host.data() + h->dw_prelu[l], pr.data(), sizeof(float) * inner);
+            }
+        }
+        h->g_out = fold_ln("output_projection.weight", "output_projection.bias", "norm.weight", "norm.bias", M, 0);
+    }
+    return DSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------
+constexpr size_t kGuard = 256;
+
+int ensure_workspace(dsd_handle* h, int B, int T) {
+    if (h->arena && h->B == B && h->T == T) return DSD_OK;
+    // shape change: drop everything that depends on it
+    for (auto& kv : h->graphs) {
+        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+    }
+    h->graphs.clear();
+    if (h->arena) hipFree(h->arena);
+    if (h->state) hipFree(h->state);
+    h->arena = nullptr;
+    h->state = nullptr;
+    h->state_nbufs = 0;
+    h->cond_ready = false;
+    const int Ts = padded_ts(T);
+    const size_t C = C_of(h), FM = FM_of(h), H = h->cfg.hidden_size, L = L_of(h);
+    size_t off = kGuard;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += (n + 63) / 64 * 64 + 64;
+        return o;
+    };
+    const size_t per = (size_t)B * Ts;
+    const size_t o_cond = take(per * H), o_cp = take(per * L * cp_rows(h)), o_xh = take(per * C);
+    const size_t o_in = take(per * FM), o_out = take(per * FM);
+    size_t o_z = 0, o_skip = 0, o_h = 0, o_xin = 0, o_u = 0, o_v = 0, o_st = 0;
+    if (is_wavenet(h)) {
+        o_z = take(per * C);
+        o_skip = take(per * C);
+        o_h = take(per * C);
+    } else {
+        o_xin = take(per * C);
+        o_u = take(per * inner_of(h));
+        o_v = take(per * inner_of(h));
+        o_st = take(per * 2);
+    }
+    off += kGuard;
+    float* a = nullptr;
+    if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
+        return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the (B=%d, T=%d) workspace failed", off * 4, B, T);
+    // padding frames and guards are masked by every consumer, but start from finite values
+    if (hipMemset(a, 0, off * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(workspace) failed");
+    h->arena = a;
+    h->arena_floats = off;
+    h->B = B; h->T = T; h->Ts = Ts;
+    h->cond_i = a + o_cond; h->cp = a + o_cp; h->xh = a + o_xh; h->io_in = a + o_in; h->io_out = a + o_out;
+    h->z = a + o_z; h->skip = a + o_skip; h->hbuf = a + o_h;
+    h->xin = a + o_xin; h->ubuf = a + o_u; h->vbuf = a + o_v; h->stats = a + o_st;
+    return DSD_OK;
+}
+
+int ensure_state(dsd_handle* h, int nbufs) {
+    if (h->state && h->state_nbufs >= nbufs) return DSD_OK;
+    if (h->state) hipFree(h->state);
+    h->state = nullptr;
+    const size_t per = ((size_t)h->B * FM_of(h) * h->Ts + 63) / 64 * 64 + 64;
+    const size_t total = kGuard * 2 + per * nbufs;
+    float* s = nullptr;
+    if (hipMalloc(&s, total * sizeof(float)) != hipSuccess)
+        return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for %d sampler state buffers failed", total * 4, nbufs);
+    if (hipMemset(s, 0, total * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(state) failed");
+    h->state = s;
+    h->state_nbufs = nbufs;
+    h->state_buf_floats = per;
+    // cached graphs captured the old pointers
+    for (auto& kv : h->graphs) {
+        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+    }
+    h->graphs.clear();
+    return DSD_OK;
+}
+inline float* state_buf(dsd_handle* h, int i) { return h->state + kGuard + h->state_buf_floats * i; }
+
+int ensure_emb(dsd_handle* h, int ncols) {
+    if (h->emb_arena && h->emb_cols >= ncols) return DSD_OK;
+    if (h->emb_arena) hipFree(h->emb_arena);
+    h->emb_arena = nullptr;
+    for (auto& kv : h->graphs) {
+        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+    }
+    h->graphs.clear();
+    const int cap = round_up(ncols, 64);
+    const int Ns = padded_ts(cap);
+    const size_t C = C_of(h), L = L_of(h);
+    size_t off = kGuard;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += (n + 63) / 64 * 64 + 64;
+        return o;
+    };
+    const size_t o_t = take(Ns), o_E = take(C * Ns), o_H = take(4 * C * Ns), o_E2 = take(C * Ns), o_D = take(L * C * Ns);
+    off += kGuard;
+    float* a = nullptr;
+    if (hipMalloc(&a, off * sizeof(float)) != hipSuccess) return fail(h, DSD_ENOMEM, "hipMalloc(step tables) failed");
+    if (hipMemset(a, 0, off * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(step tables) failed");
+    h->emb_arena = a;
+    h->emb_cols = cap;
+    h->Ns = Ns;
+    h->t_dev = a + o_t; h->E = a + o_E; h->Hd = a + o_H; h->E2 = a + o_E2; h->D = a + o_D;
+    return DSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// GEMM launch helper
+// ------------------------------------------------------------------------------------------
+struct GemmCall {
+    GemmP p;
+    int stage, taps, epi, nb, batch;
+};
+
+GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b_bstride, int b_rstride, int batch,
+                   int T, int stage, int epi, int dil) {
+    GemmCall c;
+    memset(&c.p, 0, sizeof(c.p));
+    GemmP& p = c.p;
+    p.A = h->blob + g.a_off;
+    p.bias = g.bias_off == SIZE_MAX ? nullptr : h->blob + g.bias_off;
+    p.M = g.M;
+    p.C = g.pairC;
+    p.B = Bsrc;
+    p.b_bstride = b_bstride;
+    p.b_rstride = b_rstride;
+    p.K = g.K;
+    p.Kreal = g.Kreal;
+    p.KC = g.K < 256 ? g.K : 256;
+    p.T = T;
+    p.dil = dil;
+    p.HL = g.taps == 3 ? round_up(dil, 4) : 0;
+    p.in_scale = 1.f;
+    c.stage = stage;
+    c.taps = g.taps;
+    c.epi = epi;
+    c.batch = batch;
+    // tile width: 64 frames when that still fills the chip twice over, else 32
+    const int mtiles = g.pairC > 0 ? (g.pairC + 31) / 32 : (g.M + 63) / 64;
+    const long wg64 = (long)batch * ((T + 63) / 64) * mtiles;
+    c.nb = wg64 >= 512 ? 2 : 1;
+    const int BN = 32 * c.nb;
+    p.tiles_per_b = (T + BN - 1) / BN;
+    int S = BN + 2 * p.HL;
+    while (S % 32 != 16) S += 4;
+    p.S = S;
+    return c;
+}
+
+int run_gemm(dsd_handle* h, const GemmCall& c, hipStream_t st) {
+    hipError_t e = launch_gemm(c.p, c.stage, c.taps, c.epi, c.nb, c.batch, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "GEMM launch failed: %s", hipGetErrorString(e));
+    return DSD_OK;
+}
+
+// step tables: E = sinemb(t) -> Hd = act(W0 E + b0) -> E2 = W1 Hd + b1 -> D[l*C + c][col] = Wd_l E2 + bd_l
+int run_step_tables(dsd_handle* h, int ncols, hipStream_t st) {
+    const int C = C_of(h), Ns = h->Ns;
+    hipError_t e = launch_sinemb(h->t_dev, ncols, Ns, h->blob + h->freqs_off, C, h->E, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "sinemb launch failed: %s", hipGetErrorString(e));
+    GemmCall g0 = make_gemm(h, h->g_emb0, h->E, 0, Ns, 1, ncols, ST_PLAIN, EP_BIAS_ACT, 0);
+    g0.p.act = h->emb_act; g0.p.out = h->Hd; g0.p.o_bstride = 0; g0.p.o_rstride = Ns;
+    int rc = run_gemm(h, g0, st);
+    if (rc) return rc;
+    GemmCall g1 = make_gemm(h, h->g_emb1, h->Hd, 0, Ns, 1, ncols, ST_PLAIN, EP_BIAS_ACT, 0);
+    g1.p.act = ACT_NONE; g1.p.out = h->E2; g1.p.o_rstride = Ns;
+    rc = run_gemm(h, g1, st);
+    if (rc) return rc;
+    GemmCall g2 = make_gemm(h, h->g_dproj, h->E2, 0, Ns, 1, ncols, ST_PLAIN, EP_BIAS_ACT, 0);
+    g2.p.act = ACT_NONE; g2.p.out = h->D; g2.p.o_rstride = Ns;
+    return run_gemm(h, g2, st);
+}
+
+// One backbone evaluation on the internal-layout input `xin_state` ([B][F*M][Ts]); the last GEMM's
+// epilogue writes the `nout` linear combinations `lo` (LinTerm.ptr == nullptr = model output).
+int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_colb, const LinOut* lo, int nout,
+                 hipStream_t st) {
+    const int B = h->B, T = h->T, Ts = h->Ts, C = C_of(h), FM = FM_of(h), L = L_of(h), Ns = h->Ns;
+    const long xs = (long)C * Ts;
+    int rc;
+    auto timed_begin = [&]() {
+        if (!h->timing) return;
+        if (h->ev_used == h->ev_pool.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            h->ev_pool.emplace_back(a, b);
+        }
+        hipEventRecord(h->ev_pool[h->ev_used].first, st);
+    };
+    auto timed_end = [&]() {
+        if (!h->timing) return;
+        hipEventRecord(h->ev_pool[h->ev_used].second, st);
+        ++h->ev_used;
+    };
+    {   // input projection (+ReLU for WaveNet, wavenet.py:86-88; GELU unless strong_cond for LYNXNet, lynxnet.py:141-143)
+        GemmCall g = make_gemm(h, h->g_inproj, xin_state, (long)FM * Ts, Ts, B, T, ST_PLAIN, EP_BIAS_ACT, 0);
+        g.p.act = is_wavenet(h) ? ACT_RELU : (h->cfg.strong_cond ? ACT_NONE : ACT_GELU);
+        g.p.out = h->xh; g.p.o_bstride = xs; g.p.o_rstride = Ts;
+        if ((rc = run_gemm(h, g, st))) return rc;
+    }
+    if (is_wavenet(h)) {
+        const long cps = (long)L * 2 * C * Ts;
+        for (int l = 0; l < L; ++l) {
+            const int dil = 1 << (l % h->cfg.dilation_cycle_length);
+            GemmCall g = make_gemm(h, h->g_conv[l], h->xh, xs, Ts, B, T, ST_FILM, EP_GATE, dil);
+            g.p.film = h->D + (long)l * C * Ns; g.p.film_cstride = Ns; g.p.film_col0 = film_col0; g.p.film_colb = film_colb;
+            g.p.aux = h->cp + (long)l * 2 * C * Ts; g.p.aux_bstride = cps; g.p.aux_rstride = Ts;
+            g.p.out = h->z; g.p.o_bstride = xs; g.p.o_rstride = Ts;
+            timed_begin();
+            rc = run_gemm(h, g, st);
+            timed_end();
+            if (rc) return rc;
+            GemmCall o = make_gemm(h, h->g_outp[l], h->z, xs, Ts, B, T, ST_PLAIN, EP_RESSKIP, 0);
+            o.p.C = C; o.p.x = h->xh; o.p.skip = h->skip; o.p.first_layer = (l == 0);
+            o.p.o_bstride = xs; o.p.o_rstride = Ts;
+            if ((rc = run_gemm(h, o, st))) return rc;
+        }
+        GemmCall t1 = make_gemm(h, h->g_tail1, h->skip, xs, Ts, B, T, ST_PLAIN, EP_BIAS_ACT, 0);
+        t1.p.in_scale = sqrtf((float)L);      // staged value is DIVIDED by in_scale (wavenet.py:96)
+        t1.p.act = ACT_RELU; t1.p.out = h->hbuf; t1.p.o_bstride = xs; t1.p.o_rstride = Ts;
+        if ((rc = run_gemm(h, t1, st))) return rc;
+        GemmCall t2 = make_gemm(h, h->g_out, h->hbuf, xs, Ts, B, T, ST_PLAIN, EP_LINCOMB, 0);
+        t2.p.nout = nout;
+        for (int i = 0; i < nout; ++i) t2.p.lo[i] = lo[i];
+        t2.p.o_bstride = (long)FM * Ts; t2.p.o_rstride = Ts;
+        return run_gemm(h, t2, st);
+    }
+    // ---- LYNXNet (lynxnet.py:76-87, 145-154) ----
+    const int inner = inner_of(h);
+    const long cps = (long)L * C * Ts, us = (long)inner * Ts;
+    hipError_t e;
+    for (int l = 0; l < L; ++l) {
+        e = launch_lynx_pre(h->xh, h->xin, h->cp + (long)l * C * Ts, cps, h->D + (long)l * C * Ns, Ns, film_col0,
+                            film_colb, xs, Ts, C, B, T, h->cfg.strong_cond, h->stats, Ts, st);
+        if (e != hipSuccess) return fail(h, DSD_EHIP, "lynx_pre launch failed: %s", hipGetErrorString(e));
+        GemmCall g = make_gemm(h, h->g_pw1[l], h->xin, xs, Ts, B, T, ST_LN, EP_SWIGLU, 0);
+        g.p.ln_stats = h->stats; g.p.ln_ts = Ts;
+        g.p.out = h->ubuf; g.p.o_bstride = us; g.p.o_rstride = Ts;
+        timed_begin();
+        rc = run_gemm(h, g, st);
+        timed_end();
+        if (rc) return rc;
+        e = launch_dwconv(h->ubuf, h->vbuf, us, Ts, inner, B, T, h->blob + h->dw_w[l], h->blob + h->dw_b[l],
+                          h->cfg.kernel_size, h->cfg.activation,
+                          h->dw_prelu[l] == SIZE_MAX ? nullptr : h->blob + h->dw_prelu[l], st);
+        if (e != hipSuccess) return fail(h, DSD_EHIP, "dwconv launch failed: %s", hipGetErrorString(e));
+        GemmCall o = make_gemm(h, h->g_pw2[l], h->vbuf, us, Ts, B, T, ST_PLAIN, EP_BIAS_RES, 0);
+        o.p.aux = h->xh; o.p.aux_bstride = xs; o.p.aux_rstride = Ts;
+        o.p.out = h->xh; o.p.o_bstride = xs; o.p.o_rstride = Ts;
+        if ((rc = run_gemm(h, o, st))) return rc;
+    }
+    e = launch_lynx_pre(h->xh, nullptr, nullptr, 0, nullptr, 0, 0, 0, xs, Ts, C, B, T, 0, h->stats, Ts, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "final LayerNorm stats launch failed: %s", hipGetErrorString(e));
+    GemmCall f = make_gemm(h, h->g_out, h->xh, xs, Ts, B, T, ST_LN, EP_LINCOMB, 0);
+    f.p.ln_stats = h->stats; f.p.ln_ts = Ts;
+    f.p.nout = nout;
+    for (int i = 0; i < nout; ++i) f.p.lo[i] = lo[i];
+    f.p.o_bstride = (long)FM * Ts; f.p.o_rstride = Ts;
+    return run_gemm(h, f, st);
+}
+
+void destroy_graphs(dsd_handle* h) {
+    for (auto& kv : h->graphs) {
+        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+    }
+    h->graphs.clear();
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int dsd_api_version(void) { return DSD_API_VERSION; }
+
+const char* dsd_last_error(const dsd_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dsd_create(const dsd_config* cfg, dsd_handle** out) {
+    if (!cfg || !out) return fail(nullptr, DSD_EINVAL, "dsd_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(dsd_config))
+        return fail(nullptr, DSD_EINVAL, "dsd_create: struct_size %d != %zu", cfg->struct_size, sizeof(dsd_config));
+    if (cfg->backbone != DSD_BACKBONE_WAVENET && cfg->backbone != DSD_BACKBONE_LYNXNET)
+        return fail(nullptr, DSD_EINVAL, "dsd_create: unknown backbone %d", cfg->backbone);
+    if (cfg->in_dims < 1 || cfg->n_feats < 1 || cfg->num_layers < 1 || cfg->hidden_size < 1)
+        return fail(nullptr, DSD_EINVAL, "dsd_create: non-positive dimension");
+    if (cfg->num_channels < 32 || cfg->num_channels % 32 != 0)
+        return fail(nullptr, DSD_EINVAL, "dsd_create: num_channels must be a positive multiple of 32 (got %d)",
+                    cfg->num_channels);
+    if (cfg->backbone == DSD_BACKBONE_WAVENET) {
+        if (cfg->dilation_cycle_length < 1 || cfg->dilation_cycle_length > 8)
+            return fail(nullptr, DSD_EINVAL, "dsd_create: dilation_cycle_length must be in [1, 8]");
+    } else {
+        if (cfg->expansion_factor < 1 || cfg->kernel_size < 1 || cfg->kernel_size % 2 == 0 || cfg->kernel_size > 63)
+            return fail(nullptr, DSD_EINVAL, "dsd_create: LYNXNet needs expansion_factor >= 1 and odd kernel_size <= 63");
+        if ((cfg->num_channels * cfg->expansion_factor) % 32 != 0)
+            return fail(nullptr, DSD_EINVAL, "dsd_create: num_channels * expansion_factor must be a multiple of 32");
+        if (cfg->activation < DSD_ACT_PRELU || cfg->activation > DSD_ACT_RELU)
+            return fail(nullptr, DSD_EINVAL, "dsd_create: %d is not a valid activation", cfg->activation);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, DSD_EHIP, "dsd_create: no HIP device is visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, DSD_EINVAL, "dsd_create: device %d out of range [0, %d)", cfg->device, ndev);
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: hipSetDevice failed");
+    hipError_t ie = gemm_init_all();
+    if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
+    dsd_handle* h = new dsd_handle();
+    h->cfg = *cfg;
+    *out = h;
+    return DSD_OK;
+}
+
+void dsd_destroy(dsd_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    destroy_graphs(h);
+    for (auto& ev : h->ev_pool) {
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+    }
+    if (h->blob) hipFree(h->blob);
+    if (h->arena) hipFree(h->arena);
+    if (h->state) hipFree(h->state);
+    if (h->emb_arena) hipFree(h->emb_arena);
+    delete h;
+}
+
+int dsd_load_weight(dsd_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim,
+                    int32_t on_device) {
+    if (!h || !name || !data || !shape || ndim < 1 || ndim > 4) return fail(h, DSD_EINVAL, "dsd_load_weight: bad argument");
+    const std::string n(name);
+    std::vector<int64_t> shp(shape, shape + ndim);
+    bool found = false;
+    if (n == "diffusion_embedding.freqs") {
+        if (ndim != 1 || shp[0] != h->cfg.num_channels / 2)
+            return fail(h, DSD_EINVAL, "diffusion_embedding.freqs must have shape [%d]", h->cfg.num_channels / 2);
+        found = true;
+    } else {
+        for (auto& e : expected_params(h->cfg)) {
+            if (e.first != n) continue;
+            if (e.second != shp) {
+                std::string want, got;
+                for (auto v : e.second) want += std::to_string(v) + ",";
+                for (auto v : shp) got += std::to_string(v) + ",";
+                return fail(h, DSD_EINVAL, "size mismatch for %s: expected [%s] got [%s]", name, want.c_str(), got.c_str());
+            }
+            found = true;
+            break;
+        }
+    }
+    if (!found) return fail(h, DSD_ENOTFOUND, "unexpected key in state_dict: %s", name);
+    size_t numel = 1;
+    for (auto v : shp) numel *= (size_t)v;
+    HostTensor t;
+    t.shape = shp;
+    t.data.resize(numel);
+    if (on_device) {
+        HIP_OK(h, hipSetDevice(h->cfg.device));
+        HIP_OK(h, hipMemcpy(t.data.data(), data, numel * sizeof(float), hipMemcpyDeviceToHost));
+    } else {
+        memcpy(t.data.data(), data, numel * sizeof(float));
+    }
+    h->raw[n] = std::move(t);
+    h->finalized = false;
+    return DSD_OK;
+}
+
+int dsd_finalize_weights(dsd_handle* h) {
+    if (!h) return DSD_EINVAL;
+    std::string missing;
+    for (auto& e : expected_params(h->cfg))
+        if (!h->raw.count(e.first)) missing += (missing.empty() ? "" : ", ") + e.first;
+    if (!missing.empty()) return fail(h, DSD_ESTATE, "missing keys in state_dict: %s", missing.c_str());
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    int rc = build_packed(h);
+    if (rc) return rc;
+    destroy_graphs(h);
+    if (h->blob) hipFree(h->blob);
+    h->blob = nullptr;
+    h->blob_floats = h->blob_host.size() + 1024;     // tail guard: A prefetch never runs past it
+    if (hipMalloc(&h->blob, h->blob_floats * sizeof(float)) != hipSuccess)
+        return fail(h, DSD_ENOMEM, "hipMalloc(%zu bytes of packed weights) failed", h->blob_floats * 4);
+    HIP_OK(h, hipMemset(h->blob, 0, h->blob_floats * sizeof(float)));
+    HIP_OK(h, hipMemcpy(h->blob, h->blob_host.data(), h->blob_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float>().swap(h->blob_host);
+    h->finalized = true;
+    h->cond_ready = false;
+    return DSD_OK;
+}
+
+int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64_t stride_b, int64_t stride_h,
+                     int64_t stride_t, void* stream) {
+    if (!h || !cond) return fail(h, DSD_EINVAL, "dsd_prepare_cond: null argument");
+    if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_prepare_cond: weights are not finalized");
+    if (B < 1 || T < 1) return fail(h, DSD_EINVAL, "dsd_prepare_cond: B and T must be positive (B=%d, T=%d)", B, T);
+    if (stride_t != 1 && stride_h != 1)
+        return fail(h, DSD_EINVAL, "dsd_prepare_cond: cond must be contiguous along T ([B,H,T]) or along H ([B,T,H])");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_workspace(h, B, T);
+    if (rc) return rc;
+    const int H = h->cfg.hidden_size, Ts = h->Ts, L = L_of(h), R = cp_rows(h);
+    hipError_t e = launch_pack(cond, stride_b, stride_h, stride_t, h->cond_i, B, H, T, Ts, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "pack(cond) launch failed: %s", hipGetErrorString(e));
+    GemmCall g = make_gemm(h, h->g_cp, h->cond_i, (long)H * Ts, Ts, B, T, ST_PLAIN, EP_BIAS_ACT, 0);
+    g.p.act = ACT_NONE;
+    g.p.out = h->cp; g.p.o_bstride = (long)L * R * Ts; g.p.o_rstride = Ts;
+    rc = run_gemm(h, g, st);
+    if (rc) return rc;
+    h->cond_ready = true;
+    return DSD_OK;
+}
+
+int dsd_denoise(dsd_handle* h, const float* x, const float* t, int32_t t_len, float* out, void* stream) {
+    if (!h || !x || !t || !out) return fail(h, DSD_EINVAL, "dsd_denoise: null argument");
+    if (!h->cond_ready) return fail(h, DSD_ESTATE, "dsd_denoise: call dsd_prepare_cond first");
+    if (x == out) return fail(h, DSD_EINVAL, "dsd_denoise: out must not alias x");
+    if (t_len != 1 && t_len != h->B) return fail(h, DSD_EINVAL, "dsd_denoise: t_len must be 1 or B=%d (got %d)", h->B, t_len);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    const int B = h->B, T = h->T, Ts = h->Ts, FM = FM_of(h);
+    int rc = ensure_emb(h, t_len);
+    if (rc) return rc;
+    HIP_OK(h, hipMemcpyAsync(h->t_dev, t, sizeof(float) * t_len, hipMemcpyDeviceToDevice, st));
+    if ((rc = run_step_tables(h, t_len, st))) return rc;
+    hipError_t e = launch_pack(x, (long)FM * T, T, 1, h->io_in, B, FM, T, Ts, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "pack(x) launch failed: %s", hipGetErrorString(e));
+    LinOut lo;
+    memset(&lo, 0, sizeof(lo));
+    lo.dst = h->io_out;
+    lo.nterms = 1;
+    lo.t[0].ptr = nullptr;
+    lo.t[0].coef = 1.f;
+    rc = run_backbone(h, h->io_in, 0, t_len == 1 ? 0 : 1, &lo, 1, st);
+    if (rc) return rc;
+    e = launch_unpack(h->io_out, Ts, out, B, h->cfg.n_feats, h->cfg.in_dims, T, 0, nullptr, nullptr, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "unpack launch failed: %s", hipGetErrorString(e));
+    return DSD_OK;
+}
+
+int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, const float* noise, float* out,
+               const float* out_scale, const float* out_shift, uint32_t flags, void* stream) {
+    if (!h || !prog || !x_init || !out) return fail(h, DSD_EINVAL, "dsd_sample: null argument");
+    if (!h->cond_ready) return fail(h, DSD_ESTATE, "dsd_sample: call dsd_prepare_cond first");
+    if (prog->n_bufs < 1 || prog->n_bufs > 64 || prog->n_evals < 0 || (prog->n_evals > 0 && !prog->evals))
+        return fail(h, DSD_EINVAL, "dsd_sample: malformed program");
+    if (prog->result_buf < 0 || prog->result_buf >= prog->n_bufs) return fail(h, DSD_EINVAL, "dsd_sample: bad result_buf");
+    if (prog->n_noise > 0 && !noise) return fail(h, DSD_EINVAL, "dsd_sample: program references noise but noise == NULL");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    const int B = h->B, T = h->T, Ts = h->Ts, FM = FM_of(h);
+    // validate the program before anything is launched
+    for (int i = 0; i < prog->n_evals; ++i) {
+        const dsd_eval& ev = prog->evals[i];
+        if (ev.x_buf < 0 || ev.x_buf >= prog->n_bufs) return fail(h, DSD_EINVAL, "eval %d: bad x_buf %d", i, ev.x_buf);
+        if (ev.n_out < 1 || ev.n_out > DSD_MAX_OUT) return fail(h, DSD_EINVAL, "eval %d: bad n_out %d", i, ev.n_out);
+        for (int o = 0; o < ev.n_out; ++o) {
+            const dsd_lincomb& lc = ev.out[o];
+            if (lc.dst < 0 || lc.dst >= prog->n_bufs) return fail(h, DSD_EINVAL, "eval %d out %d: bad dst %d", i, o, lc.dst);
+            if (lc.n_terms < 1 || lc.n_terms > DSD_MAX_TERMS) return fail(h, DSD_EINVAL, "eval %d out %d: bad n_terms", i, o);
+            for (int k = 0; k < lc.n_terms; ++k) {
+                const int s = lc.terms[k].src;
+                const bool ok = (s >= 0 && s < prog->n_bufs) || s == DSD_SRC_MODEL ||
+                                (s <= DSD_SRC_NOISE_BASE && DSD_SRC_NOISE_BASE - s < prog->n_noise);
+                if (!ok) return fail(h, DSD_EINVAL, "eval %d out %d term %d: bad src %d", i, o, k, s);
+            }
+        }
+    }
+    int rc = ensure_state(h, prog->n_bufs);
+    if (rc) return rc;
+    if (prog->n_evals > 0 && (rc = ensure_emb(h, prog->n_evals))) return rc;
+
+    // x_T (or the shallow-diffusion start) -> state buffer 0
+    hipError_t e = launch_pack(x_init, (long)FM * T, T, 1, state_buf(h, 0), B, FM, T, Ts, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "pack(x_init) launch failed: %s", hipGetErrorString(e));
+
+    if (prog->n_evals > 0) {
+        h->t_host.resize(prog->n_evals);
+        for (int i = 0; i < prog->n_evals; ++i) h->t_host[i] = prog->evals[i].t;
+        HIP_OK(h, hipMemcpyAsync(h->t_dev, h->t_host.data(), sizeof(float) * prog->n_evals, hipMemcpyHostToDevice, st));
+    }
+
+    const long ext_b = (long)FM * T;
+    auto body = [&](hipStream_t s) -> int {
+        int r = DSD_OK;
+        if (prog->n_evals > 0 && (r = run_step_tables(h, prog->n_evals, s))) return r;
+        for (int i = 0; i < prog->n_evals; ++i) {
+            const dsd_eval& ev = prog->evals[i];
+            LinOut lo[kMaxOut];
+            memset(lo, 0, sizeof(lo));
+            for (int o = 0; o < ev.n_out; ++o) {
+                lo[o].dst = state_buf(h, ev.out[o].dst);
+                lo[o].nterms = ev.out[o].n_terms;
+                for (int k = 0; k < ev.out[o].n_terms; ++k) {
+                    const dsd_term& tm = ev.out[o].terms[k];
+                    LinTerm& lt = lo[o].t[k];
+                    lt.coef = tm.coef;
+                    if (tm.src == DSD_SRC_MODEL) {
+                        lt.ptr = nullptr;
+                    } else if (tm.src >= 0) {
+                        lt.ptr = state_buf(h, tm.src);
+                        lt.bstride = (long)FM * Ts;
+                        lt.rstride = Ts;
+                    } else {
+                        lt.ptr = noise + (long)(DSD_SRC_NOISE_BASE - tm.src) * B * ext_b;
+                        lt.bstride = ext_b;
+                        lt.rstride = T;
+                        lt.ext = 1;
+                    }
+                }
+            }
+            if ((r = run_backbone(h, state_buf(h, ev.x_buf), i, 0, lo, ev.n_out, s))) return r;
+        }
+        return r;
+    };
+
+    const bool use_graph = (flags & DSD_SAMPLE_GRAPH) && !h->timing && prog->n_evals > 0;
+    if (!use_graph) {
+        if ((rc = body(st))) return rc;
+    } else {
+        // key: program bytes + noise pointer (baked into kernel arguments)
+        std::string key((const char*)prog->evals, sizeof(dsd_eval) * prog->n_evals);
+        key.append((const char*)&prog->n_bufs, sizeof(int32_t));
+        key.append((const char*)&noise, sizeof(noise));
+        auto it = h->graphs.find(key);
+        if (it == h->graphs.end()) {
+            hipStream_t cs = nullptr;
+            HIP_OK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            hipError_t ce = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+            if (ce != hipSuccess) {
+                hipStreamDestroy(cs);
+                return fail(h, DSD_EHIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(ce));
+            }
+            rc = body(cs);
+            GraphEntry ge;
+            ce = hipStreamEndCapture(cs, &ge.graph);
+            hipStreamDestroy(cs);
+            if (rc) {
+                if (ge.graph) hipGraphDestroy(ge.graph);
+                return rc;
+            }
+            if (ce != hipSuccess) return fail(h, DSD_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            ce = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0);
+            if (ce != hipSuccess) {
+                hipGraphDestroy(ge.graph);
+                return fail(h, DSD_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ce));
+            }
+            if (h->graphs.size() >= 16) destroy_graphs(h);
+            it = h->graphs.emplace(key, ge).first;
+        }
+        HIP_OK(h, hipGraphLaunch(it->second.exec, st));
+    }
+    e = launch_unpack(state_buf(h, prog->result_buf), Ts, out, B, h->cfg.n_feats, h->cfg.in_dims, T,
+                      (flags & DSD_SAMPLE_TRANSPOSE) ? 1 : 0, (flags & DSD_SAMPLE_TRANSPOSE) ? out_scale : nullptr,
+                      (flags & DSD_SAMPLE_TRANSPOSE) ? out_shift : nullptr, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "unpack launch failed: %s", hipGetErrorString(e));
+    return DSD_OK;
+}
+
+int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
+    if (!h || !out) return DSD_EINVAL;
+    memset(out, 0, sizeof(*out));
+    const int64_t C = C_of(h), M = FM_of(h), L = L_of(h);
+    out->weight_bytes = (int64_t)h->blob_floats * 4;
+    out->workspace_bytes = (int64_t)h->arena_floats * 4;
+    if (is_wavenet(h)) {
+        // 2*(M*C + L*(3*C*2C + C*2C) + C*C + C*M); bytes L*24C + 2*4*M
+        out->flops_per_frame_nfe = 2 * (M * C + L * (3 * C * 2 * C + C * 2 * C) + C * C + C * M);
+        out->bytes_per_frame_nfe = L * 24 * C + 8 * M;
+        out->kernels_per_nfe = 1 + 2 * (int)L + 2;
+    } else {
+        const int64_t inner = inner_of(h), ks = h->cfg.kernel_size;
+        out->flops_per_frame_nfe = 2 * (M * C + L * (C * 2 * inner + ks * inner + inner * C) + C * M);
+        out->bytes_per_frame_nfe = L * 12 * C + 8 * M;
+        out->kernels_per_nfe = 1 + 4 * (int)L + 2;
+    }
+    out->graphs_cached = (int)h->graphs.size();
+    return DSD_OK;
+}
+
+int dsd_kernel_timing(dsd_handle* h, int32_t enable) {
+    if (!h) return DSD_EINVAL;
+    h->timing = enable != 0;
+    h->ev_used = 0;
+    return DSD_OK;
+}
+
+int dsd_kernel_timing_read(dsd_handle* h, double* mean_ms, int64_t* launches) {
+    if (!h || !mean_ms || !launches) return DSD_EINVAL;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    double sum = 0;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        HIP_OK(h, hipEventSynchronize(h->ev_pool[i].second));
+        float ms = 0.f;
+        HIP_OK(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+        sum += ms;
+    }
+    *launches = (int64_t)h->ev_used;
+    *mean_ms = h->ev_used ? sum / (double)h->ev_used : 0.0;
+    h->ev_used = 0;
+    return DSD_OK;
+}
+
+}  // extern "C"

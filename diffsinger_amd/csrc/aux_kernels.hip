@@ -1,0 +1,256 @@
+// Non-GEMM kernels of the denoiser path (gfx950): layout conversion at the boundary, the sinusoidal
+// step embedding, LYNXNet's LayerNorm statistics and its depthwise k=31 convolution.
+// All of them are HBM/L2-bound streaming kernels: 64-wide wavefronts run along the time axis so
+// that every global access is a contiguous 256-B row segment.
+#include "dsd_internal.h"
+
+namespace dsd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// pack: caller tensor (element (b, r, t) at src[b*sb + r*sr + t*st]) -> internal [B][R][Ts].
+// A 32x32 tile goes through LDS so that both the [B,R,T] (st == 1) and the [B,T,R] (sr == 1)
+// caller layouts are read with their contiguous axis on the lanes.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, long sb, long sr, long st,
+                                                   float* __restrict__ dst, int R, int T, int Ts) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
+    const float* s = src + (long)b * sb;
+    if (st == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + ly + i * 8, t = t0 + lx;
+            tile[ly + i * 8][lx] = (r < R && t < T) ? s[(long)r * sr + t] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = t0 + ly + i * 8, r = r0 + lx;
+            tile[lx][ly + i * 8] = (r < R && t < T) ? s[(long)r * sr + (long)t * st] : 0.f;
+        }
+    }
+    __syncthreads();
+    float* d = dst + (long)b * R * Ts;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ly + i * 8, t = t0 + lx;
+        if (r < R && t < Ts) d[(long)r * Ts + t] = tile[ly + i * 8][lx];
+    }
+}
+
+hipError_t launch_pack(const float* src, long sb, long sr, long st, float* dst, int B, int R, int T, int Ts,
+                       hipStream_t stream) {
+    dim3 grid((round_up(T, 32)) / 32, (R + 31) / 32, B);
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, src, sb, sr, st, dst, R, T, Ts);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// unpack: internal [B][F*M][Ts] -> caller [B,F,M,T] (transpose == 0) or [B,F,T,M] with the
+// per-bin affine of denorm_spec (ddpm.py:350,382-383): out = x * scale[f*M+m] + shift[f*M+m].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ src, int Ts, float* __restrict__ dst,
+                                                     int F, int M, int T, int transpose,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z / F, f = blockIdx.z % F;
+    const int m0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const float* s = src + ((long)b * F + f) * M * Ts;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ly + i * 8, t = t0 + lx;
+        float v = 0.f;
+        if (m < M && t < T) {
+            v = s[(long)m * Ts + t];
+            if (scale) v = v * scale[f * M + m];
+            if (shift) v = v + shift[f * M + m];
+        }
+        tile[ly + i * 8][lx] = v;
+    }
+    __syncthreads();
+    float* d = dst + ((long)b * F + f) * M * T;
+    if (!transpose) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ly + i * 8, t = t0 + lx;
+            if (m < M && t < T) d[(long)m * T + t] = tile[ly + i * 8][lx];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = t0 + ly + i * 8, m = m0 + lx;
+            if (m < M && t < T) d[(long)t * M + m] = tile[lx][ly + i * 8];
+        }
+    }
+}
+
+hipError_t launch_unpack(const float* src, int Ts, float* dst, int B, int F, int M, int T, int transpose,
+                         const float* scale, const float* shift, hipStream_t stream) {
+    dim3 grid((T + 31) / 32, (M + 31) / 32, B * F);
+    hipLaunchKernelGGL(unpack_kernel, grid, dim3(256), 0, stream, src, Ts, dst, F, M, T, transpose, scale, shift);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// SinusoidalPosEmb (common_layers.py:273-280) for `ncols` step values at once:
+//   dst[i][col] = sin(t[col] * f_i),  dst[C/2 + i][col] = cos(t[col] * f_i)
+// written as a [C][colstride] matrix (columns = steps), i.e. already the B operand of the MLP GEMM.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sinemb_kernel(const float* __restrict__ t, int ncols, int colstride,
+                                                     const float* __restrict__ freqs, int C, float* __restrict__ dst) {
+    const int half = C >> 1;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= half * colstride) return;
+    const int i = idx / colstride, col = idx - i * colstride;
+    float s = 0.f, c = 0.f;
+    if (col < ncols) {
+        const float arg = t[col] * freqs[i];     // fp32 product first, as the reference does
+        s = sinf(arg);
+        c = cosf(arg);
+    }
+    dst[(long)i * colstride + col] = s;
+    dst[(long)(half + i) * colstride + col] = c;
+}
+
+hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const float* freqs, int C, float* dst,
+                         hipStream_t stream) {
+    const int n = (C / 2) * colstride;
+    hipLaunchKernelGGL(sinemb_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, t_dev, ncols, colstride, freqs, C,
+                       dst);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LYNXNet layer prologue (lynxnet.py:76-84) + LayerNorm statistics (lynxnet.py:53, :151):
+//   strong_cond:   x <- x + cp ;  xin = x + d          (residual taken AFTER the conditioner add)
+//   otherwise:     xin = x + cp + d                    (residual = untouched x)
+//   stats[b][0][t] = mean_c xin,  stats[b][1][t] = 1/sqrt(var_c xin + 1e-5)   (biased variance)
+// One workgroup owns 64 frames x all channels; lanes run along time (256-B row segments), the
+// channel reduction is a register loop per wave followed by a 4-wave LDS combine.  Two passes
+// (mean, then centred second moment) like torch's LayerNorm; the second pass re-reads the tile
+// this workgroup just wrote (L2-resident).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lynx_pre_kernel(float* __restrict__ x, float* __restrict__ xin,
+                                                       const float* __restrict__ cp, long cp_bstride,
+                                                       const float* __restrict__ film, int film_cstride,
+                                                       int film_col0, int film_colb, long bstride, int rstride, int C,
+                                                       int T, int strong, float* __restrict__ stats, int ts) {
+    __shared__ float red[4][64];
+    __shared__ float mean_s[64];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    float* xb = x + (long)b * bstride;
+    float* xi = xin ? xin + (long)b * bstride : nullptr;
+    const float* cpb = cp ? cp + (long)b * cp_bstride : nullptr;
+    float sum = 0.f;
+    for (int c = wave; c < C; c += 4) {
+        float v = xb[(long)c * rstride + t];
+        if (cpb) {
+            const float w = v + cpb[(long)c * rstride + t];
+            if (strong) xb[(long)c * rstride + t] = w;
+            v = w;
+        }
+        if (film) v = v + film[(long)c * film_cstride + film_col0 + b * film_colb];
+        if (xi) xi[(long)c * rstride + t] = v;
+        sum += v;
+    }
+    red[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0) mean_s[lane] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    __syncthreads();
+    const float mean = mean_s[lane];
+    const float* rd = xi ? xi : xb;
+    float sq = 0.f;
+    for (int c = wave; c < C; c += 4) {
+        const float dlt = rd[(long)c * rstride + t] - mean;
+        sq += dlt * dlt;
+    }
+    __syncthreads();
+    red[wave][lane] = sq;
+    __syncthreads();
+    if (wave == 0 && t < ts) {
+        const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+        float* st = stats + (long)b * 2 * ts;
+        st[t] = mean;
+        st[ts + t] = 1.f / sqrtf(var + 1e-5f);
+    }
+}
+
+hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstride, const float* film,
+                           int film_cstride, int film_col0, int film_colb, long bstride, int rstride, int C, int B,
+                           int T, int strong, float* stats, int ts, hipStream_t stream) {
+    dim3 grid(round_up(T, 64) / 64, B);
+    hipLaunchKernelGGL(lynx_pre_kernel, grid, dim3(256), 0, stream, x, xin, cp, cp_bstride, film, film_cstride,
+                       film_col0, film_colb, bstride, rstride, C, T, strong, stats, ts);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise Conv1d(k, padding=k//2, groups=C) + activation (lynxnet.py:57-58):
+//   dst[c, t] = act( bias[c] + sum_j w[c, j] * src[c, t + j - k/2] ),   zero padded on [0, T)
+// One workgroup = 4 channels x 256 frames; each wave stages its channel's (256 + k - 1)-frame row
+// in LDS (masked to [0, T)) and every lane produces 4 consecutive frames from registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int DW_TT = 256;
+constexpr int DW_MAXK = 63;
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                     long bstride, int rstride, int C, int T,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     int ksz, int act, const float* __restrict__ prelu) {
+    __shared__ float row[4][DW_TT + 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int c = blockIdx.y * 4 + wave;
+    const int t0 = blockIdx.x * DW_TT;
+    const int pad = ksz >> 1;
+    if (c < C) {
+        const float* s = src + (long)b * bstride + (long)c * rstride;
+        for (int i = lane; i < DW_TT + ksz - 1; i += 64) {
+            const int t = t0 - pad + i;
+            row[wave][i] = (t >= 0 && t < T) ? s[t] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (c >= C) return;
+    float acc[4];
+    const float bv = bias[c];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = bv;
+    const float* wc = w + (long)c * ksz;
+    const float* r = &row[wave][lane * 4];
+    for (int j = 0; j < ksz; ++j) {
+        const float wj = wc[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += wj * r[j + e];
+    }
+    float* d = dst + (long)b * bstride + (long)c * rstride + t0 + lane * 4;
+    const float slope = (act == 0) ? prelu[c] : 0.f;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = acc[e];
+        if (act == 0) v = v >= 0.f ? v : v * slope;                 // PReLU(per channel)
+        else if (act == 1) v = v * (1.f / (1.f + expf(-v)));        // SiLU
+        else v = fmaxf(v, 0.f);                                     // ReLU
+        o[e] = v;
+    }
+    if (t0 + lane * 4 < rstride - 3) *reinterpret_cast<f32x4*>(d) = o;
+}
+
+hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T,
+                         const float* w, const float* bias, int ksz, int act, const float* prelu,
+                         hipStream_t stream) {
+    if (ksz > DW_MAXK) return hipErrorInvalidValue;
+    dim3 grid((T + DW_TT - 1) / DW_TT, (C + 3) / 4, B);
+    hipLaunchKernelGGL(dwconv_kernel, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, w, bias, ksz, act,
+                       prelu);
+    return hipGetLastError();
+}
+
+}  // namespace dsd

@@ -1,0 +1,100 @@
+// Internal declarations shared by the HIP translation units of libdsdenoise (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsd {
+
+// ---------------------------------------------------------------------------------------------
+// Activation layout in HBM ("internal layout"): [batch][channel][Ts] fp32, time innermost,
+// Ts = round_up(T, 64) + 32 floats (a multiple of 32 floats = 128 B that is never a multiple of
+// 4 KiB, so the rows of a channel x time tile rotate over the memory channels).  Frames
+// t in [T, Ts) are padding: kernels may write garbage there and every consumer masks on t < T
+// when it stages a tile.  Every buffer lives in one arena with a 256-float guard in front and
+// behind, so the halo over-reads of the first/last tile land in allocated memory (and are masked).
+// ---------------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int padded_ts(int T) { return round_up(T, 64) + 32; }
+
+enum Stage { ST_PLAIN = 0, ST_FILM = 1, ST_LN = 2 };
+enum Epi { EP_BIAS_ACT = 0, EP_GATE = 1, EP_RESSKIP = 2, EP_LINCOMB = 3, EP_SWIGLU = 4, EP_BIAS_RES = 5 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3 };
+
+constexpr int kMaxTerms = 8;
+constexpr int kMaxOut = 3;
+
+struct LinTerm {
+    const float* ptr;   // nullptr: the model output of this launch
+    long bstride;       // floats between batch items
+    int rstride;        // floats between channel rows
+    int ext;            // 1: caller tensor with row stride T (mask reads on t < T)
+    float coef;
+    int pad_;
+};
+struct LinOut {
+    float* dst;         // internal layout
+    int nterms;
+    int pad_;
+    LinTerm t[kMaxTerms];
+};
+
+// One GEMM-shaped launch:  out[m, t] = epilogue( sum_{tap, c} A[m, tap, c] * stage(B)[c, t + (tap-1)*dil] )
+struct GemmP {
+    // A: weights pre-packed in MFMA 16x16x4 fragment order, [mblk][tap*K16 + k16][lane][4]
+    const float* A;
+    const float* bias;      // original row indexing, may be nullptr
+    int M;                  // real output rows (original indexing)
+    int C;                  // EP_GATE / EP_SWIGLU: rows per half; EP_RESSKIP: residual rows
+    // B: activations, internal layout
+    const float* B;
+    long b_bstride;
+    int b_rstride;
+    int K;                  // input channels padded to a multiple of 16
+    int Kreal;
+    int KC;                 // channels staged in LDS per chunk (multiple of 16)
+    int T;                  // valid frames
+    int tiles_per_b;
+    int dil;                // dilation (TAPS == 3)
+    int HL;                 // halo columns staged on each side (multiple of 4, >= dil)
+    int S;                  // LDS row stride in floats, S % 32 == 16
+    float in_scale;         // ST_PLAIN: staged value DIVIDED by this (1 = identity)
+    // ST_FILM: y = x + film[c * film_cstride + film_col0 + b * film_colb]
+    const float* film;
+    int film_cstride, film_col0, film_colb;
+    // ST_LN: y = (x - mean[b, t]) * rstd[b, t]; stats laid out [b][2][ln_ts]
+    const float* ln_stats;
+    int ln_ts;
+    // epilogue
+    int act;
+    float* out;             // EP_BIAS_ACT / EP_GATE / EP_SWIGLU / EP_BIAS_RES destination
+    long o_bstride;
+    int o_rstride;
+    const float* aux;       // EP_GATE: hoisted conditioner projection (+ biases); EP_BIAS_RES: residual
+    long aux_bstride;
+    int aux_rstride;
+    float* x;               // EP_RESSKIP: residual stream, updated in place
+    float* skip;            // EP_RESSKIP: running skip sum
+    int first_layer;        // EP_RESSKIP: 1 = skip is written, not accumulated
+    int nout;               // EP_LINCOMB
+    LinOut lo[kMaxOut];
+};
+
+// gemm.hip
+hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int batch, hipStream_t st);
+int gemm_lds_bytes(int KC, int S);
+hipError_t gemm_init_all();
+
+// aux_kernels.hip
+hipError_t launch_pack(const float* src, long sb, long sr, long st, float* dst, int B, int R, int T, int Ts,
+                       hipStream_t stream);
+hipError_t launch_unpack(const float* src, int Ts, float* dst, int B, int F, int M, int T, int transpose,
+                         const float* scale, const float* shift, hipStream_t stream);
+hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const float* freqs, int C, float* dst,
+                         hipStream_t stream);
+hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstride, const float* film,
+                           int film_cstride, int film_col0, int film_colb, long bstride, int rstride, int C, int B,
+                           int T, int strong, float* stats, int ts, hipStream_t stream);
+hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T,
+                         const float* w, const float* bias, int ksz, int act, const float* prelu, hipStream_t stream);
+
+}  // namespace dsd

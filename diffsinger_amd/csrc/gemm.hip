@@ -1,0 +1,281 @@
+// fp32 MFMA "conv-GEMM" family for gfx950 (MI355X).
+//
+// Every dense contraction on the denoiser path has the same shape:
+//     out[m, t] = epilogue( sum_{tap, c} W[m, c, tap] * stage(x)[c, t + (tap - 1) * dil] )
+// with m = output channel, c = input channel, t = frame (time innermost in HBM).  It covers
+//   * the k=3 dilated conv of ResidualBlock (wavenet.py:22-28,36-38) with the FiLM add folded into
+//     staging and the sigmoid*tanh gate (wavenet.py:41-42) folded into the epilogue,
+//   * every 1x1 conv / Linear on the path (wavenet.py:29-31,56-62,71-72; lynxnet.py:55,59,71-72,104-124),
+//   * the residual/skip update (wavenet.py:44-48), SwiGLU (common_layers.py:116-117) and the
+//     solver's linear combination as epilogues.
+//
+// Mapping to CDNA4:
+//   * v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD).  A = weights, B = activations.
+//   * A is pre-packed on the host in fragment order, so a wave fetches the fragments of 4 k-steps
+//     of one 16-row block with ONE coalesced 1 KiB global_load_dwordx4 straight into VGPRs
+//     (weights are L2/MALL resident; no LDS round trip), software-pipelined PF iterations ahead.
+//   * B: a [KC channels x (BN + 2*halo) frames] tile is staged in LDS once per K-chunk with 16-B
+//     loads along the time axis; fragments are read with ds_read_b32 (row stride S = 16 mod 32
+//     floats -> the 4 k-rows x 16 columns of a fragment hit 64 distinct banks).
+//   * workgroup = 4 waves (one per SIMD) as 2 (rows) x 2 (frames); tile = 64 rows x 32*NB frames.
+//     Gate/SwiGLU pairs (row r and row r + C) are packed into the same wave so the nonlinearity
+//     is a pure register epilogue.
+#include "dsd_internal.h"
+
+namespace dsd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_MISH: return v * tanhf(log1pf(expf(v)));           // nn.Mish (wavenet.py:60)
+        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // exact GELU (lynxnet.py:106)
+        default: return v;
+    }
+}
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
+
+constexpr int PF = 4;   // A-fragment prefetch distance in k16 iterations
+
+template <int STAGE, int TAPS, int EPI, int NB>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BN = 32 * NB;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.x / p.tiles_per_b;
+    const int t0 = (blockIdx.x - b * p.tiles_per_b) * BN;
+    const int mtile = blockIdx.y;
+    const int K16 = p.K >> 4;
+    const int S = p.S, HL = p.HL;
+
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // packed A: [mblk][TAPS*K16][64 lanes][4]; this wave owns packed m-blocks 4*mtile + 2*wm + {0,1}
+    const long a_blk = (long)(TAPS * K16) * 256;
+    const float* a0p = p.A + (long)(mtile * 4 + wm * 2) * a_blk + lane * 4;
+    const float* a1p = a0p + a_blk;
+
+    const float* bsrc = p.B + (long)b * p.b_bstride;
+    const int W4 = (BN + 2 * HL) >> 2;      // float4 per staged row
+    const int lrow = lane >> 4, lcol = lane & 15;
+
+    for (int kc = 0; kc < p.K; kc += p.KC) {
+        const int kcn = min(p.KC, p.K - kc);
+        if (kc > 0) __syncthreads();
+        // ---------------- stage B chunk: rows [kc, kc+kcn), frames [t0-HL, t0+BN+HL) ----------------
+        for (int idx = tid; idx < kcn * W4; idx += 256) {
+            const int r = idx / W4;
+            const int c4 = idx - r * W4;
+            const int tcol = t0 - HL + c4 * 4;
+            const int ch = kc + r;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ch < p.Kreal) v = *reinterpret_cast<const f32x4*>(bsrc + (long)ch * p.b_rstride + tcol);
+            float add = 0.f;
+            if (STAGE == ST_FILM && ch < p.Kreal) add = p.film[(long)ch * p.film_cstride + p.film_col0 + b * p.film_colb];
+            f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, rstd = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (STAGE == ST_LN) {
+                const float* st = p.ln_stats + (long)b * 2 * p.ln_ts;
+                if (tcol >= 0 && tcol + 3 < p.ln_ts) {
+                    mean = *reinterpret_cast<const f32x4*>(st + tcol);
+                    rstd = *reinterpret_cast<const f32x4*>(st + p.ln_ts + tcol);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = tcol + e;
+                float y = v[e];
+                if (STAGE == ST_FILM) y = y + add;
+                else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
+                else y = y / p.in_scale;     // exact for in_scale == 1; the skip sum is DIVIDED by sqrt(L) (wavenet.py:96)
+                const bool ok = (t >= 0) && (t < p.T) && (ch < p.Kreal);
+                v[e] = ok ? y : 0.f;       // zero padding applies AFTER the FiLM add (wavenet.py:36-38)
+            }
+            *reinterpret_cast<f32x4*>(&lds[r * S + c4 * 4]) = v;
+        }
+        __syncthreads();
+
+        // ---------------- MFMA over (tap, k16) with A prefetched PF iterations ahead ----------------
+        const int n16 = kcn >> 4;
+        const int nit = TAPS * n16;
+        const int kc16 = kc >> 4;
+        f32x4 ra0[PF], ra1[PF];
+        int pf_tap = 0, pf_c = 0;     // position of the next iteration to prefetch
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (u < nit) {
+                const long off = (long)(pf_tap * K16 + kc16 + pf_c) * 256;
+                ra0[u] = *reinterpret_cast<const f32x4*>(a0p + off);
+                ra1[u] = *reinterpret_cast<const f32x4*>(a1p + off);
+                if (++pf_c == n16) { pf_c = 0; ++pf_tap; }
+            }
+        }
+        int tap = 0, c16 = 0;
+        for (int it = 0; it < nit; it += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (it + u < nit) {
+                    const f32x4 A0 = ra0[u], A1 = ra1[u];
+                    if (it + u + PF < nit) {
+                        const long off = (long)(pf_tap * K16 + kc16 + pf_c) * 256;
+                        ra0[u] = *reinterpret_cast<const f32x4*>(a0p + off);
+                        ra1[u] = *reinterpret_cast<const f32x4*>(a1p + off);
+                        if (++pf_c == n16) { pf_c = 0; ++pf_tap; }
+                    }
+                    const int shift = HL + (TAPS == 3 ? (tap - 1) * p.dil : 0);
+                    const float* bl = &lds[(c16 * 16 + lrow) * S + wn * (16 * NB) + lcol + shift];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float bv[NB];
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) bv[n] = bl[j * 4 * S + n * 16];
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) {
+                            acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], bv[n], acc[0][n], 0, 0, 0);
+                            acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], bv[n], acc[1][n], 0, 0, 0);
+                        }
+                    }
+                    if (++c16 == n16) { c16 = 0; ++tap; }
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------- epilogue ----------------------------------------
+    // C/D layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + reg.
+    const int rq = (lane >> 4) * 4;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int t = t0 + wn * (16 * NB) + n * 16 + lcol;
+        if (EPI == EP_GATE || EPI == EP_SWIGLU) {
+            // packed pair block: acc[0] = first-half rows (gate / out), acc[1] = second-half rows (filter / gate)
+            const int chb = (mtile * 2 + wm) * 16 + rq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = chb + r;
+                if (ch < p.C) {
+                    float u0 = acc[0][n][r], u1 = acc[1][n][r];
+                    float y;
+                    if (EPI == EP_GATE) {
+                        const float* cp = p.aux + (long)b * p.aux_bstride + t;
+                        u0 += cp[(long)ch * p.aux_rstride];
+                        u1 += cp[(long)(ch + p.C) * p.aux_rstride];
+                        y = sigmoid_f(u0) * tanhf(u1);                 // wavenet.py:41-42
+                    } else {
+                        u0 += p.bias[ch];
+                        u1 += p.bias[ch + p.C];
+                        y = u0 * (u1 * sigmoid_f(u1));                 // out * silu(gate), common_layers.py:116-117
+                    }
+                    p.out[(long)b * p.o_bstride + (long)ch * p.o_rstride + t] = y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int rowb = mtile * 64 + (wm * 2 + mb) * 16 + rq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rowb + r;
+                    if (row >= p.M) continue;
+                    float v = acc[mb][n][r] + (p.bias ? p.bias[row] : 0.f);
+                    if (EPI == EP_BIAS_ACT) {
+                        p.out[(long)b * p.o_bstride + (long)row * p.o_rstride + t] = act_apply(v, p.act);
+                    } else if (EPI == EP_BIAS_RES) {
+                        const float res = p.aux[(long)b * p.aux_bstride + (long)row * p.aux_rstride + t];
+                        p.out[(long)b * p.o_bstride + (long)row * p.o_rstride + t] = v + res;
+                    } else if (EPI == EP_RESSKIP) {
+                        if (row < p.C) {                               // residual half (wavenet.py:47-48)
+                            float* xp = p.x + (long)b * p.o_bstride + (long)row * p.o_rstride + t;
+                            *xp = (*xp + v) / 1.41421356237309504880f;
+                        } else {                                       // skip half: running sum replaces stack+sum (wavenet.py:96)
+                            float* sp = p.skip + (long)b * p.o_bstride + (long)(row - p.C) * p.o_rstride + t;
+                            *sp = p.first_layer ? v : (*sp + v);
+                        }
+                    } else if (EPI == EP_LINCOMB) {
+                        float outv[kMaxOut];
+#pragma unroll
+                        for (int o = 0; o < kMaxOut; ++o) {
+                            outv[o] = 0.f;
+                            if (o < p.nout) {
+                                const LinOut& lo = p.lo[o];
+                                for (int k = 0; k < lo.nterms; ++k) {
+                                    const LinTerm& tm = lo.t[k];
+                                    float s;
+                                    if (tm.ptr == nullptr) s = v;
+                                    else if (tm.ext && t >= p.T) s = 0.f;
+                                    else s = tm.ptr[(long)b * tm.bstride + (long)row * tm.rstride + t];
+                                    outv[o] += tm.coef * s;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int o = 0; o < kMaxOut; ++o)
+                            if (o < p.nout) p.lo[o].dst[(long)b * p.o_bstride + (long)row * p.o_rstride + t] = outv[o];
+                    }
+                }
+            }
+        }
+    }
+}
+
+int gemm_lds_bytes(int KC, int S) { return KC * S * 4; }
+
+template <int STAGE, int TAPS, int EPI, int NB>
+static hipError_t set_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<STAGE, TAPS, EPI, NB>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+template <int STAGE, int TAPS, int EPI, int NB>
+static hipError_t launch_one(const GemmP& p, int batch, int mtiles, hipStream_t st) {
+    const int lds = gemm_lds_bytes(p.KC, p.S);
+    dim3 grid(batch * p.tiles_per_b, mtiles, 1);
+    hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB>), grid, dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+#define DSD_ATTR(ST, TP, EP)                                         \
+    if ((e = set_attr<ST, TP, EP, 1>()) != hipSuccess) return e;     \
+    if ((e = set_attr<ST, TP, EP, 2>()) != hipSuccess) return e;
+
+// Raise the dynamic-LDS limit of every instantiation once, outside any stream capture.
+hipError_t gemm_init_all() {
+    hipError_t e;
+    DSD_ATTR(ST_PLAIN, 1, EP_BIAS_ACT)
+    DSD_ATTR(ST_FILM, 3, EP_GATE)
+    DSD_ATTR(ST_PLAIN, 1, EP_RESSKIP)
+    DSD_ATTR(ST_PLAIN, 1, EP_LINCOMB)
+    DSD_ATTR(ST_LN, 1, EP_SWIGLU)
+    DSD_ATTR(ST_PLAIN, 1, EP_BIAS_RES)
+    DSD_ATTR(ST_LN, 1, EP_LINCOMB)
+    return hipSuccess;
+}
+
+#define DSD_CASE(ST, TP, EP)                                                         \
+    if (stage == ST && taps == TP && epi == EP) {                                    \
+        return nb == 1 ? launch_one<ST, TP, EP, 1>(p, batch, mtiles, st)             \
+                       : launch_one<ST, TP, EP, 2>(p, batch, mtiles, st);            \
+    }
+
+hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int batch, hipStream_t st) {
+    int mtiles;
+    if (epi == EP_GATE || epi == EP_SWIGLU) mtiles = (p.C + 31) / 32;   // 32 pairs = 64 packed rows per tile
+    else mtiles = (p.M + 63) / 64;
+    DSD_CASE(ST_PLAIN, 1, EP_BIAS_ACT)
+    DSD_CASE(ST_FILM, 3, EP_GATE)
+    DSD_CASE(ST_PLAIN, 1, EP_RESSKIP)
+    DSD_CASE(ST_PLAIN, 1, EP_LINCOMB)
+    DSD_CASE(ST_LN, 1, EP_SWIGLU)
+    DSD_CASE(ST_PLAIN, 1, EP_BIAS_RES)
+    DSD_CASE(ST_LN, 1, EP_LINCOMB)
+    return hipErrorInvalidValue;
+}
+
+}  // namespace dsd

@@ -1,0 +1,188 @@
+/*
+ * libdsdenoise - MI355X-native (gfx950) diffusion denoiser for DiffSinger.
+ *
+ * C-ABI drop-in boundary for the ONE hot path of hrukalive/DiffSinger inference: the backbone
+ * forward (WaveNet / LYNXNet) and the sampling loops that call it once per NFE.  Every entry
+ * point replaces (is bound in place of) a reference Python interface, cited per function as
+ * `path:line` into the reference tree.  Plain pointers and sizes only: no torch types cross
+ * this boundary.  All device pointers are fp32, on the HIP device the handle was created for;
+ * `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).
+ *
+ * Return value: 0 on success, a negative DSD_E* code on failure; nothing is thrown across the
+ * ABI.  `dsd_last_error` returns a human-readable message for the last failure on a handle.
+ *
+ * Threading: like the reference modules (module-level `noise_list`/`bar`,
+ * modules/core/ddpm.py:78,276,324) a handle is NOT re-entrant: calls on one handle are
+ * serialised by the caller.  One handle per (model, device, process).
+ */
+#ifndef DSDENOISE_H_
+#define DSDENOISE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSD_API_VERSION 1
+
+/* error codes */
+#define DSD_OK 0
+#define DSD_EINVAL (-1)   /* bad argument / shape / enum                        */
+#define DSD_ESTATE (-2)   /* call order violated (weights missing, no cond ...) */
+#define DSD_EHIP (-3)     /* a HIP runtime call failed                          */
+#define DSD_ENOMEM (-4)   /* device allocation failed                           */
+#define DSD_ENOTFOUND (-5) /* unknown weight name                                */
+
+typedef struct dsd_handle dsd_handle;
+
+/* modules/backbones/__init__.py:6-9  BACKBONES = {'wavenet': WaveNet, 'lynxnet': LYNXNet} */
+enum { DSD_BACKBONE_WAVENET = 0, DSD_BACKBONE_LYNXNET = 1 };
+/* modules/backbones/lynxnet.py:38-42  activation_classes */
+enum { DSD_ACT_PRELU = 0, DSD_ACT_SILU = 1, DSD_ACT_RELU = 2 };
+
+/*
+ * Constructor arguments of the backbone, i.e. what
+ *   build_backbone(out_dims, num_feats, backbone_type, backbone_args)   modules/backbones/__init__.py:12-18
+ * forwards to WaveNet.__init__ (modules/backbones/wavenet.py:52) or
+ * LYNXNet.__init__ (modules/backbones/lynxnet.py:91-92), plus hparams['hidden_size']
+ * (wavenet.py:65, lynxnet.py:113).
+ */
+typedef struct dsd_config {
+    int32_t struct_size;            /* sizeof(dsd_config), for forward compatibility        */
+    int32_t backbone;               /* DSD_BACKBONE_*                                       */
+    int32_t in_dims;                /* M: mel bins / repeat bins (`in_dims`)                */
+    int32_t n_feats;                /* F: `n_feats`                                         */
+    int32_t num_layers;             /* L                                                    */
+    int32_t num_channels;           /* C                                                    */
+    int32_t hidden_size;            /* H: encoder hidden size of `cond`                     */
+    int32_t dilation_cycle_length;  /* WaveNet only                                         */
+    int32_t expansion_factor;       /* LYNXNet only                                         */
+    int32_t kernel_size;            /* LYNXNet only (depthwise conv, odd)                   */
+    int32_t activation;             /* LYNXNet only: DSD_ACT_*                              */
+    int32_t strong_cond;            /* LYNXNet only: 0/1                                    */
+    int32_t device;                 /* HIP device ordinal                                   */
+} dsd_config;
+
+/* Replaces: BACKBONES[backbone_type](out_dims, num_feats, **kwargs)  (backbones/__init__.py:16-18). */
+int dsd_create(const dsd_config* cfg, dsd_handle** out);
+void dsd_destroy(dsd_handle* h);
+/* Message for the last failed call on `h` (h == NULL: last failed dsd_create).  Never NULL. */
+const char* dsd_last_error(const dsd_handle* h);
+int dsd_api_version(void);
+
+/*
+ * Replaces: nn.Module.load_state_dict for the backbone (utils/__init__.py:166-222 load_ckpt ->
+ * strict load).  `name` is the reference state_dict key relative to the backbone, e.g.
+ * "residual_layers.3.dilated_conv.weight" (wavenet.py:22-31,56-72; lynxnet.py:52-62,71-74,104-124);
+ * `shape`/`ndim` must equal the reference parameter's shape.  `data` is read during the call
+ * (host pointer if on_device == 0, device pointer otherwise).  One extra, non-parameter entry is
+ * accepted: "diffusion_embedding.freqs" [C/2], the SinusoidalPosEmb frequency table
+ * (common_layers.py:275-276); if it is not supplied it is computed in fp32 on the host.
+ */
+int dsd_load_weight(dsd_handle* h, const char* name, const float* data, const int64_t* shape,
+                    int32_t ndim, int32_t on_device);
+/* Strictness check (every parameter present) + re-layout into MFMA fragment order on the device. */
+int dsd_finalize_weights(dsd_handle* h);
+
+/*
+ * Hoists ResidualBlock.conditioner_projection / LYNXNetResidualLayer.conditioner_projection
+ * (wavenet.py:30,35; lynxnet.py:72,77-82) out of the denoise loop: they depend on `cond` only.
+ * The reference's own ONNX exporter does the same hoist (utils/onnx_helper.py:267-349).
+ * cond element (b, h, t) is read at cond[b*stride_b + h*stride_h + t*stride_t], so both the
+ * backbone's [B,H,T] view (wavenet.py:75-81) and GaussianDiffusion.forward's [B,T,H] `condition`
+ * (ddpm.py:353-357) can be passed without a transpose.  Also (re)sizes the workspace for (B, T).
+ */
+int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64_t stride_b,
+                     int64_t stride_h, int64_t stride_t, void* stream);
+
+/*
+ * Replaces: WaveNet.forward / LYNXNet.forward(spec, diffusion_step, cond)
+ * (wavenet.py:75-107, lynxnet.py:128-163) for the cond given to the last dsd_prepare_cond.
+ * x, out: [B, F, M, T] contiguous device fp32 (out must not alias x: the reference does not
+ * mutate its input either).  t: device fp32, t_len == B or 1 (a [1] step is broadcast,
+ * reflow.py:135); integer steps are passed as their float value (common_layers.py:277).
+ */
+int dsd_denoise(dsd_handle* h, const float* x, const float* t, int32_t t_len, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampling programs.  Every sampler of the reference (ddpm.py:149-204,221-351 p_sample /
+ * p_sample_ddim / p_sample_plms; dpm_solver_pytorch.py:1171-1213; uni_pc.py:590-672;
+ * reflow.py:66-138 euler/rk2/rk4/rk5) is a sequence of backbone evaluations whose results enter
+ * the solver state only through linear combinations with scalar coefficients that are known
+ * before the loop starts.  A program states exactly that: per evaluation, the state buffer fed
+ * to the backbone, the model time, and up to DSD_MAX_OUT linear combinations
+ *      dst = sum_k coef_k * src_k,     src_k in { model output, state buffers, injected noise }
+ * which the library fuses into the epilogue of the backbone's last GEMM.  The host-side
+ * scheduler (diffsinger_amd/schedule.py) computes the coefficients; the device does NFE + axpy.
+ * ------------------------------------------------------------------------------------------ */
+#define DSD_MAX_TERMS 8
+#define DSD_MAX_OUT 3
+#define DSD_SRC_MODEL (-1)            /* the backbone output of this evaluation            */
+#define DSD_SRC_NOISE_BASE (-1000)    /* src = DSD_SRC_NOISE_BASE - k : k-th injected noise */
+
+typedef struct dsd_term {
+    int32_t src;   /* state buffer id >= 0, DSD_SRC_MODEL, or DSD_SRC_NOISE_BASE - k */
+    float coef;
+} dsd_term;
+
+typedef struct dsd_lincomb {
+    int32_t dst;      /* state buffer id */
+    int32_t n_terms;  /* 1..DSD_MAX_TERMS */
+    dsd_term terms[DSD_MAX_TERMS];
+} dsd_lincomb;
+
+typedef struct dsd_eval {
+    int32_t x_buf;    /* state buffer holding the backbone input x_t */
+    float t;          /* model time fed to SinusoidalPosEmb (same for the whole batch) */
+    int32_t n_out;    /* 1..DSD_MAX_OUT */
+    dsd_lincomb out[DSD_MAX_OUT];
+} dsd_eval;
+
+typedef struct dsd_program {
+    int32_t n_bufs;          /* number of state buffers (each [B, F*M, T]); buffer 0 = x_T on entry */
+    int32_t result_buf;      /* buffer holding the sample after the last evaluation */
+    int32_t n_evals;
+    int32_t n_noise;         /* number of injected [B,F,M,T] noise tensors referenced by terms */
+    const dsd_eval* evals;
+} dsd_program;
+
+#define DSD_SAMPLE_GRAPH 1u      /* replay the whole loop from a cached hipGraph */
+#define DSD_SAMPLE_TRANSPOSE 2u  /* out is [B,T,M] (F == 1) or [B,F,T,M] and
+                                    out = sample * out_scale[f*M+m] + out_shift[f*M+m]
+                                    (x.transpose(2,3).squeeze(1) + denorm_spec, ddpm.py:350,382-383) */
+
+/*
+ * Replaces: the loop of GaussianDiffusion.inference (ddpm.py:244-349) / RectifiedFlow.inference
+ * (reflow.py:132-136) after x has been initialised, for the cond of the last dsd_prepare_cond.
+ *   x_init    [B,F,M,T] device: initial state (x_T, or the shallow-diffusion start)
+ *   noise     n_noise x [B,F,M,T] device, or NULL when n_noise == 0 (ancestral DDPM, ddpm.py:153)
+ *   out       [B,F,M,T], or the transposed/denormalised form with DSD_SAMPLE_TRANSPOSE
+ *   out_scale/out_shift: device [F*M] (only with DSD_SAMPLE_TRANSPOSE; NULL = identity)
+ */
+int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, const float* noise,
+               float* out, const float* out_scale, const float* out_shift, uint32_t flags, void* stream);
+
+/* Introspection used by tests, bench.py and the roofline report. */
+typedef struct dsd_stats {
+    int64_t weight_bytes;        /* packed weights on the device                        */
+    int64_t workspace_bytes;     /* current arena size                                  */
+    int64_t flops_per_frame_nfe; /* algorithmic FLOPs per mel frame per NFE (hoisted)   */
+    int64_t bytes_per_frame_nfe; /* algorithmic HBM bytes per mel frame per NFE         */
+    int32_t kernels_per_nfe;     /* kernel launches per backbone evaluation             */
+    int32_t graphs_cached;
+} dsd_stats;
+int dsd_get_stats(const dsd_handle* h, dsd_stats* out);
+
+/*
+ * Timing hook for bench.py: the dominant kernel (WaveNet: dilated-conv+gate GEMM; LYNXNet: the
+ * C->4C SwiGLU GEMM) is bracketed by hipEvents on its own stream when enabled; returns the mean
+ * duration in milliseconds over the launches recorded since the last reset and their count.
+ */
+int dsd_kernel_timing(dsd_handle* h, int32_t enable);
+int dsd_kernel_timing_read(dsd_handle* h, double* mean_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSDENOISE_H_ */

@@ -1,0 +1,95 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol that
+include/dsdenoise.h declares; struct layouts agree with the ctypes mirror.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "dsdenoise.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsd_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from diffsinger_amd import _lib
+    names = header_functions()
+    assert len(names) >= 12
+    assert sorted(_lib.EXPORTS) == names
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert _lib.lib().dsd_api_version() == 1
+
+
+def test_struct_sizes_match_header():
+    from diffsinger_amd import _lib
+    assert C.sizeof(_lib.DsdConfig) == 13 * 4
+    assert C.sizeof(_lib.DsdTerm) == 8
+    assert C.sizeof(_lib.DsdLincomb) == 8 + 8 * _lib.DSD_MAX_TERMS
+    assert C.sizeof(_lib.DsdEval) == 12 + _lib.DSD_MAX_OUT * C.sizeof(_lib.DsdLincomb)
+    assert C.sizeof(_lib.DsdProgram) == 24
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from diffsinger_amd import _lib
+    cfg = _lib.DsdConfig(C.sizeof(_lib.DsdConfig), 0, 128, 1, 20, 256, 256, 4, 0, 0, 0, 0, 0)
+    h = C.c_void_p()
+    rc = _lib.lib().dsd_create(C.byref(cfg), C.byref(h))
+    assert rc < 0
+    assert b"no HIP device" in _lib.lib().dsd_last_error(None)
+
+
+def test_bad_config_rejected():
+    from diffsinger_amd import _lib
+    cfg = _lib.DsdConfig(C.sizeof(_lib.DsdConfig), 7, 128, 1, 20, 256, 256, 4, 0, 0, 0, 0, 0)
+    h = C.c_void_p()
+    assert _lib.lib().dsd_create(C.byref(cfg), C.byref(h)) == -1
+    cfg = _lib.DsdConfig(C.sizeof(_lib.DsdConfig), 0, 128, 1, 20, 250, 256, 4, 0, 0, 0, 0, 0)
+    assert _lib.lib().dsd_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"multiple of 32" in _lib.lib().dsd_last_error(None)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "diffsinger_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            txt = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), fn
+
+
+def test_cpu_tensor_raises_not_falls_back():
+    import torch
+    from diffsinger_amd.hparams import hparams
+    hparams.update(hidden_size=256)
+    from diffsinger_amd.backbones import build_backbone
+    net = build_backbone(32, 1, "wavenet", dict(num_layers=2, num_channels=64, dilation_cycle_length=2, junk=1))
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path"):
+        net(torch.zeros(1, 1, 32, 8), torch.zeros(1), torch.zeros(1, 256, 8))
+    with pytest.raises(RuntimeError, match="inference-only"):
+        net(torch.zeros(1, 1, 32, 8), torch.zeros(1), torch.zeros(1, 256, 8))
+
+
+def test_state_dict_names_match_reference_layout():
+    import torch  # noqa: F401
+    from diffsinger_amd import synth
+    from diffsinger_amd.hparams import hparams
+    hparams.update(hidden_size=256)
+    from diffsinger_amd.backbones import build_backbone
+    for kind, args in (("wavenet", dict(num_layers=3, num_channels=64, dilation_cycle_length=2)),
+                       ("lynxnet", dict(num_layers=2, num_channels=64, expansion_factor=2, kernel_size=31,
+                                        activation="PReLU", dropout_rate=0.1)),
+                       ("lynxnet", dict(num_layers=2, num_channels=64, activation="SiLU"))):
+        net = build_backbone(32, 1, kind, args)
+        shapes = synth.backbone_param_shapes(kind, 32, 1, hidden_size=256, **args)
+        sd = net.state_dict()
+        assert list(sd) == list(shapes) or set(sd) == set(shapes)
+        for k, v in shapes.items():
+            assert tuple(sd[k].shape) == tuple(v), k

@@ -1,0 +1,352 @@
+"""Parity of the HIP path (through the C-ABI) against the numpy oracle and the committed golden
+fixtures generated from the reference.  Run on the MI355X box: `pytest tests -m gpu`.
+
+Stated fp32 tolerances (max abs error / max abs reference value):
+  * one backbone evaluation            <= 2e-5   (oracle-vs-reference itself is <= 6e-6)
+  * full sampler runs (<= 120 NFE)     <= 5e-4   (oracle-vs-reference is <= 2e-6; random weights make the
+                                                  denoiser expansive, so rounding differences grow per step)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from diffsinger_amd import synth  # noqa: E402
+from gpu_util import dev, load_synth, make_backbone, rel_err, set_hp, synth_params  # noqa: E402
+from oracle import backbones as ob  # noqa: E402
+from oracle import diffusion as od  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_NFE = 2e-5
+TOL_SAMPLER = 5e-4
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    set_hp()
+
+
+WN = {
+    "wn_acoustic": (128, 1, dict(num_layers=20, num_channels=256, dilation_cycle_length=4)),
+    "wn_pitch": (64, 1, dict(num_layers=20, num_channels=256, dilation_cycle_length=5)),
+    "wn_multivar": (24, 2, dict(num_layers=10, num_channels=192, dilation_cycle_length=4)),
+    "wn_small": (32, 1, dict(num_layers=4, num_channels=64, dilation_cycle_length=2)),
+}
+LX = {
+    "lx_default": (128, 1, dict(num_layers=6, num_channels=512, expansion_factor=2, kernel_size=31,
+                                activation="PReLU", strong_cond=False)),
+    "lx_acoustic1024": (128, 1, dict(num_layers=6, num_channels=1024, expansion_factor=2, kernel_size=31,
+                                     activation="PReLU", strong_cond=True)),
+    "lx_silu": (64, 1, dict(num_layers=2, num_channels=128, expansion_factor=2, kernel_size=31,
+                            activation="SiLU", strong_cond=False)),
+    "lx_relu": (24, 2, dict(num_layers=2, num_channels=128, expansion_factor=1, kernel_size=7,
+                            activation="ReLU", strong_cond=True)),
+}
+
+
+def _golden_backbone_cases(kind, name, table, prefix):
+    in_dims, n_feats, args = table[name]
+    g = load(prefix + name)
+    set_hp()
+    net, params = make_backbone(kind, in_dims, n_feats, args, int(g["weight_seed"]))
+    assert synth.state_dict_digest(params) == str(g["digest"])
+    ci = 0
+    while f"c{ci}_meta" in g:
+        bsz, t_len, xs, cs, _ = (int(v) for v in g[f"c{ci}_meta"])
+        x = synth.synth_normal((bsz, n_feats, in_dims, t_len), xs)
+        cond = synth.synth_normal((bsz, 256, t_len), cs)
+        t = g[f"c{ci}_t"]
+        with torch.no_grad():
+            out = net(dev(x), dev(t), dev(cond))
+        torch.cuda.synchronize()
+        assert tuple(out.shape) == g[f"c{ci}_out"].shape
+        err = rel_err(out, g[f"c{ci}_out"])
+        assert err < TOL_NFE, (name, ci, err)
+        ci += 1
+    assert ci > 0
+    net.release_native()
+
+
+@pytest.mark.parametrize("name", sorted(WN))
+def test_wavenet_single_nfe_vs_golden(name):
+    _golden_backbone_cases("wavenet", name, WN, "g2_")
+
+
+@pytest.mark.parametrize("name", sorted(LX))
+def test_lynxnet_single_nfe_vs_golden(name):
+    _golden_backbone_cases("lynxnet", name, LX, "g3_")
+
+
+@pytest.mark.parametrize("bsz,t_len", [(1, 1), (1, 31), (3, 64), (2, 257), (1, 1000)])
+def test_wavenet_vs_oracle_ragged_sizes(bsz, t_len):
+    """Edge sizes: T = 1, T < dilation, T not a multiple of any tile, exact tile multiples, headline T."""
+    set_hp()
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    net, params = make_backbone("wavenet", 128, 1, args, 42)
+    x = synth.synth_normal((bsz, 1, 128, t_len), 11)
+    cond = synth.synth_normal((bsz, 256, t_len), 12)
+    t = (np.arange(bsz) * 333.25 + 7.5).astype(np.float32)
+    want = ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=4)
+    with torch.no_grad():
+        out = net(dev(x), dev(t), dev(cond))
+        out2 = net(dev(x), dev(t), dev(cond))              # second call: cached cond, same result
+    assert rel_err(out, want) < TOL_NFE
+    assert torch.equal(out, out2)
+    net.release_native()
+
+
+def test_wavenet_intermediate_state_does_not_leak_between_calls():
+    """The handle is reused across shapes and inputs: results must depend on the inputs only."""
+    set_hp()
+    args = dict(num_layers=4, num_channels=64, dilation_cycle_length=2)
+    net, params = make_backbone("wavenet", 32, 1, args, 45)
+    outs = []
+    for bsz, t_len in ((2, 50), (1, 200), (2, 50)):
+        x = synth.synth_normal((bsz, 1, 32, t_len), 5)
+        cond = synth.synth_normal((bsz, 256, t_len), 6)
+        t = np.full((bsz,), 123.0, np.float32)
+        with torch.no_grad():
+            outs.append(net(dev(x), dev(t), dev(cond)).cpu().numpy())
+        want = ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=2)
+        assert rel_err(outs[-1], want) < TOL_NFE
+    np.testing.assert_array_equal(outs[0], outs[2])
+    net.release_native()
+
+
+def test_lynxnet_vs_oracle_ragged():
+    set_hp()
+    args = dict(num_layers=3, num_channels=256, expansion_factor=2, kernel_size=31, activation="PReLU",
+                strong_cond=True)
+    net, params = make_backbone("lynxnet", 128, 1, args, 56)
+    for bsz, t_len in ((1, 5), (2, 333)):
+        x = synth.synth_normal((bsz, 1, 128, t_len), 21)
+        cond = synth.synth_normal((bsz, 256, t_len), 22)
+        t = np.array([500.5], np.float32)           # [1] step broadcast over the batch (reflow.py:135)
+        want = ob.lynxnet_forward(params, x, t, cond, activation="PReLU", strong_cond=True)
+        with torch.no_grad():
+            out = net(dev(x), dev(t), dev(cond))
+        assert rel_err(out, want) < TOL_NFE
+    net.release_native()
+
+
+# ------------------------------------------------------------------------------------------------
+# samplers through the coarse boundary (GaussianDiffusion.forward / RectifiedFlow.forward)
+# ------------------------------------------------------------------------------------------------
+SN = dict(in_dims=32, n_feats=1, args=dict(num_layers=4, num_channels=64, dilation_cycle_length=2), wseed=45)
+
+GD_CASES = {
+    "ddim10": (dict(diff_accelerator="ddim", diff_speedup=10, K_step_infer=1000), 1000, False),
+    "ddim100": (dict(diff_accelerator="ddim", diff_speedup=100, K_step_infer=1000), 1000, False),
+    "pndm20": (dict(diff_accelerator="pndm", diff_speedup=20, K_step_infer=1000), 1000, False),
+    "dpm20": (dict(diff_accelerator="dpm-solver", diff_speedup=50, K_step_infer=1000), 1000, False),
+    "dpm50": (dict(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000), 1000, False),
+    "dpm5": (dict(diff_accelerator="dpm-solver", diff_speedup=200, K_step_infer=1000), 1000, False),
+    "unipc20": (dict(diff_accelerator="unipc", diff_speedup=50, K_step_infer=1000), 1000, False),
+    "unipc50": (dict(diff_accelerator="unipc", diff_speedup=20, K_step_infer=1000), 1000, False),
+    "ddpm_shallow20": (dict(diff_accelerator="ddim", diff_speedup=1, K_step_infer=20), 400, True),
+    "dpm_shallow": (dict(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=400), 400, True),
+    "ddim_shallow": (dict(diff_accelerator="ddim", diff_speedup=10, K_step_infer=200), 400, True),
+}
+
+
+def _gd(k_step, kind="wavenet", in_dims=None, args=None, wseed=None):
+    from diffsinger_amd.diffusion import GaussianDiffusion
+    in_dims = in_dims or SN["in_dims"]
+    args = args or SN["args"]
+    wseed = wseed or SN["wseed"]
+    d = GaussianDiffusion(in_dims, 1, timesteps=1000, k_step=k_step, backbone_type=kind, backbone_args=args,
+                          spec_min=[-12.0], spec_max=[0.0])
+    load_synth(d.denoise_fn, synth_params(kind, in_dims, 1, args, wseed))
+    return d.cuda().eval()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("tag", sorted(GD_CASES))
+def test_gaussian_diffusion_samplers_vs_golden(tag, use_graph):
+    hp, k_step, shallow = GD_CASES[tag]
+    g = load("g5_samplers")
+    bsz, t_len, nseed, n_randn, _, _ = (int(v) for v in g[f"{tag}_meta"])
+    set_hp(use_shallow_diffusion=shallow, **hp)
+    d = _gd(k_step)
+    d.use_graph = use_graph
+    cond = dev(synth.synth_normal((bsz, t_len, 256), nseed + 500))
+    src = None
+    if shallow:
+        src = dev((synth.synth_normal((bsz, t_len, 32), nseed + 501) * 1.5 - 6.0).astype(np.float32))
+    noise = dev(synth.synth_normal((bsz, 1, 32, t_len), nseed))
+    step_noise = None
+    if n_randn > 1:
+        step_noise = dev(np.stack([synth.synth_normal((bsz, 1, 32, t_len), nseed + 1 + i) for i in range(n_randn - 1)]))
+    out = d(cond, src_spec=src, infer=True, noise=noise, step_noise=step_noise)
+    out_again = d(cond, src_spec=src, infer=True, noise=noise, step_noise=step_noise)   # graph replay / cache
+    err = rel_err(out, g[f"{tag}_out"])
+    assert err < TOL_SAMPLER, (tag, err)
+    assert torch.equal(out, out_again)
+    d.denoise_fn.release_native()
+
+
+RF_CASES = {"rf_euler20": ("euler", 0.0, False), "rf_rk2_20": ("rk2", 0.0, False), "rf_rk4_20": ("rk4", 0.0, False),
+            "rf_rk5_20": ("rk5", 0.0, False), "rf_euler_shallow": ("euler", 0.4, True)}
+
+
+@pytest.mark.parametrize("tag", sorted(RF_CASES))
+def test_rectified_flow_samplers_vs_golden(tag):
+    from diffsinger_amd.diffusion import RectifiedFlow
+    algo, t_start, shallow = RF_CASES[tag]
+    g = load("g5_samplers")
+    bsz, t_len, nseed, _, steps, _ = (int(v) for v in g[f"{tag}_meta"])
+    set_hp(use_shallow_diffusion=shallow, sampling_algorithm=algo, sampling_steps=steps, T_start_infer=t_start)
+    r = RectifiedFlow(32, 1, t_start=t_start, time_scale_factor=1000, backbone_type="wavenet",
+                      backbone_args=SN["args"], spec_min=[-12.0], spec_max=[0.0])
+    load_synth(r.velocity_fn, synth_params("wavenet", 32, 1, SN["args"], SN["wseed"]))
+    r = r.cuda().eval()
+    cond = dev(synth.synth_normal((bsz, t_len, 256), nseed + 500))
+    src = None
+    if shallow:
+        src = dev((synth.synth_normal((bsz, t_len, 32), nseed + 501) * 1.5 - 6.0).astype(np.float32))
+    out = r(cond, src_spec=src, infer=True, noise=dev(synth.synth_normal((bsz, 1, 32, t_len), nseed)))
+    err = rel_err(out, g[f"{tag}_out"])
+    assert err < TOL_SAMPLER, (tag, err)
+    r.velocity_fn.release_native()
+
+
+def test_full_size_wavenet_dpm20_vs_golden():
+    g = load("g5_full_dpm20")
+    bsz, t_len, nseed, _, cseed = (int(v) for v in g["meta"])
+    set_hp(diff_accelerator="dpm-solver", diff_speedup=50, K_step_infer=1000)
+    d = _gd(1000, in_dims=128, args=dict(num_layers=20, num_channels=256, dilation_cycle_length=4), wseed=42)
+    out = d(dev(synth.synth_normal((bsz, t_len, 256), cseed)), infer=True,
+            noise=dev(synth.synth_normal((bsz, 1, 128, t_len), nseed)))
+    err = rel_err(out, g["out"])
+    assert err < TOL_SAMPLER, err
+    d.denoise_fn.release_native()
+
+
+def test_lynxnet_samplers_vs_golden():
+    from diffsinger_amd.diffusion import RectifiedFlow
+    g = load("g5_lynx")
+    bsz, t_len, s_ddim, s_rf, cseed, wseed = (int(v) for v in g["meta"])
+    largs = dict(num_layers=3, num_channels=256, expansion_factor=2, kernel_size=31, activation="PReLU",
+                 strong_cond=True)
+    cond = dev(synth.synth_normal((bsz, t_len, 256), cseed))
+    set_hp(diff_accelerator="ddim", diff_speedup=50, K_step_infer=1000)
+    d = _gd(1000, kind="lynxnet", in_dims=128, args=largs, wseed=wseed)
+    out = d(cond, infer=True, noise=dev(synth.synth_normal((bsz, 1, 128, t_len), s_ddim)))
+    assert rel_err(out, g["ddim20_out"]) < TOL_SAMPLER
+    d.denoise_fn.release_native()
+    set_hp(sampling_algorithm="euler", sampling_steps=10)
+    r = RectifiedFlow(128, 1, backbone_type="lynxnet", backbone_args=largs, spec_min=[-12.0], spec_max=[0.0])
+    load_synth(r.velocity_fn, synth_params("lynxnet", 128, 1, largs, wseed))
+    r = r.cuda().eval()
+    out2 = r(cond, infer=True, noise=dev(synth.synth_normal((bsz, 1, 128, t_len), s_rf)))
+    assert rel_err(out2, g["rf_euler10_out"]) < TOL_SAMPLER
+    r.velocity_fn.release_native()
+
+
+def test_headline_config_properties_full_size():
+    """BASELINE config 2 at full size (20x256 WaveNet, DPM-Solver++ 1000->50, B=1, T=1000), checked through
+    size-independent properties instead of the (slow) oracle: determinism, batch independence (utterances do
+    not interact), and time-locality (the receptive field of one NFE is +-75 frames)."""
+    set_hp(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
+    d = _gd(1000, in_dims=128, args=dict(num_layers=20, num_channels=256, dilation_cycle_length=4), wseed=42)
+    t_len = 1000
+    cond = dev(synth.synth_normal((2, t_len, 256), 900))
+    noise = dev(synth.synth_normal((2, 1, 128, t_len), 901))
+    out_b2 = d(cond, infer=True, noise=noise)
+    out_b1 = d(cond[1:2].contiguous(), infer=True, noise=noise[1:2].contiguous())
+    assert torch.isfinite(out_b2).all()
+    assert rel_err(out_b1, out_b2[1:2].cpu().numpy()) < 1e-6       # same arithmetic per utterance
+    net = d.denoise_fn
+    x = dev(synth.synth_normal((1, 1, 128, t_len), 902))
+    c1 = dev(synth.synth_normal((1, 256, t_len), 903))
+    t = dev(np.array([412.0], np.float32))
+    with torch.no_grad():
+        y1 = net(x, t, c1)
+        x2 = x.clone()
+        x2[..., 600:] += 1.0                                         # perturb frames >= 600
+        y2 = net(x2, t, c1)
+    assert torch.equal(y1[..., :600 - 75], y2[..., :600 - 75])      # outside the receptive field: identical
+    assert not torch.equal(y1[..., 600:], y2[..., 600:])
+    net.release_native()
+
+
+def test_reference_error_behaviour():
+    from diffsinger_amd.diffusion import RectifiedFlow
+    set_hp(diff_accelerator="nope", diff_speedup=10, K_step_infer=1000)
+    d = _gd(1000)
+    cond = dev(synth.synth_normal((1, 8, 256), 1))
+    with pytest.raises(ValueError, match="Unsupported acceleration algorithm"):
+        d(cond, infer=True)
+    set_hp(diff_accelerator="ddim", diff_speedup=7, K_step_infer=1000)
+    with pytest.raises(AssertionError, match="factor of diffusion depth"):
+        d(cond, infer=True)
+    set_hp(diff_accelerator="pndm", diff_speedup=20, K_step_infer=1000)
+    with pytest.raises(RuntimeError):
+        d(dev(synth.synth_normal((2, 8, 256), 1)), infer=True)
+    with pytest.raises(NotImplementedError):
+        d(cond, gt_spec=torch.zeros(1, 8, 32).cuda(), infer=False)
+    d.denoise_fn.release_native()
+    set_hp(use_shallow_diffusion=True, diff_accelerator="ddim", diff_speedup=10, K_step_infer=100)
+    d2 = _gd(400)
+    with pytest.raises(AssertionError, match="Missing shallow diffusion source"):
+        d2(cond, infer=True)
+    d2.denoise_fn.release_native()
+    set_hp(sampling_algorithm="nope", sampling_steps=4)
+    r = RectifiedFlow(32, 1, backbone_type="wavenet", backbone_args=SN["args"], spec_min=[-12.0], spec_max=[0.0])
+    load_synth(r.velocity_fn, synth_params("wavenet", 32, 1, SN["args"], SN["wseed"]))
+    with pytest.raises(ValueError, match="Unsupported algorithm for Rectified Flow"):
+        r.cuda()(cond, infer=True)
+    r.velocity_fn.release_native()
+
+
+def test_variance_wrappers_gpu_vs_oracle():
+    """PitchDiffusion / MultiVarianceDiffusion end to end (norm -> sample -> denorm/mean/clamp), config-5 shapes."""
+    from diffsinger_amd.diffusion import MultiVarianceRectifiedFlow, PitchDiffusion
+    args = dict(num_layers=4, num_channels=64, dilation_cycle_length=2)
+    bsz, t_len = 2, 40
+    cond = synth.synth_normal((bsz, t_len, 256), 70)
+    # pitch, DDIM
+    set_hp(diff_accelerator="ddim", diff_speedup=100, K_step_infer=1000)
+    p = PitchDiffusion(vmin=-8.0, vmax=8.0, cmin=-12.0, cmax=12.0, repeat_bins=64, backbone_type="wavenet",
+                       backbone_args=args)
+    params = synth_params("wavenet", 64, 1, args, 71)
+    load_synth(p.denoise_fn, params)
+    p = p.cuda().eval()
+    noise = synth.synth_normal((bsz, 1, 64, t_len), 72)
+    out = p(dev(cond), infer=True, noise=dev(noise))
+    fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=2)
+    nf, smin, smax = od.repetitive_spec_ranges(-8.0, 8.0)
+    o = od.GaussianDiffusion(fn, 64, nf, spec_min=smin, spec_max=smax)
+    xo = o.inference(np.ascontiguousarray(np.swapaxes(cond, 1, 2)), noise, diff_speedup=100, diff_accelerator="ddim",
+                     K_step_infer=1000)
+    want = od.pitch_denorm(o, xo, -12.0, 12.0)
+    assert tuple(out.shape) == want.shape == (bsz, t_len)
+    assert np.abs(out.cpu().numpy() - want).max() < 5e-3          # values clamp to [-12, 12]
+    p.denoise_fn.release_native()
+    # multi-variance (F = 2), reflow euler
+    set_hp(sampling_algorithm="euler", sampling_steps=8)
+    ranges, clamps = [(-96.0, -12.0), (-96.0, -20.0)], [(-96.0, 0.0), None]
+    m = MultiVarianceRectifiedFlow(ranges=ranges, clamps=clamps, repeat_bins=24, backbone_type="wavenet",
+                                   backbone_args=args)
+    params2 = synth_params("wavenet", 24, 2, args, 73)
+    load_synth(m.velocity_fn, params2)
+    m = m.cuda().eval()
+    noise2 = synth.synth_normal((bsz, 2, 24, t_len), 74)
+    outs = m(dev(cond), infer=True, noise=dev(noise2))
+    fn2 = lambda x, t, c: ob.wavenet_forward(params2, x, t, c, dilation_cycle_length=2)
+    nf, smin, smax = od.repetitive_spec_ranges([r[0] for r in ranges], [r[1] for r in ranges])
+    orf = od.RectifiedFlow(fn2, 24, nf, spec_min=smin, spec_max=smax)
+    xo = orf.inference(np.ascontiguousarray(np.swapaxes(cond, 1, 2)), noise2, sampling_algorithm="euler", sampling_steps=8)
+    want = od.multivar_denorm(orf, xo, clamps)
+    assert len(outs) == 2
+    for a, w in zip(outs, want):
+        assert np.abs(a.cpu().numpy() - w).max() < 2e-2 * max(1.0, np.abs(w).max()) * 1e-1
+    m.velocity_fn.release_native()
