@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the diffusion-denoiser hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): WaveNet 20 layers x 256 channels (dilation cycle 4, 128 mel bins,
+hidden 256), DPM-Solver++ 2M 1000 -> 50 steps (50 NFE), B = 1 utterance of T = 1000 frames per GPU, fp32,
+synthetic seeded weights/inputs.  One "step" = one whole sampling loop over the batch (cond hoist +
+50 NFE + fused solver updates + transposed/denormalised mel); inputs are resident in HBM when the timed
+region starts.  With N > 1 ranks each rank denoises its own utterances (weak scaling); the only exchange
+is the cond scatter before and the mel gather after the loop (RCCL over xGMI), both inside the timed step.
+
+value = mel-frames/s per denoise step = N * B * T * NFE / seconds per step  (whole-job aggregate).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+HOP, SR = 512, 44100
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=1000, help="mel frames per utterance (T)")
+    ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(params, t_len, cycle):
+    """The numpy oracle (a port of the reference algorithm, parity-pinned by tests/golden) timed on the host
+    cores of this box on a bounded sample of the same workload: NFE evaluations of the 20x256 WaveNet at
+    B=1, T=t_len - including, like the reference, the per-NFE conditioner projections."""
+    import numpy as np
+    from oracle import backbones as ob
+    from diffsinger_amd import synth
+    from threadpoolctl import threadpool_limits
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))          # the GPU box gives one GPU a 16-core CPU share
+    limiter = threadpool_limits(limits=cores)
+    x = synth.synth_normal((1, 1, 128, t_len), 1)
+    cond = synth.synth_normal((1, 256, t_len), 0)
+    t = np.array([500.0], np.float32)
+    ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=cycle)       # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=cycle)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or n >= 40:
+            break
+    limiter.unregister() if hasattr(limiter, "unregister") else None
+    return {"value": round(t_len * n / el, 1), "unit": "mel-frames/s per denoise step", "cores": int(cores),
+            "kind": "port", "sample": f"{n} backbone evaluations (NFE) of the same WaveNet at B=1, T={t_len}, "
+                                      f"numpy fp32 oracle, {el:.1f} s"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from diffsinger_amd import synth, sharding
+    from diffsinger_amd.hparams import hparams
+    from diffsinger_amd.diffusion import GaussianDiffusion
+
+    B, T = args.batch, args.frames
+    if args.workload == "wavenet_dpm50":
+        kind, bargs = "wavenet", dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+        hp = dict(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
+        nfe, wname = 50, "WaveNet 20x256 (cycle 4, 128 bins), DPM-Solver++ 2M 1000->50"
+    else:
+        kind, bargs = "lynxnet", dict(num_layers=6, num_channels=1024, expansion_factor=2, kernel_size=31,
+                                      activation="PReLU", strong_cond=True)
+        hp = dict(diff_accelerator="ddim", diff_speedup=10, K_step_infer=1000)
+        nfe, wname = 100, "LYNXNet 6x1024 (k31, strong_cond), DDIM 1000->100"
+    hparams.clear()
+    hparams.update(hidden_size=256, schedule_type="linear", use_shallow_diffusion=False, infer=False, **hp)
+    shapes = synth.backbone_param_shapes(kind, 128, 1, hidden_size=256, **bargs)
+    params = synth.synth_state_dict(shapes, seed=42)
+    d = GaussianDiffusion(128, 1, timesteps=1000, k_step=1000, backbone_type=kind, backbone_args=bargs,
+                          spec_min=[-12.0], spec_max=[0.0])
+    d.denoise_fn.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    d = d.to(device).eval()
+    d.use_graph = not args.no_graph
+
+    n_utt = world * B
+    cond_all = None
+    if rank == 0:
+        cond_all = torch.from_numpy(synth.synth_normal((n_utt, T, 256), 0)).to(device)
+    mine = sharding.shard_ranges(n_utt, world)[rank]
+    noise = sharding.utterance_noise((1, 128, T), mine, seed=1, device=device)      # x_T, resident before timing
+    cond_local = cond_all if world == 1 else None
+
+    def step():
+        if world == 1:
+            return d(cond_local, infer=True, noise=noise)
+        c = sharding.scatter_condition(cond_all, n_utt, T, 256, device)
+        mel = d(c, infer=True, noise=noise)
+        return sharding.gather_mels(mel, n_utt)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    if rank == 0:
+        assert out is not None and torch.isfinite(out).all()
+    sec_per_step = elapsed / max(args.steps, 1)
+    frames = n_utt * T * nfe
+    value = frames / sec_per_step
+
+    stats = d.denoise_fn.stats()
+    result = {
+        "metric": "mel-frames/sec (128-bin, 44.1 kHz hop) per denoise step; end-to-end RTF",
+        "value": round(value, 1),
+        "unit": "mel-frames/s per denoise step",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(sec_per_step * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wname, "utterances_per_gpu": B, "frames": T, "nfe": nfe,
+                   "hipgraph": bool(d.use_graph), "sharding": f"{world} rank(s) x {B} utterance(s), cond scatter + mel gather"},
+        "rtf": round(sec_per_step / (n_utt * T * HOP / SR), 6),
+        "ms_per_nfe": round(sec_per_step * 1e3 / nfe, 5),
+        "path_tflops": round(stats["flops_per_frame_nfe"] * frames / sec_per_step / 1e12 / world, 3),
+        "path_mfma_frac": round(stats["flops_per_frame_nfe"] * frames / sec_per_step / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),
+        "path_hbm_frac": round(stats["bytes_per_frame_nfe"] * frames / sec_per_step / 1e9 / world / PEAK_HBM_GBPS, 5),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel (WaveNet: dilated conv + FiLM + gate GEMM; LYNXNet: LN -> C->4C -> SwiGLU GEMM),
+        # bracketed by hipEvents on its own stream, one eager pass of the same workload
+        import ctypes as C
+        from diffsinger_amd import _lib
+        h = d.denoise_fn._handle
+        _lib.check(h, _lib.lib().dsd_kernel_timing(h, 1), "dsd_kernel_timing")
+        d(cond_all[:len(mine)] if world > 1 else cond_local, infer=True, noise=noise)
+        torch.cuda.synchronize(device)
+        mean_ms, n = C.c_double(), C.c_int64()
+        _lib.check(h, _lib.lib().dsd_kernel_timing_read(h, C.byref(mean_ms), C.byref(n)), "dsd_kernel_timing_read")
+        _lib.check(h, _lib.lib().dsd_kernel_timing(h, 0), "dsd_kernel_timing")
+        Cc = bargs["num_channels"]
+        if kind == "wavenet":
+            kflops = 2 * 3 * Cc * 2 * Cc * B * T              # 786,432 FLOP/frame
+            kbytes = (4 * Cc + 8 * Cc + 4 * Cc) * B * T       # read x, read hoisted cond-proj, write gated z
+            kname = "gemm_kernel<ST_FILM,3,EP_GATE> (dilated conv k=3 + FiLM + sigmoid*tanh gate)"
+        else:
+            inner = Cc * bargs["expansion_factor"]
+            kflops = 2 * Cc * 2 * inner * B * T
+            kbytes = (4 * Cc + 4 * inner) * B * T
+            kname = "gemm_kernel<ST_LN,1,EP_SWIGLU> (LayerNorm -> 1x1 C->4C -> SwiGLU)"
+        sec = mean_ms.value / 1e3
+        ach = kflops / sec / 1e12 if sec > 0 else 0.0
+        result["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                              "kernel": kname, "launches_timed": int(n.value),
+                              "avg_launch_us": round(mean_ms.value * 1e3, 3),
+                              "algorithmic_flops_per_launch": kflops, "algorithmic_bytes_per_launch": kbytes,
+                              "hbm_achieved_GBps": round(kbytes / sec / 1e9, 1) if sec > 0 else 0.0,
+                              "hbm_frac": round(kbytes / sec / 1e9 / PEAK_HBM_GBPS, 5) if sec > 0 else 0.0}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind == "wavenet":
+        result["cpu_baseline"] = cpu_baseline(params, T, bargs["dilation_cycle_length"])
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

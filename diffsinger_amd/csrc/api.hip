@@ -498,6 +498,10 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     int S = BN + 2 * p.HL;
     while (S % 32 != 16) S += 4;
     p.S = S;
+    p.mtiles = mtiles;
+    const int w4 = (BN + 2 * p.HL) / 4;
+    p.lpr_shift = 3;
+    while ((1 << p.lpr_shift) < w4) ++p.lpr_shift;
     return c;
 }
 

@@ -54,6 +54,8 @@ struct GemmP {
     int KC;                 // channels staged in LDS per chunk (multiple of 16)
     int T;                  // valid frames
     int tiles_per_b;
+    int mtiles;             // 64-row tiles (EP_GATE / EP_SWIGLU: 32 pairs each)
+    int lpr_shift;          // staging: 2^lpr_shift lanes per staged row (>= float4 per row)
     int dil;                // dilation (TAPS == 3)
     int HL;                 // halo columns staged on each side (multiple of 4, >= dil)
     int S;                  // LDS row stride in floats, S % 32 == 16

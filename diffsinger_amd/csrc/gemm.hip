@@ -38,6 +38,19 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-
 
 constexpr int PF = 4;   // A-fragment prefetch distance in k16 iterations
 
+// The weight-fragment ring is loaded with inline asm and waited for with hand-counted s_waitcnt vmcnt(N):
+// hipcc (ROCm 7.2) parks a conservative vmcnt(1) on the loop header for a loop-carried register ring, which
+// exposes the whole L2 latency once per group.  Form (ii) of cdna_hip_programming.md 5.7: "=v" loads, then a
+// wait statement that names the destinations "+v" so no consumer can be scheduled above it.  Inside the K loop
+// the ring loads are the only VMEM operations, so "all but the 2*(PF-1) youngest" is exactly "slot u landed".
+__device__ __forceinline__ void ring_load(f32x4& dst, const float* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ring_wait(f32x4& a, f32x4& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
 template <int STAGE, int TAPS, int EPI, int NB>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -46,9 +59,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.x / p.tiles_per_b;
-    const int t0 = (blockIdx.x - b * p.tiles_per_b) * BN;
-    const int mtile = blockIdx.y;
+    // 1-D grid, row tile fastest: with the dispatcher dealing workgroups round-robin over the 8 XCDs, the
+    // workgroups that stream the SAME weight rows (same mtile) land on the same XCD when mtiles % 8 == 0
+    // (8 tiles for C = 256), so each XCD's L2 serves 1/8 of the layer's weights (speed only).
+    const int mtile = blockIdx.x % p.mtiles;
+    const int rest = blockIdx.x / p.mtiles;
+    const int b = rest / p.tiles_per_b;
+    const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int K16 = p.K >> 4;
     const int S = p.S, HL = p.HL;
 
@@ -67,84 +84,143 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const int W4 = (BN + 2 * HL) >> 2;      // float4 per staged row
     const int lrow = lane >> 4, lcol = lane & 15;
 
+    // EP_GATE: the hoisted conditioner projection of this wave's outputs is fetched now and consumed in the
+    // epilogue, so its latency hides under the whole K loop.
+    float cpv[2][NB][4];
+    if (EPI == EP_GATE) {
+        const int chb = (mtile * 2 + wm) * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const float* cp = p.aux + (long)b * p.aux_bstride + t0 + wn * (16 * NB) + n * 16 + lcol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = chb + r;
+                cpv[0][n][r] = ch < p.C ? cp[(long)ch * p.aux_rstride] : 0.f;
+                cpv[1][n][r] = ch < p.C ? cp[(long)(ch + p.C) * p.aux_rstride] : 0.f;
+            }
+        }
+    }
+
     for (int kc = 0; kc < p.K; kc += p.KC) {
         const int kcn = min(p.KC, p.K - kc);
+        const int n16 = kcn >> 4;
+        const int nit = TAPS * n16;
+        // A-fragment ring: PF iterations (one k16 step of both row blocks each) are kept in flight.  The loop
+        // body is branch-free - offsets past the chunk's last block are clamped (the reload is never used) -
+        // because conditional refills make hipcc serialise every load behind an s_waitcnt vmcnt(0).
+        const long tap_jump = (long)(K16 - n16) * 256;
+        const long last_off = (long)((TAPS - 1) * K16 + (kc >> 4) + n16 - 1) * 256;
+        long pf_off = (long)(kc >> 4) * 256;
+        int pf_c = 0;
+        f32x4 ra0[PF], ra1[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {          // issued before staging: weights do not depend on LDS
+            const long off = pf_off < last_off ? pf_off : last_off;
+            ring_load(ra0[u], a0p + off);
+            ring_load(ra1[u], a1p + off);
+            const bool w = (++pf_c == n16);
+            pf_c = w ? 0 : pf_c;
+            pf_off += 256 + (w ? tap_jump : 0);
+        }
         if (kc > 0) __syncthreads();
         // ---------------- stage B chunk: rows [kc, kc+kcn), frames [t0-HL, t0+BN+HL) ----------------
-        for (int idx = tid; idx < kcn * W4; idx += 256) {
-            const int r = idx / W4;
-            const int c4 = idx - r * W4;
+        // 2^lpr_shift lanes walk one row (16-B loads along time), SU row-loads are issued back to back
+        // before the first one is consumed, so the L2/MALL latency is paid once per batch, not per row.
+        {
+            constexpr int SU = 8;
+            const int rows_per_it = 256 >> p.lpr_shift;
+            const int c4 = tid & ((1 << p.lpr_shift) - 1);
+            const int r_in = tid >> p.lpr_shift;
+            const bool col_ok = c4 < W4;
             const int tcol = t0 - HL + c4 * 4;
-            const int ch = kc + r;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ch < p.Kreal) v = *reinterpret_cast<const f32x4*>(bsrc + (long)ch * p.b_rstride + tcol);
-            float add = 0.f;
-            if (STAGE == ST_FILM && ch < p.Kreal) add = p.film[(long)ch * p.film_cstride + p.film_col0 + b * p.film_colb];
             f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, rstd = f32x4{1.f, 1.f, 1.f, 1.f};
             if (STAGE == ST_LN) {
                 const float* st = p.ln_stats + (long)b * 2 * p.ln_ts;
-                if (tcol >= 0 && tcol + 3 < p.ln_ts) {
+                if (col_ok && tcol >= 0 && tcol + 3 < p.ln_ts) {
                     mean = *reinterpret_cast<const f32x4*>(st + tcol);
                     rstd = *reinterpret_cast<const f32x4*>(st + p.ln_ts + tcol);
                 }
             }
+            for (int r0 = 0; r0 < kcn; r0 += rows_per_it * SU) {
+                f32x4 v[SU];
+                float add[SU];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int t = tcol + e;
-                float y = v[e];
-                if (STAGE == ST_FILM) y = y + add;
-                else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
-                else y = y / p.in_scale;     // exact for in_scale == 1; the skip sum is DIVIDED by sqrt(L) (wavenet.py:96)
-                const bool ok = (t >= 0) && (t < p.T) && (ch < p.Kreal);
-                v[e] = ok ? y : 0.f;       // zero padding applies AFTER the FiLM add (wavenet.py:36-38)
-            }
-            *reinterpret_cast<f32x4*>(&lds[r * S + c4 * 4]) = v;
-        }
-        __syncthreads();
-
-        // ---------------- MFMA over (tap, k16) with A prefetched PF iterations ahead ----------------
-        const int n16 = kcn >> 4;
-        const int nit = TAPS * n16;
-        const int kc16 = kc >> 4;
-        f32x4 ra0[PF], ra1[PF];
-        int pf_tap = 0, pf_c = 0;     // position of the next iteration to prefetch
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            if (u < nit) {
-                const long off = (long)(pf_tap * K16 + kc16 + pf_c) * 256;
-                ra0[u] = *reinterpret_cast<const f32x4*>(a0p + off);
-                ra1[u] = *reinterpret_cast<const f32x4*>(a1p + off);
-                if (++pf_c == n16) { pf_c = 0; ++pf_tap; }
-            }
-        }
-        int tap = 0, c16 = 0;
-        for (int it = 0; it < nit; it += PF) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                if (it + u < nit) {
-                    const f32x4 A0 = ra0[u], A1 = ra1[u];
-                    if (it + u + PF < nit) {
-                        const long off = (long)(pf_tap * K16 + kc16 + pf_c) * 256;
-                        ra0[u] = *reinterpret_cast<const f32x4*>(a0p + off);
-                        ra1[u] = *reinterpret_cast<const f32x4*>(a1p + off);
-                        if (++pf_c == n16) { pf_c = 0; ++pf_tap; }
+                for (int u = 0; u < SU; ++u) {
+                    const int r = r0 + u * rows_per_it + r_in;
+                    const int ch = kc + r;
+                    const bool ld = col_ok && r < kcn && ch < p.Kreal;
+                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    add[u] = 0.f;
+                    if (ld) {
+                        v[u] = *reinterpret_cast<const f32x4*>(bsrc + (long)ch * p.b_rstride + tcol);
+                        if (STAGE == ST_FILM) add[u] = p.film[(long)ch * p.film_cstride + p.film_col0 + b * p.film_colb];
                     }
-                    const int shift = HL + (TAPS == 3 ? (tap - 1) * p.dil : 0);
-                    const float* bl = &lds[(c16 * 16 + lrow) * S + wn * (16 * NB) + lcol + shift];
+                }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float bv[NB];
+                for (int u = 0; u < SU; ++u) {
+                    const int r = r0 + u * rows_per_it + r_in;
+                    const bool row_ok = (kc + r) < p.Kreal;
+                    f32x4 o;
 #pragma unroll
-                        for (int n = 0; n < NB; ++n) bv[n] = bl[j * 4 * S + n * 16];
-#pragma unroll
-                        for (int n = 0; n < NB; ++n) {
-                            acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], bv[n], acc[0][n], 0, 0, 0);
-                            acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], bv[n], acc[1][n], 0, 0, 0);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const int t = tcol + e;
+                        float y = v[u][e];
+                        if (STAGE == ST_FILM) y = y + add[u];
+                        else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
+                        else y = y / p.in_scale;   // exact for 1; the skip sum is DIVIDED by sqrt(L) (wavenet.py:96)
+                        const bool ok = (t >= 0) && (t < p.T) && row_ok;
+                        o[e] = ok ? y : 0.f;       // zero padding applies AFTER the FiLM add (wavenet.py:36-38)
                     }
-                    if (++c16 == n16) { c16 = 0; ++tap; }
+                    if (col_ok && r < kcn) *reinterpret_cast<f32x4*>(&lds[r * S + c4 * 4]) = o;
                 }
             }
+        }
+        // Everything hipcc counts (staging loads, the EP_GATE prefetch) and the ring prologue is retired here,
+        // visibly to the compiler (builtin, vmcnt(0) only), so that it parks no vmcnt wait of its own on the
+        // K-loop header; the ring prologue has had the whole staging phase to land.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+
+        // ---------------- MFMA over (tap, k16) ----------------
+        int c16 = 0;
+        int bsh = HL - (TAPS == 3 ? p.dil : 0);     // column shift of the current tap
+        const float* bl0 = &lds[lrow * S + wn * (16 * NB) + lcol];
+        auto compute = [&](const f32x4& A0, const f32x4& A1) {
+            const float* bl = bl0 + c16 * 16 * S + bsh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float bv[NB];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) bv[n] = bl[j * 4 * S + n * 16];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], bv[n], acc[0][n], 0, 0, 0);
+                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], bv[n], acc[1][n], 0, 0, 0);
+                }
+            }
+            const bool w = (++c16 == n16);
+            c16 = w ? 0 : c16;
+            bsh += w ? p.dil : 0;
+        };
+        const int groups = nit / PF, rem = nit - groups * PF;
+        for (int g = 0; g < groups; ++g) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                ring_wait<2 * (PF - 1)>(ra0[u], ra1[u]);
+                compute(ra0[u], ra1[u]);
+                __builtin_amdgcn_sched_barrier(0);      // refill only after the slot's last use has issued
+                const long off = pf_off < last_off ? pf_off : last_off;
+                ring_load(ra0[u], a0p + off);
+                ring_load(ra1[u], a1p + off);
+                const bool w = (++pf_c == n16);
+                pf_c = w ? 0 : pf_c;
+                pf_off += 256 + (w ? tap_jump : 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            ring_wait<0>(ra0[u], ra1[u]);       // drain: also keeps the compiler's own counting exact below
+            if (u < rem) compute(ra0[u], ra1[u]);
         }
     }
 
@@ -164,9 +240,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                     float u0 = acc[0][n][r], u1 = acc[1][n][r];
                     float y;
                     if (EPI == EP_GATE) {
-                        const float* cp = p.aux + (long)b * p.aux_bstride + t;
-                        u0 += cp[(long)ch * p.aux_rstride];
-                        u1 += cp[(long)(ch + p.C) * p.aux_rstride];
+                        u0 += cpv[0][n][r];
+                        u1 += cpv[1][n][r];
                         y = sigmoid_f(u0) * tanhf(u1);                 // wavenet.py:41-42
                     } else {
                         u0 += p.bias[ch];
@@ -236,7 +311,7 @@ static hipError_t set_attr() {
 template <int STAGE, int TAPS, int EPI, int NB>
 static hipError_t launch_one(const GemmP& p, int batch, int mtiles, hipStream_t st) {
     const int lds = gemm_lds_bytes(p.KC, p.S);
-    dim3 grid(batch * p.tiles_per_b, mtiles, 1);
+    dim3 grid(batch * p.tiles_per_b * mtiles, 1, 1);
     hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB>), grid, dim3(256), lds, st, p);
     return hipGetLastError();
 }
@@ -265,9 +340,7 @@ hipError_t gemm_init_all() {
     }
 
 hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int batch, hipStream_t st) {
-    int mtiles;
-    if (epi == EP_GATE || epi == EP_SWIGLU) mtiles = (p.C + 31) / 32;   // 32 pairs = 64 packed rows per tile
-    else mtiles = (p.M + 63) / 64;
+    const int mtiles = p.mtiles;
     DSD_CASE(ST_PLAIN, 1, EP_BIAS_ACT)
     DSD_CASE(ST_FILM, 3, EP_GATE)
     DSD_CASE(ST_PLAIN, 1, EP_RESSKIP)

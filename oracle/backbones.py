@@ -72,7 +72,8 @@ def _dilated_conv3(x, w, b, dil):
     xp[:, :, dil:dil + t] = x
     y = np.zeros((bsz, w.shape[0], t), dtype=F32)
     for k in range(3):
-        y += np.matmul(w[:, :, k], xp[:, :, k * dil:k * dil + t])
+        # contiguous tap matrix: a stride-3 view falls off numpy's BLAS path (170x slower)
+        y += np.matmul(np.ascontiguousarray(w[:, :, k]), xp[:, :, k * dil:k * dil + t])
     return (y + b[None, :, None]).astype(F32)
 
 
