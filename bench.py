@@ -16,6 +16,8 @@ value = mel-frames/s per denoise step = N * B * T * NFE / seconds per step  (who
 """
 from __future__ import annotations
 
+import os as _os0
+_os0.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 import argparse
 import json
 import os

@@ -36,7 +36,26 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
 
-constexpr int PF = 4;   // A-fragment prefetch distance in k16 iterations
+#ifdef DSD_STAMPS
+// Diagnostic build only (tools/stamp_profile.py): wave 0 of every workgroup records s_memtime at phase
+// boundaries into a buffer of its own; no output value depends on a stamp.
+__device__ unsigned long long g_stamps[8][4096][8];
+#define DSD_STAMP(i)                                                                              \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            g_stamps[EPI][blockIdx.x][i] = __builtin_amdgcn_s_memtime();                          \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+        }                                                                                         \
+    } while (0)
+extern "C" int dsd_dbg_read_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#else
+#define DSD_STAMP(i)
+#endif
+
+constexpr int PF = 8;   // A-fragment prefetch distance in k16 iterations (2 x 1 KiB loads each)
 
 // The weight-fragment ring is loaded with inline asm and waited for with hand-counted s_waitcnt vmcnt(N):
 // hipcc (ROCm 7.2) parks a conservative vmcnt(1) on the loop header for a loop-carried register ring, which
@@ -45,6 +64,12 @@ constexpr int PF = 4;   // A-fragment prefetch distance in k16 iterations
 // the ring loads are the only VMEM operations, so "all but the 2*(PF-1) youngest" is exactly "slot u landed".
 __device__ __forceinline__ void ring_load(f32x4& dst, const float* ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+__device__ __forceinline__ void pre_load(float& dst, const float* ptr) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+__device__ __forceinline__ void pre_wait4(float (&a)[4]) {      // after a vmcnt(0) drain: orders the consumers
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) :: "memory");
 }
 template <int N>
 __device__ __forceinline__ void ring_wait(f32x4& a, f32x4& b) {
@@ -68,6 +93,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int K16 = p.K >> 4;
     const int S = p.S, HL = p.HL;
+    DSD_STAMP(0);
 
     f32x4 acc[2][NB];
 #pragma unroll
@@ -87,19 +113,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     // EP_GATE: the hoisted conditioner projection of this wave's outputs is fetched now and consumed in the
     // epilogue, so its latency hides under the whole K loop.
     float cpv[2][NB][4];
-    if (EPI == EP_GATE) {
-        const int chb = (mtile * 2 + wm) * 16 + (lane >> 4) * 4;
+    auto epi_prefetch = [&]() {
+        if (EPI == EP_RESSKIP) {
+            // residual stream / running skip sum of this wave's outputs, fetched before the K loop.
+            // A 16-row block lies entirely in the residual half or in the skip half (C % 16 == 0): the base
+            // pointer is chosen with integer arithmetic on values already in SGPRs (a select between the two
+            // struct FIELDS makes hipcc load the pointer itself through a dependent vector load).
+            const unsigned long long xa = (unsigned long long)p.x, sa = (unsigned long long)p.skip;
 #pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            const float* cp = p.aux + (long)b * p.aux_bstride + t0 + wn * (16 * NB) + n * 16 + lcol;
+            for (int mb = 0; mb < 2; ++mb) {
+                const int row0 = mtile * 64 + (wm * 2 + mb) * 16;
+                const bool is_res = row0 < p.C;
+                const unsigned long long ba = is_res ? xa : sa;
+                const int rowb = (is_res ? row0 : row0 - p.C) + (lane >> 4) * 4;
+                const float* base = (const float*)ba;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ch = chb + r;
-                cpv[0][n][r] = ch < p.C ? cp[(long)ch * p.aux_rstride] : 0.f;
-                cpv[1][n][r] = ch < p.C ? cp[(long)(ch + p.C) * p.aux_rstride] : 0.f;
+                for (int n = 0; n < NB; ++n) {
+                    const long col = (long)b * p.o_bstride + t0 + wn * (16 * NB) + n * 16 + lcol;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        pre_load(cpv[mb][n][r], base + col + (long)(rowb + r) * p.o_rstride);
+                }
             }
         }
-    }
+        if (EPI == EP_GATE) {
+            const int chb = (mtile * 2 + wm) * 16 + (lane >> 4) * 4;
+    #pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const float* cp = p.aux + (long)b * p.aux_bstride + t0 + wn * (16 * NB) + n * 16 + lcol;
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = min(chb + r, p.C - 1);
+                    pre_load(cpv[0][n][r], cp + (long)ch * p.aux_rstride);
+                    pre_load(cpv[1][n][r], cp + (long)(ch + p.C) * p.aux_rstride);
+                }
+            }
+        }
+    };
 
     for (int kc = 0; kc < p.K; kc += p.KC) {
         const int kcn = min(p.KC, p.K - kc);
@@ -113,16 +163,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         long pf_off = (long)(kc >> 4) * 256;
         int pf_c = 0;
         f32x4 ra0[PF], ra1[PF];
+        auto ring_prologue = [&]() {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {          // issued before staging: weights do not depend on LDS
-            const long off = pf_off < last_off ? pf_off : last_off;
-            ring_load(ra0[u], a0p + off);
-            ring_load(ra1[u], a1p + off);
-            const bool w = (++pf_c == n16);
-            pf_c = w ? 0 : pf_c;
-            pf_off += 256 + (w ? tap_jump : 0);
-        }
+            for (int u = 0; u < PF; ++u) {
+                const long off = pf_off < last_off ? pf_off : last_off;
+                ring_load(ra0[u], a0p + off);
+                ring_load(ra1[u], a1p + off);
+                const bool w = (++pf_c == n16);
+                pf_c = w ? 0 : pf_c;
+                pf_off += 256 + (w ? tap_jump : 0);
+            }
+        };
         if (kc > 0) __syncthreads();
+        DSD_STAMP(1);
         // ---------------- stage B chunk: rows [kc, kc+kcn), frames [t0-HL, t0+BN+HL) ----------------
         // 2^lpr_shift lanes walk one row (16-B loads along time), SU row-loads are issued back to back
         // before the first one is consumed, so the L2/MALL latency is paid once per batch, not per row.
@@ -141,21 +194,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                     rstd = *reinterpret_cast<const f32x4*>(st + p.ln_ts + tcol);
                 }
             }
-            for (int r0 = 0; r0 < kcn; r0 += rows_per_it * SU) {
-                f32x4 v[SU];
-                float add[SU];
+            // Branch-free on purpose: every lane always loads from a clamped (in-bounds) address and the mask is
+            // applied by select afterwards.  Predicated loads become exec-masked branches, and hipcc then parks an
+            // s_waitcnt vmcnt(0) between consecutive loads - the whole batch serialises on memory latency.
+            const int c4c = col_ok ? c4 : W4 - 1;
+            const int tcolc = t0 - HL + c4c * 4;
+            const int ch_last = p.Kreal - 1;
+            f32x4 v[SU];
+            float add[SU];
+            auto issue = [&](int r0) {
 #pragma unroll
                 for (int u = 0; u < SU; ++u) {
-                    const int r = r0 + u * rows_per_it + r_in;
-                    const int ch = kc + r;
-                    const bool ld = col_ok && r < kcn && ch < p.Kreal;
-                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int ch = min(kc + r0 + u * rows_per_it + r_in, ch_last);
+                    v[u] = *reinterpret_cast<const f32x4*>(bsrc + (long)ch * p.b_rstride + tcolc);
                     add[u] = 0.f;
-                    if (ld) {
-                        v[u] = *reinterpret_cast<const f32x4*>(bsrc + (long)ch * p.b_rstride + tcol);
-                        if (STAGE == ST_FILM) add[u] = p.film[(long)ch * p.film_cstride + p.film_col0 + b * p.film_colb];
-                    }
+                    if (STAGE == ST_FILM) add[u] = p.film[(long)ch * p.film_cstride + p.film_col0 + b * p.film_colb];
                 }
+            };
+            auto finish = [&](int r0) {
 #pragma unroll
                 for (int u = 0; u < SU; ++u) {
                     const int r = r0 + u * rows_per_it + r_in;
@@ -167,47 +223,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                         float y = v[u][e];
                         if (STAGE == ST_FILM) y = y + add[u];
                         else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
-                        else y = y / p.in_scale;   // exact for 1; the skip sum is DIVIDED by sqrt(L) (wavenet.py:96)
+                        else if (p.in_scale != 1.f) y = y / p.in_scale;   // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
                         const bool ok = (t >= 0) && (t < p.T) && row_ok;
                         o[e] = ok ? y : 0.f;       // zero padding applies AFTER the FiLM add (wavenet.py:36-38)
                     }
                     if (col_ok && r < kcn) *reinterpret_cast<f32x4*>(&lds[r * S + c4 * 4]) = o;
                 }
+            };
+            // first batch of activation loads, THEN the weight ring + epilogue prefetch (all in flight together),
+            // then the LDS writes; hipcc's header wait of the remaining-batches loop no longer precedes any issue
+            const int batch = rows_per_it * SU;
+            issue(0);
+            ring_prologue();
+            if (kc == 0) epi_prefetch();
+            finish(0);
+            for (int r0 = batch; r0 < kcn; r0 += batch) {
+                issue(r0);
+                finish(r0);
             }
         }
         // Everything hipcc counts (staging loads, the EP_GATE prefetch) and the ring prologue is retired here,
         // visibly to the compiler (builtin, vmcnt(0) only), so that it parks no vmcnt wait of its own on the
         // K-loop header; the ring prologue has had the whole staging phase to land.
+        DSD_STAMP(2);
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        DSD_STAMP(3);
         __syncthreads();
+        DSD_STAMP(4);
 
         // ---------------- MFMA over (tap, k16) ----------------
-        int c16 = 0;
-        int bsh = HL - (TAPS == 3 ? p.dil : 0);     // column shift of the current tap
-        const float* bl0 = &lds[lrow * S + wn * (16 * NB) + lcol];
-        auto compute = [&](const f32x4& A0, const f32x4& A1) {
-            const float* bl = bl0 + c16 * 16 * S + bsh;
+        // B fragments are read one iteration ahead (two register sets), so the ds_read latency of step i+1
+        // hides under the 8*NB MFMAs of step i instead of draining the matrix pipe at every step.
+        int rc16 = 0;
+        const float* blp = &lds[lrow * S + wn * (16 * NB) + lcol] + (HL - (TAPS == 3 ? p.dil : 0));
+        const int b_step = 16 * S;
+        const int b_wrap = p.dil - (n16 - 1) * 16 * S;       // next tap: back to row 0, columns shifted by dil
+        float bq[2][4][NB];
+        auto read_b = [&](float (&bv)[4][NB]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float bv[NB];
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int n = 0; n < NB; ++n) bv[n] = bl[j * 4 * S + n * 16];
+                for (int n = 0; n < NB; ++n) bv[j][n] = blp[j * 4 * S + n * 16];
+            const bool w = (++rc16 == n16);
+            rc16 = w ? 0 : rc16;
+            blp += w ? b_wrap : b_step;
+        };
+        auto mfma_step = [&](const f32x4& A0, const f32x4& A1, const float (&bv)[4][NB]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
-                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], bv[n], acc[0][n], 0, 0, 0);
-                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], bv[n], acc[1][n], 0, 0, 0);
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], bv[j][n], acc[0][n], 0, 0, 0);
+                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], bv[j][n], acc[1][n], 0, 0, 0);
                 }
-            }
-            const bool w = (++c16 == n16);
-            c16 = w ? 0 : c16;
-            bsh += w ? p.dil : 0;
         };
+        read_b(bq[0]);
         const int groups = nit / PF, rem = nit - groups * PF;
         for (int g = 0; g < groups; ++g) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ring_wait<2 * (PF - 1)>(ra0[u], ra1[u]);
-                compute(ra0[u], ra1[u]);
+                read_b(bq[(u + 1) & 1]);                 // past the last step this reads in-bounds, unused data
+                mfma_step(ra0[u], ra1[u], bq[u & 1]);
                 __builtin_amdgcn_sched_barrier(0);      // refill only after the slot's last use has issued
                 const long off = pf_off < last_off ? pf_off : last_off;
                 ring_load(ra0[u], a0p + off);
@@ -220,10 +297,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             ring_wait<0>(ra0[u], ra1[u]);       // drain: also keeps the compiler's own counting exact below
-            if (u < rem) compute(ra0[u], ra1[u]);
+            if (u < rem) {
+                read_b(bq[(u + 1) & 1]);
+                mfma_step(ra0[u], ra1[u], bq[u & 1]);
+            }
         }
     }
 
+    if (EPI == EP_GATE || EPI == EP_RESSKIP) {      // prefetched operands: retired by the ring drain (vmcnt(0)) above
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) pre_wait4(cpv[i][n]);
+    }
+    DSD_STAMP(5);
     // ---------------------------------------- epilogue ----------------------------------------
     // C/D layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + reg.
     const int rq = (lane >> 4) * 4;
@@ -268,10 +355,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                     } else if (EPI == EP_RESSKIP) {
                         if (row < p.C) {                               // residual half (wavenet.py:47-48)
                             float* xp = p.x + (long)b * p.o_bstride + (long)row * p.o_rstride + t;
-                            *xp = (*xp + v) / 1.41421356237309504880f;
+                            *xp = (cpv[mb][n][r] + v) / 1.41421356237309504880f;
                         } else {                                       // skip half: running sum replaces stack+sum (wavenet.py:96)
                             float* sp = p.skip + (long)b * p.o_bstride + (long)(row - p.C) * p.o_rstride + t;
-                            *sp = p.first_layer ? v : (*sp + v);
+                            *sp = p.first_layer ? v : (cpv[mb][n][r] + v);
                         }
                     } else if (EPI == EP_LINCOMB) {
                         float outv[kMaxOut];
@@ -298,6 +385,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             }
         }
     }
+    DSD_STAMP(6);
 }
 
 int gemm_lds_bytes(int KC, int S) { return KC * S * 4; }
