@@ -463,7 +463,7 @@ int ensure_emb(dsd_handle* h, int ncols) {
 // ------------------------------------------------------------------------------------------
 struct GemmCall {
     GemmP p;
-    int stage, taps, epi, nb, batch;
+    int stage, taps, epi, nb, batch, fast;
 };
 
 GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b_bstride, int b_rstride, int batch,
@@ -480,7 +480,7 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     p.b_rstride = b_rstride;
     p.K = g.K;
     p.Kreal = g.Kreal;
-    p.KC = g.K < 256 ? g.K : 256;
+    p.KC = g.K < 256 ? g.K : 256;       // re-decided below once the LDS row stride is known
     p.T = T;
     p.dil = dil;
     p.HL = g.taps == 3 ? round_up(dil, 4) : 0;
@@ -499,14 +499,18 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     while (S % 32 != 16) S += 4;
     p.S = S;
     p.mtiles = mtiles;
+    p.rot_den = p.tiles_per_b > 0 ? p.tiles_per_b : 1;
     const int w4 = (BN + 2 * p.HL) / 4;
     p.lpr_shift = 3;
     while ((1 << p.lpr_shift) < w4) ++p.lpr_shift;
+    // a k=3 conv keeps all its input channels resident when they fit (the fast K walk does not mix taps and chunks)
+    if (g.taps == 3 && (long)g.K * S * 4 <= 144 * 1024) p.KC = g.K;
+    c.fast = (p.KC % 128 == 0) && (g.taps == 1 || p.KC == g.K) && gemm_has_fast(g.taps, c.nb, S);
     return c;
 }
 
 int run_gemm(dsd_handle* h, const GemmCall& c, hipStream_t st) {
-    hipError_t e = launch_gemm(c.p, c.stage, c.taps, c.epi, c.nb, c.batch, st);
+    hipError_t e = launch_gemm(c.p, c.stage, c.taps, c.epi, c.nb, c.fast, c.batch, st);
     if (e != hipSuccess) return fail(h, DSD_EHIP, "GEMM launch failed: %s", hipGetErrorString(e));
     return DSD_OK;
 }
@@ -740,7 +744,7 @@ int dsd_finalize_weights(dsd_handle* h) {
     destroy_graphs(h);
     if (h->blob) hipFree(h->blob);
     h->blob = nullptr;
-    h->blob_floats = h->blob_host.size() + 1024;     // tail guard: A prefetch never runs past it
+    h->blob_floats = h->blob_host.size() + 8192;     // tail guard: the fragment ring reads up to one group (2 x 8 KiB) past the end
     if (hipMalloc(&h->blob, h->blob_floats * sizeof(float)) != hipSuccess)
         return fail(h, DSD_ENOMEM, "hipMalloc(%zu bytes of packed weights) failed", h->blob_floats * 4);
     HIP_OK(h, hipMemset(h->blob, 0, h->blob_floats * sizeof(float)));

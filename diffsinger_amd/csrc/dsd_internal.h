@@ -55,6 +55,7 @@ struct GemmP {
     int T;                  // valid frames
     int tiles_per_b;
     int mtiles;             // 64-row tiles (EP_GATE / EP_SWIGLU: 32 pairs each)
+    int rot_den;            // K-walk rotation: start step = (tile index * nit / rot_den) % nit
     int lpr_shift;          // staging: 2^lpr_shift lanes per staged row (>= float4 per row)
     int dil;                // dilation (TAPS == 3)
     int HL;                 // halo columns staged on each side (multiple of 4, >= dil)
@@ -82,7 +83,8 @@ struct GemmP {
 };
 
 // gemm.hip
-hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int batch, hipStream_t st);
+hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int fast, int batch, hipStream_t st);
+bool gemm_has_fast(int taps, int nb, int S);
 int gemm_lds_bytes(int KC, int S);
 hipError_t gemm_init_all();
 

@@ -20,6 +20,8 @@
 //   * workgroup = 4 waves (one per SIMD) as 2 (rows) x 2 (frames); tile = 64 rows x 32*NB frames.
 //     Gate/SwiGLU pairs (row r and row r + C) are packed into the same wave so the nonlinearity
 //     is a pure register epilogue.
+#include <type_traits>
+
 #include "dsd_internal.h"
 
 namespace dsd {
@@ -76,13 +78,25 @@ __device__ __forceinline__ void ring_wait(f32x4& a, f32x4& b) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
-template <int STAGE, int TAPS, int EPI, int NB>
+// Fast-path form: SGPR base + 32-bit lane offset + immediate, so a refill costs one instruction and no
+// per-iteration address arithmetic.  `base` is advanced with SALU adds only (an SGPR written by a VALU
+// readfirstlane needs 5 wait states before a VMEM reads it; it is produced once, long before its first use).
+template <int IMM>
+__device__ __forceinline__ void ring_load_s(f32x4& dst, unsigned voff, unsigned long long base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+
+// SW > 0: "fast" instantiation - LDS row stride S == SW is a compile-time constant (every B-fragment read is
+// base + immediate), the K walk is linear in groups of 8 steps (K % 128 == 0 and no tap/chunk mixing), so a
+// k16 step is 8*NB MFMAs + 4*NB ds_read + 2 loads + 1 counted wait and nothing else.  SW == 0: generic
+// instantiation (runtime S, any K multiple of 16, rotation-free wraparound walk) for every other shape.
+template <int STAGE, int TAPS, int EPI, int NB, int SW>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BN = 32 * NB;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (SGPR)
     const int wm = wave >> 1, wn = wave & 1;
     // 1-D grid, row tile fastest: with the dispatcher dealing workgroups round-robin over the 8 XCDs, the
     // workgroups that stream the SAME weight rows (same mtile) land on the same XCD when mtiles % 8 == 0
@@ -92,7 +106,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const int b = rest / p.tiles_per_b;
     const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int K16 = p.K >> 4;
-    const int S = p.S, HL = p.HL;
+    const int S = SW > 0 ? SW : p.S;
+    const int HL = p.HL;
     DSD_STAMP(0);
 
     f32x4 acc[2][NB];
@@ -156,22 +171,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         const int n16 = kcn >> 4;
         const int nit = TAPS * n16;
         // A-fragment ring: PF iterations (one k16 step of both row blocks each) are kept in flight.  The loop
-        // body is branch-free - offsets past the chunk's last block are clamped (the reload is never used) -
-        // because conditional refills make hipcc serialise every load behind an s_waitcnt vmcnt(0).
-        const long tap_jump = (long)(K16 - n16) * 256;
-        const long last_off = (long)((TAPS - 1) * K16 + (kc >> 4) + n16 - 1) * 256;
-        long pf_off = (long)(kc >> 4) * 256;
-        int pf_c = 0;
+        // body is branch-free (conditional refills make hipcc serialise every load behind an s_waitcnt vmcnt(0)):
+        // the (k16, tap) position simply wraps around, so refills past the end re-read valid, unused blocks.
+        // The walk over the nit = TAPS * n16 steps starts at a per-workgroup ROTATION: the workgroups that
+        // stream the same weight rows run in lockstep, and without it they all hit the same L2 channel with the
+        // same 1 KiB block at the same moment.  Summation order therefore depends on the tile index only
+        // (deterministic; fp32 rounding differs between tiles by the usual reassociation error).
+        const int kc16 = kc >> 4;
+        const int rot = SW > 0 ? 0 : (int)(((long)rest * nit) / p.rot_den) % nit;
+        int pf_tap = rot / n16;
+        int pf_c = rot - pf_tap * n16;
         f32x4 ra0[PF], ra1[PF];
+        // fast path: byte address of this wave's block (tap 0, k16 = kc16) as a scalar; blocks follow linearly
+        const unsigned long long a0s =
+            (unsigned long long)(p.A + ((long)(mtile * 4 + wm * 2) * (TAPS * K16) + kc16) * 256);
+        const unsigned long long a1s = a0s + (unsigned long long)a_blk * 4;
+        unsigned long long an0 = a0s, an1 = a1s;            // base of the group the next refills belong to
+        const unsigned voff0 = lane * 16, voff1 = lane * 16 + 4096;
+        auto ring_issue = [&](f32x4& d0, f32x4& d1) {        // generic path
+#ifdef DSD_EXP_NOSTREAM
+            const long off = 0;      // diagnostic: every fragment load hits the same (L1-resident) block
+#else
+            const long off = (long)(pf_tap * K16 + kc16 + pf_c) * 256;
+#endif
+            ring_load(d0, a0p + off);
+            ring_load(d1, a1p + off);
+            const bool w = (++pf_c == n16);
+            pf_c = w ? 0 : pf_c;
+            pf_tap += w ? 1 : 0;
+            pf_tap = (pf_tap == TAPS) ? 0 : pf_tap;
+        };
+        auto ring_group_fast = [&](auto uc) {                // fast path: slot u of the group at an0/an1
+            constexpr int u = decltype(uc)::value;
+            ring_load_s<(u & 3) * 1024>(ra0[u], u < 4 ? voff0 : voff1, an0);
+            ring_load_s<(u & 3) * 1024>(ra1[u], u < 4 ? voff0 : voff1, an1);
+        };
         auto ring_prologue = [&]() {
+            if constexpr (SW > 0) {
+                ring_group_fast(std::integral_constant<int, 0>{});
+                ring_group_fast(std::integral_constant<int, 1>{});
+                ring_group_fast(std::integral_constant<int, 2>{});
+                ring_group_fast(std::integral_constant<int, 3>{});
+                ring_group_fast(std::integral_constant<int, 4>{});
+                ring_group_fast(std::integral_constant<int, 5>{});
+                ring_group_fast(std::integral_constant<int, 6>{});
+                ring_group_fast(std::integral_constant<int, 7>{});
+                an0 += 8192;
+                an1 += 8192;
+            } else {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const long off = pf_off < last_off ? pf_off : last_off;
-                ring_load(ra0[u], a0p + off);
-                ring_load(ra1[u], a1p + off);
-                const bool w = (++pf_c == n16);
-                pf_c = w ? 0 : pf_c;
-                pf_off += 256 + (w ? tap_jump : 0);
+                for (int u = 0; u < PF; ++u) ring_issue(ra0[u], ra1[u]);
             }
         };
         if (kc > 0) __syncthreads();
@@ -254,19 +303,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         // ---------------- MFMA over (tap, k16) ----------------
         // B fragments are read one iteration ahead (two register sets), so the ds_read latency of step i+1
         // hides under the 8*NB MFMAs of step i instead of draining the matrix pipe at every step.
-        int rc16 = 0;
-        const float* blp = &lds[lrow * S + wn * (16 * NB) + lcol] + (HL - (TAPS == 3 ? p.dil : 0));
-        const int b_step = 16 * S;
-        const int b_wrap = p.dil - (n16 - 1) * 16 * S;       // next tap: back to row 0, columns shifted by dil
+        int rtap = rot / n16;
+        int rc16 = rot - rtap * n16;
+        const float* bl0 = &lds[lrow * S + wn * (16 * NB) + lcol] + (HL - (TAPS == 3 ? p.dil : 0));
         float bq[2][4][NB];
         auto read_b = [&](float (&bv)[4][NB]) {
+            const float* blp = bl0 + rc16 * (16 * S) + (TAPS == 3 ? rtap * p.dil : 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int n = 0; n < NB; ++n) bv[j][n] = blp[j * 4 * S + n * 16];
             const bool w = (++rc16 == n16);
             rc16 = w ? 0 : rc16;
-            blp += w ? b_wrap : b_step;
+            rtap += w ? 1 : 0;
+            rtap = (rtap == TAPS) ? 0 : rtap;
         };
         auto mfma_step = [&](const f32x4& A0, const f32x4& A1, const float (&bv)[4][NB]) {
 #pragma unroll
@@ -277,21 +327,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                     acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], bv[j][n], acc[1][n], 0, 0, 0);
                 }
         };
+        if constexpr (SW > 0) {
+            static_assert(PF == 8, "fast path walks groups of 8 k16 steps");
+            const int groups = nit >> 3;
+            const int gpt = n16 >> 3;                         // groups per tap
+            int gt = 0;
+            auto read_bf = [&](float (&bv)[4][NB], const float* base, auto uc) {
+                constexpr int u = decltype(uc)::value;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) bv[j][n] = base[(u * 16 + j * 4) * SW + n * 16];
+            };
+            const float* bt = bl0;
+            read_bf(bq[0], bt, std::integral_constant<int, 0>{});
+            for (int g = 0; g < groups; ++g) {
+                const bool wrap = (++gt == gpt);
+                gt = wrap ? 0 : gt;
+                const float* btn = bt + (wrap ? (TAPS == 3 ? p.dil : 0) - (n16 - 8) * 16 * SW : 8 * 16 * SW);
+#define DSD_FAST_STEP(U)                                                                           \
+    ring_wait<2 * (PF - 1)>(ra0[U], ra1[U]);                                                        \
+    if constexpr (U < 7) read_bf(bq[(U + 1) & 1], bt, std::integral_constant<int, (U + 1) & 7>{}); \
+    else read_bf(bq[0], btn, std::integral_constant<int, 0>{});                                    \
+    mfma_step(ra0[U], ra1[U], bq[U & 1]);                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    ring_group_fast(std::integral_constant<int, U>{});
+                DSD_FAST_STEP(0) DSD_FAST_STEP(1) DSD_FAST_STEP(2) DSD_FAST_STEP(3)
+                DSD_FAST_STEP(4) DSD_FAST_STEP(5) DSD_FAST_STEP(6) DSD_FAST_STEP(7)
+#undef DSD_FAST_STEP
+                bt = btn;
+                an0 += 8192;
+                an1 += 8192;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) ring_wait<0>(ra0[u], ra1[u]);     // drain
+        } else {
         read_b(bq[0]);
         const int groups = nit / PF, rem = nit - groups * PF;
         for (int g = 0; g < groups; ++g) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 ring_wait<2 * (PF - 1)>(ra0[u], ra1[u]);
-                read_b(bq[(u + 1) & 1]);                 // past the last step this reads in-bounds, unused data
+                read_b(bq[(u + 1) & 1]);                 // past the last step this wraps to a valid, unused block
                 mfma_step(ra0[u], ra1[u], bq[u & 1]);
                 __builtin_amdgcn_sched_barrier(0);      // refill only after the slot's last use has issued
-                const long off = pf_off < last_off ? pf_off : last_off;
-                ring_load(ra0[u], a0p + off);
-                ring_load(ra1[u], a1p + off);
-                const bool w = (++pf_c == n16);
-                pf_c = w ? 0 : pf_c;
-                pf_off += 256 + (w ? tap_jump : 0);
+                ring_issue(ra0[u], ra1[u]);
             }
         }
 #pragma unroll
@@ -301,6 +381,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                 read_b(bq[(u + 1) & 1]);
                 mfma_step(ra0[u], ra1[u], bq[u & 1]);
             }
+        }
         }
     }
 
@@ -390,45 +471,72 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 
 int gemm_lds_bytes(int KC, int S) { return KC * S * 4; }
 
-template <int STAGE, int TAPS, int EPI, int NB>
+template <int STAGE, int TAPS, int EPI, int NB, int SW>
 static hipError_t set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<STAGE, TAPS, EPI, NB>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<STAGE, TAPS, EPI, NB, SW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-template <int STAGE, int TAPS, int EPI, int NB>
-static hipError_t launch_one(const GemmP& p, int batch, int mtiles, hipStream_t st) {
+template <int STAGE, int TAPS, int EPI, int NB, int SW>
+static hipError_t launch_one(const GemmP& p, int batch, hipStream_t st) {
     const int lds = gemm_lds_bytes(p.KC, p.S);
-    dim3 grid(batch * p.tiles_per_b * mtiles, 1, 1);
-    hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB>), grid, dim3(256), lds, st, p);
+    dim3 grid(batch * p.tiles_per_b * p.mtiles, 1, 1);
+    hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW>), grid, dim3(256), lds, st, p);
     return hipGetLastError();
 }
 
-#define DSD_ATTR(ST, TP, EP)                                         \
-    if ((e = set_attr<ST, TP, EP, 1>()) != hipSuccess) return e;     \
-    if ((e = set_attr<ST, TP, EP, 2>()) != hipSuccess) return e;
+// fast instantiations exist for S = 48 / 80 (32-frame tiles) and 80 / 112 (64-frame tiles); 1x1 GEMMs have
+// no halo, so only the smaller stride of each tile width occurs for them
+bool gemm_has_fast(int taps, int nb, int S) {
+    if (nb == 1) return S == 48 || (taps == 3 && S == 80);
+    return S == 80 || (taps == 3 && S == 112);
+}
+
+template <int STAGE, int TAPS, int EPI>
+static hipError_t dispatch(const GemmP& p, int nb, int fast, int batch, hipStream_t st) {
+    if (nb == 1) {
+        if (fast && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48>(p, batch, st);
+        if constexpr (TAPS == 3)
+            if (fast && p.S == 80) return launch_one<STAGE, TAPS, EPI, 1, 80>(p, batch, st);
+        return launch_one<STAGE, TAPS, EPI, 1, 0>(p, batch, st);
+    }
+    if (fast && p.S == 80) return launch_one<STAGE, TAPS, EPI, 2, 80>(p, batch, st);
+    if constexpr (TAPS == 3)
+        if (fast && p.S == 112) return launch_one<STAGE, TAPS, EPI, 2, 112>(p, batch, st);
+    return launch_one<STAGE, TAPS, EPI, 2, 0>(p, batch, st);
+}
+
+template <int STAGE, int TAPS, int EPI>
+static hipError_t attr_all() {
+    hipError_t e;
+    if ((e = set_attr<STAGE, TAPS, EPI, 1, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<STAGE, TAPS, EPI, 2, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<STAGE, TAPS, EPI, 1, 48>()) != hipSuccess) return e;
+    if ((e = set_attr<STAGE, TAPS, EPI, 2, 80>()) != hipSuccess) return e;
+    if constexpr (TAPS == 3) {
+        if ((e = set_attr<STAGE, TAPS, EPI, 1, 80>()) != hipSuccess) return e;
+        if ((e = set_attr<STAGE, TAPS, EPI, 2, 112>()) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 // Raise the dynamic-LDS limit of every instantiation once, outside any stream capture.
 hipError_t gemm_init_all() {
     hipError_t e;
-    DSD_ATTR(ST_PLAIN, 1, EP_BIAS_ACT)
-    DSD_ATTR(ST_FILM, 3, EP_GATE)
-    DSD_ATTR(ST_PLAIN, 1, EP_RESSKIP)
-    DSD_ATTR(ST_PLAIN, 1, EP_LINCOMB)
-    DSD_ATTR(ST_LN, 1, EP_SWIGLU)
-    DSD_ATTR(ST_PLAIN, 1, EP_BIAS_RES)
-    DSD_ATTR(ST_LN, 1, EP_LINCOMB)
+    if ((e = attr_all<ST_PLAIN, 1, EP_BIAS_ACT>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_FILM, 3, EP_GATE>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_PLAIN, 1, EP_RESSKIP>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_PLAIN, 1, EP_LINCOMB>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_LN, 1, EP_SWIGLU>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_PLAIN, 1, EP_BIAS_RES>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_LN, 1, EP_LINCOMB>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
-#define DSD_CASE(ST, TP, EP)                                                         \
-    if (stage == ST && taps == TP && epi == EP) {                                    \
-        return nb == 1 ? launch_one<ST, TP, EP, 1>(p, batch, mtiles, st)             \
-                       : launch_one<ST, TP, EP, 2>(p, batch, mtiles, st);            \
-    }
+#define DSD_CASE(ST, TP, EP) \
+    if (stage == ST && taps == TP && epi == EP) return dispatch<ST, TP, EP>(p, nb, fast, batch, st);
 
-hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int batch, hipStream_t st) {
-    const int mtiles = p.mtiles;
+hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int fast, int batch, hipStream_t st) {
     DSD_CASE(ST_PLAIN, 1, EP_BIAS_ACT)
     DSD_CASE(ST_FILM, 3, EP_GATE)
     DSD_CASE(ST_PLAIN, 1, EP_RESSKIP)

@@ -13,8 +13,9 @@ CSRC = os.path.join(ROOT, "diffsinger_amd", "csrc")
 OUT = os.path.join(ROOT, "diffsinger_amd", "libdsdenoise_stamps.so")
 srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "aux_kernels.hip", "api.hip")]
 if not os.path.exists(OUT) or any(os.path.getmtime(s) > os.path.getmtime(OUT) for s in srcs):
+    extra = [a for a in sys.argv[1:] if a.startswith("-D")]
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DDSD_STAMPS",
-                    "-shared", "-o", OUT] + srcs, check=True)
+                    "-w", "-shared", "-o", OUT] + extra + srcs, check=True)
 if "--build-only" in sys.argv:
     sys.exit(0)
 
@@ -27,7 +28,7 @@ from diffsinger_amd.hparams import hparams
 hparams.update(hidden_size=256)
 from diffsinger_amd.backbones import build_backbone
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for a in sys.argv[1:] if not a.startswith("-")]
 B = int(args[0]) if args else 1
 T = int(args[1]) if len(args) > 1 else 1000
 bargs = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
