@@ -186,8 +186,11 @@ def main():
         _lib.check(h, _lib.lib().dsd_kernel_timing(h, 1), "dsd_kernel_timing")
         d(cond_all[:len(mine)] if world > 1 else cond_local, infer=True, noise=noise)
         torch.cuda.synchronize(device)
-        mean_ms, n = C.c_double(), C.c_int64()
-        _lib.check(h, _lib.lib().dsd_kernel_timing_read(h, C.byref(mean_ms), C.byref(n)), "dsd_kernel_timing_read")
+        raw_ms, empty_ms, n = C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(h, _lib.lib().dsd_kernel_timing_read(h, C.byref(raw_ms), C.byref(empty_ms), C.byref(n)),
+                   "dsd_kernel_timing_read")
+        # a hipEvent bracket costs time by itself (two back-to-back records, measured in the same pass)
+        mean_ms = C.c_double(max(raw_ms.value - empty_ms.value, 1e-9))
         _lib.check(h, _lib.lib().dsd_kernel_timing(h, 0), "dsd_kernel_timing")
         Cc = bargs["num_channels"]
         if kind == "wavenet":
@@ -199,12 +202,23 @@ def main():
             kflops = 2 * Cc * 2 * inner * B * T
             kbytes = (4 * Cc + 4 * inner) * B * T
             kname = "gemm_kernel<ST_LN,1,EP_SWIGLU> (LayerNorm -> 1x1 C->4C -> SwiGLU)"
+        traffic, traffic_src = None, None
+        try:   # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of this same command
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            ent = tj.get(f"{args.workload}/B{B}/T{T}")
+            if ent:
+                traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
+        except Exception:
+            pass
         sec = mean_ms.value / 1e3
         ach = kflops / sec / 1e12 if sec > 0 else 0.0
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                              "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                              "traffic_source": traffic_src,
                               "kernel": kname, "launches_timed": int(n.value),
                               "avg_launch_us": round(mean_ms.value * 1e3, 3),
+                              "event_bracket_raw_us": round(raw_ms.value * 1e3, 3),
+                              "event_bracket_empty_us": round(empty_ms.value * 1e3, 3),
                               "algorithmic_flops_per_launch": kflops, "algorithmic_bytes_per_launch": kbytes,
                               "hbm_achieved_GBps": round(kbytes / sec / 1e9, 1) if sec > 0 else 0.0,
                               "hbm_frac": round(kbytes / sec / 1e9 / PEAK_HBM_GBPS, 5) if sec > 0 else 0.0}

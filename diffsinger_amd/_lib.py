@@ -86,7 +86,7 @@ def _load():
     lib.dsd_sample.argtypes = [vp, C.POINTER(DsdProgram), vp, vp, vp, vp, vp, C.c_uint32, vp]
     lib.dsd_get_stats.argtypes = [vp, C.POINTER(DsdStats)]
     lib.dsd_kernel_timing.argtypes = [vp, i32]
-    lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
+    lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     for name in EXPORTS:
         getattr(lib, name)
     if lib.dsd_api_version() != 1:

@@ -83,6 +83,8 @@ struct dsd_handle {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> cal_pool;   // back-to-back pairs: the cost of the bracket itself
+    size_t cal_used = 0;
 };
 
 namespace {
@@ -358,12 +360,12 @@ int ensure_workspace(dsd_handle* h, int B, int T) {
     if (h->arena && h->B == B && h->T == T) return DSD_OK;
     // shape change: drop everything that depends on it
     for (auto& kv : h->graphs) {
-        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
-        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     h->graphs.clear();
-    if (h->arena) hipFree(h->arena);
-    if (h->state) hipFree(h->state);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->state) (void)hipFree(h->state);
     h->arena = nullptr;
     h->state = nullptr;
     h->state_nbufs = 0;
@@ -407,7 +409,7 @@ int ensure_workspace(dsd_handle* h, int B, int T) {
 
 int ensure_state(dsd_handle* h, int nbufs) {
     if (h->state && h->state_nbufs >= nbufs) return DSD_OK;
-    if (h->state) hipFree(h->state);
+    if (h->state) (void)hipFree(h->state);
     h->state = nullptr;
     const size_t per = ((size_t)h->B * FM_of(h) * h->Ts + 63) / 64 * 64 + 64;
     const size_t total = kGuard * 2 + per * nbufs;
@@ -420,8 +422,8 @@ int ensure_state(dsd_handle* h, int nbufs) {
     h->state_buf_floats = per;
     // cached graphs captured the old pointers
     for (auto& kv : h->graphs) {
-        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
-        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     h->graphs.clear();
     return DSD_OK;
@@ -430,11 +432,11 @@ inline float* state_buf(dsd_handle* h, int i) { return h->state + kGuard + h->st
 
 int ensure_emb(dsd_handle* h, int ncols) {
     if (h->emb_arena && h->emb_cols >= ncols) return DSD_OK;
-    if (h->emb_arena) hipFree(h->emb_arena);
+    if (h->emb_arena) (void)hipFree(h->emb_arena);
     h->emb_arena = nullptr;
     for (auto& kv : h->graphs) {
-        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
-        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     h->graphs.clear();
     const int cap = round_up(ncols, 64);
@@ -544,17 +546,28 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
         if (!h->timing) return;
         if (h->ev_used == h->ev_pool.size()) {
             hipEvent_t a, b;
-            hipEventCreate(&a);
-            hipEventCreate(&b);
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
             h->ev_pool.emplace_back(a, b);
         }
-        hipEventRecord(h->ev_pool[h->ev_used].first, st);
+        (void)hipEventRecord(h->ev_pool[h->ev_used].first, st);
     };
     auto timed_end = [&]() {
         if (!h->timing) return;
-        hipEventRecord(h->ev_pool[h->ev_used].second, st);
+        (void)hipEventRecord(h->ev_pool[h->ev_used].second, st);
         ++h->ev_used;
     };
+    if (h->timing) {      // one empty bracket per evaluation calibrates what a hipEvent pair itself costs
+        if (h->cal_used == h->cal_pool.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            h->cal_pool.emplace_back(a, b);
+        }
+        (void)hipEventRecord(h->cal_pool[h->cal_used].first, st);
+        (void)hipEventRecord(h->cal_pool[h->cal_used].second, st);
+        ++h->cal_used;
+    }
     {   // input projection (+ReLU for WaveNet, wavenet.py:86-88; GELU unless strong_cond for LYNXNet, lynxnet.py:141-143)
         GemmCall g = make_gemm(h, h->g_inproj, xin_state, (long)FM * Ts, Ts, B, T, ST_PLAIN, EP_BIAS_ACT, 0);
         g.p.act = is_wavenet(h) ? ACT_RELU : (h->cfg.strong_cond ? ACT_NONE : ACT_GELU);
@@ -624,8 +637,8 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
 
 void destroy_graphs(dsd_handle* h) {
     for (auto& kv : h->graphs) {
-        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
-        if (kv.second.graph) hipGraphDestroy(kv.second.graph);
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     h->graphs.clear();
 }
@@ -679,16 +692,20 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
 
 void dsd_destroy(dsd_handle* h) {
     if (!h) return;
-    hipSetDevice(h->cfg.device);
+    (void)hipSetDevice(h->cfg.device);
     destroy_graphs(h);
     for (auto& ev : h->ev_pool) {
-        hipEventDestroy(ev.first);
-        hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
     }
-    if (h->blob) hipFree(h->blob);
-    if (h->arena) hipFree(h->arena);
-    if (h->state) hipFree(h->state);
-    if (h->emb_arena) hipFree(h->emb_arena);
+    for (auto& ev : h->cal_pool) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (h->blob) (void)hipFree(h->blob);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->state) (void)hipFree(h->state);
+    if (h->emb_arena) (void)hipFree(h->emb_arena);
     delete h;
 }
 
@@ -742,7 +759,7 @@ int dsd_finalize_weights(dsd_handle* h) {
     int rc = build_packed(h);
     if (rc) return rc;
     destroy_graphs(h);
-    if (h->blob) hipFree(h->blob);
+    if (h->blob) (void)hipFree(h->blob);
     h->blob = nullptr;
     h->blob_floats = h->blob_host.size() + 8192;     // tail guard: the fragment ring reads up to one group (2 x 8 KiB) past the end
     if (hipMalloc(&h->blob, h->blob_floats * sizeof(float)) != hipSuccess)
@@ -895,21 +912,21 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
             HIP_OK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             hipError_t ce = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
             if (ce != hipSuccess) {
-                hipStreamDestroy(cs);
+                (void)hipStreamDestroy(cs);
                 return fail(h, DSD_EHIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(ce));
             }
             rc = body(cs);
             GraphEntry ge;
             ce = hipStreamEndCapture(cs, &ge.graph);
-            hipStreamDestroy(cs);
+            (void)hipStreamDestroy(cs);
             if (rc) {
-                if (ge.graph) hipGraphDestroy(ge.graph);
+                if (ge.graph) (void)hipGraphDestroy(ge.graph);
                 return rc;
             }
             if (ce != hipSuccess) return fail(h, DSD_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
             ce = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0);
             if (ce != hipSuccess) {
-                hipGraphDestroy(ge.graph);
+                (void)hipGraphDestroy(ge.graph);
                 return fail(h, DSD_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ce));
             }
             if (h->graphs.size() >= 16) destroy_graphs(h);
@@ -949,22 +966,31 @@ int dsd_kernel_timing(dsd_handle* h, int32_t enable) {
     if (!h) return DSD_EINVAL;
     h->timing = enable != 0;
     h->ev_used = 0;
+    h->cal_used = 0;
     return DSD_OK;
 }
 
-int dsd_kernel_timing_read(dsd_handle* h, double* mean_ms, int64_t* launches) {
-    if (!h || !mean_ms || !launches) return DSD_EINVAL;
+int dsd_kernel_timing_read(dsd_handle* h, double* mean_ms, double* empty_pair_ms, int64_t* launches) {
+    if (!h || !mean_ms || !empty_pair_ms || !launches) return DSD_EINVAL;
     HIP_OK(h, hipSetDevice(h->cfg.device));
-    double sum = 0;
+    double sum = 0, cal = 0;
     for (size_t i = 0; i < h->ev_used; ++i) {
         HIP_OK(h, hipEventSynchronize(h->ev_pool[i].second));
         float ms = 0.f;
         HIP_OK(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
         sum += ms;
     }
+    for (size_t i = 0; i < h->cal_used; ++i) {
+        HIP_OK(h, hipEventSynchronize(h->cal_pool[i].second));
+        float ms = 0.f;
+        HIP_OK(h, hipEventElapsedTime(&ms, h->cal_pool[i].first, h->cal_pool[i].second));
+        cal += ms;
+    }
     *launches = (int64_t)h->ev_used;
     *mean_ms = h->ev_used ? sum / (double)h->ev_used : 0.0;
+    *empty_pair_ms = h->cal_used ? cal / (double)h->cal_used : 0.0;
     h->ev_used = 0;
+    h->cal_used = 0;
     return DSD_OK;
 }
 

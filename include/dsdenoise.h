@@ -175,12 +175,15 @@ typedef struct dsd_stats {
 int dsd_get_stats(const dsd_handle* h, dsd_stats* out);
 
 /*
- * Timing hook for bench.py: the dominant kernel (WaveNet: dilated-conv+gate GEMM; LYNXNet: the
- * C->4C SwiGLU GEMM) is bracketed by hipEvents on its own stream when enabled; returns the mean
- * duration in milliseconds over the launches recorded since the last reset and their count.
+ * Timing hook for bench.py: while enabled, every launch of the dominant kernel (WaveNet: dilated-conv +
+ * FiLM + gate GEMM; LYNXNet: the LayerNorm -> C->4C -> SwiGLU GEMM) is bracketed by a hipEvent pair recorded
+ * on the stream the kernel is launched on (graph replay is bypassed while enabled).  dsd_kernel_timing_read
+ * returns the mean bracket time in milliseconds over the launches recorded since the last reset, their
+ * count, and the mean time of EMPTY brackets (two events recorded back to back, one per backbone
+ * evaluation): what a bracket costs by itself and must be subtracted to compare with a kernel trace.
  */
 int dsd_kernel_timing(dsd_handle* h, int32_t enable);
-int dsd_kernel_timing_read(dsd_handle* h, double* mean_ms, int64_t* launches);
+int dsd_kernel_timing_read(dsd_handle* h, double* mean_ms, double* empty_pair_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/, scratch) into the small committed summaries under
+profiles/.  Usage: python tools/summarize_profile.py <tag> <trace_dir> [<fetch_dir> <write_dir> [<mfma_dir>]]
+
+FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  On gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e.
+it reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section): the summary stores the
+raw value and the x2-corrected byte count.  Both counters sit on the fabric side of L2, so Infinity-Cache
+hits are included - they bound HBM traffic from above."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, trace = sys.argv[1], sys.argv[2]
+extra = sys.argv[3:]
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(pattern, "*", "*" + "") if os.path.isdir(pattern) else pattern)
+    return g
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "*", "*" + suffix))
+    assert hits, (d, suffix)
+    return hits[0]
+
+
+stats = find(trace, "kernel_stats.csv")
+shutil.copy(stats, os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+summary = {"tag": tag, "kernels": {}}
+for r in csv.DictReader(open(stats)):
+    if float(r["Percentage"]) < 0.05:
+        continue
+    summary["kernels"][r["Name"]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                     "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
+                                     "pct": float(r["Percentage"])}
+
+
+def counters(d):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+for d in extra:
+    for k, cs in counters(d).items():
+        if k not in summary["kernels"]:
+            continue
+        for c, v in cs.items():
+            summary["kernels"][k][c + "_mean"] = sum(v) / len(v)
+for k, e in summary["kernels"].items():
+    if "FETCH_SIZE_mean" in e and "WRITE_SIZE_mean" in e:
+        e["fabric_bytes_per_launch_corrected"] = (2 * e["FETCH_SIZE_mean"] + e["WRITE_SIZE_mean"]) * 1024
+    if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in e and "GRBM_GUI_ACTIVE_mean" in e:
+        # MFMA busy cycles are summed over 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (profiled pass)
+        e["mfma_busy_frac_profiled"] = e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (1024 * e["GRBM_GUI_ACTIVE_mean"] / 8)
+out = os.path.join(ROOT, "profiles", f"{tag}_summary.json")
+json.dump(summary, open(out, "w"), indent=1)
+print(out)
