@@ -98,11 +98,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (SGPR)
     const int wm = wave >> 1, wn = wave & 1;
-    // 1-D grid, row tile fastest: with the dispatcher dealing workgroups round-robin over the 8 XCDs, the
-    // workgroups that stream the SAME weight rows (same mtile) land on the same XCD when mtiles % 8 == 0
-    // (8 tiles for C = 256), so each XCD's L2 serves 1/8 of the layer's weights (speed only).
-    const int mtile = blockIdx.x % p.mtiles;
-    const int rest = blockIdx.x / p.mtiles;
+    // 1-D grid with an XCD-aware remap (speed only, bijective for any grid size): the dispatcher deals
+    // workgroups round-robin over the 8 XCDs, so blocks b and b+8 share an L2.  Work items are numbered with the
+    // row tile fastest, and XCD k takes a CONTIGUOUS range of them: the workgroups that stage the SAME activation
+    // tile (same frames, all row tiles) share an XCD, so each L2 pulls 1/8 of the activations through the fabric
+    // instead of all of them (measured: the staging phase was bound by 8 XCDs each re-reading the whole x).
+    // Weights are then read by every XCD, but they stream during the K loop, off the latency-critical path.
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int mtile = work % p.mtiles;
+    const int rest = work / p.mtiles;
     const int b = rest / p.tiles_per_b;
     const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int K16 = p.K >> 4;
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         // 2^lpr_shift lanes walk one row (16-B loads along time), SU row-loads are issued back to back
         // before the first one is consumed, so the L2/MALL latency is paid once per batch, not per row.
         {
-            constexpr int SU = 8;
+            constexpr int SU = 8;       // row-loads in flight per lane and batch (16 would need ~280 VGPRs)
             const int rows_per_it = 256 >> p.lpr_shift;
             const int c4 = tid & ((1 << p.lpr_shift) - 1);
             const int r_in = tid >> p.lpr_shift;
@@ -279,21 +286,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                     if (col_ok && r < kcn) *reinterpret_cast<f32x4*>(&lds[r * S + c4 * 4]) = o;
                 }
             };
-            // first batch of activation loads, THEN the weight ring + epilogue prefetch (all in flight together),
-            // then the LDS writes; hipcc's header wait of the remaining-batches loop no longer precedes any issue
+            // 1. every activation load of the (first) batch is issued back to back and RETIRED with a
+            //    compiler-visible vmcnt(0): hipcc's own counted waits would otherwise also wait for the younger
+            //    asm loads issued next (it cannot see them), i.e. for the whole 64 KB weight ring;
+            // 2. the weight ring and the epilogue operands go out;  3. transform + LDS writes run under their flight.
             const int batch = rows_per_it * SU;
             issue(0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             ring_prologue();
             if (kc == 0) epi_prefetch();
             finish(0);
             for (int r0 = batch; r0 < kcn; r0 += batch) {
                 issue(r0);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
                 finish(r0);
             }
         }
-        // Everything hipcc counts (staging loads, the EP_GATE prefetch) and the ring prologue is retired here,
-        // visibly to the compiler (builtin, vmcnt(0) only), so that it parks no vmcnt wait of its own on the
-        // K-loop header; the ring prologue has had the whole staging phase to land.
+        // The asm loads (weight ring prologue, epilogue operands) are retired here as well.  They must be:
+        // hipcc does not know their destinations are still in flight and is free to MOVE those registers
+        // (observed: wrong cond-proj / residual values, then a fault) - form (ii) of cdna_hip_programming.md
+        // 5.7 pins order, not register allocation.  The wait is cheap: the loads had the whole transform +
+        // LDS-write phase to land.
         DSD_STAMP(2);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         DSD_STAMP(3);
