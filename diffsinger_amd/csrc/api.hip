@@ -4,7 +4,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
+#include <algorithm>
 #include <functional>
 #include <map>
 #include <string>
@@ -195,9 +197,14 @@ PackedGemm pack_gemm(dsd_handle* h, int M, int Kreal, int taps, int pairC, const
     const int mblks = ntile * 4;
     g.a_off = blob_reserve(h, (size_t)mblks * taps * K16 * 256);
     float* dst = h->blob_host.data() + g.a_off;
+    // block order = the order the K walk consumes them: [64-channel chunk][tap][k16 within the chunk]
+    std::vector<std::pair<int, int>> order;      // (tap, k16)
+    for (int c0 = 0; c0 < K16; c0 += 4)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int k = c0; k < std::min(c0 + 4, K16); ++k) order.emplace_back(tap, k);
     for (int mblk = 0; mblk < mblks; ++mblk)
         for (int kk = 0; kk < taps * K16; ++kk) {
-            const int tap = kk / K16, k16 = kk % K16;
+            const int tap = order[kk].first, k16 = order[kk].second;
             float* blk = dst + ((size_t)mblk * taps * K16 + kk) * 256;
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 4; ++j) {
@@ -501,17 +508,20 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     while (S % 32 != 16) S += 4;
     p.S = S;
     p.mtiles = mtiles;
-    p.rot_den = p.tiles_per_b > 0 ? p.tiles_per_b : 1;
     const int w4 = (BN + 2 * p.HL) / 4;
     p.lpr_shift = 3;
     while ((1 << p.lpr_shift) < w4) ++p.lpr_shift;
-    // a k=3 conv keeps all its input channels resident when they fit (the fast K walk does not mix taps and chunks)
-    if (g.taps == 3 && (long)g.K * S * 4 <= 144 * 1024) p.KC = g.K;
-    c.fast = (p.KC % 128 == 0) && (g.taps == 1 || p.KC == g.K) && gemm_has_fast(g.taps, c.nb, S);
+    // a k=3 conv keeps all its input channels resident on the generic path (its walk does not mix taps and chunks)
+    if (g.taps == 3) p.KC = g.K;
+    c.fast = (g.K % gemm_fast_chunk_rows(g.taps, c.nb) == 0) && (g.Kreal == g.K) && gemm_has_fast(g.taps, c.nb, S);
+    p.lds_bytes = c.fast ? gemm_lds_bytes_fast(S, stage, g.taps, g.K, c.nb) : gemm_lds_bytes(p.KC, S);
     return c;
 }
 
 int run_gemm(dsd_handle* h, const GemmCall& c, hipStream_t st) {
+    if (c.p.lds_bytes > 160 * 1024)
+        return fail(h, DSD_EINVAL, "GEMM tile needs %d bytes of LDS (> 160 KiB): %d input channels x k=%d at dilation %d "
+                    "is outside the supported shapes", c.p.lds_bytes, c.p.K, c.taps, c.p.dil);
     hipError_t e = launch_gemm(c.p, c.stage, c.taps, c.epi, c.nb, c.fast, c.batch, st);
     if (e != hipSuccess) return fail(h, DSD_EHIP, "GEMM launch failed: %s", hipGetErrorString(e));
     return DSD_OK;

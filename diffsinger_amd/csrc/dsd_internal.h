@@ -40,7 +40,7 @@ struct LinOut {
 
 // One GEMM-shaped launch:  out[m, t] = epilogue( sum_{tap, c} A[m, tap, c] * stage(B)[c, t + (tap-1)*dil] )
 struct GemmP {
-    // A: weights pre-packed in MFMA 16x16x4 fragment order, [mblk][tap*K16 + k16][lane][4]
+    // A: weights pre-packed in MFMA 16x16x4 fragment order, [mblk][64-ch chunk][tap][k16 in chunk][lane][4]
     const float* A;
     const float* bias;      // original row indexing, may be nullptr
     int M;                  // real output rows (original indexing)
@@ -55,7 +55,7 @@ struct GemmP {
     int T;                  // valid frames
     int tiles_per_b;
     int mtiles;             // 64-row tiles (EP_GATE / EP_SWIGLU: 32 pairs each)
-    int rot_den;            // K-walk rotation: start step = (tile index * nit / rot_den) % nit
+    int lds_bytes;          // dynamic LDS of this launch
     int lpr_shift;          // staging: 2^lpr_shift lanes per staged row (>= float4 per row)
     int dil;                // dilation (TAPS == 3)
     int HL;                 // halo columns staged on each side (multiple of 4, >= dil)
@@ -86,6 +86,8 @@ struct GemmP {
 hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int fast, int batch, hipStream_t st);
 bool gemm_has_fast(int taps, int nb, int S);
 int gemm_lds_bytes(int KC, int S);
+int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb);
+int gemm_fast_chunk_rows(int taps, int nb);
 hipError_t gemm_init_all();
 
 // aux_kernels.hip

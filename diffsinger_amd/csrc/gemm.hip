@@ -125,8 +125,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 
     // packed A: [mblk][TAPS*K16][64 lanes][4]; this wave owns packed m-blocks 4*mtile + 2*wm + {0,1}
     const long a_blk = (long)(TAPS * K16) * 256;
-    const float* a0p = p.A + (long)(mtile * 4 + wm * 2) * a_blk + lane * 4;
-    const float* a1p = a0p + a_blk;
 
     const float* bsrc = p.B + (long)b * p.b_bstride;
     const int W4 = (BN + 2 * HL) >> 2;      // float4 per staged row
@@ -173,228 +171,345 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         }
     };
 
-    for (int kc = 0; kc < p.K; kc += p.KC) {
-        const int kcn = min(p.KC, p.K - kc);
-        const int n16 = kcn >> 4;
-        const int nit = TAPS * n16;
-        // A-fragment ring: PF iterations (one k16 step of both row blocks each) are kept in flight.  The loop
-        // body is branch-free (conditional refills make hipcc serialise every load behind an s_waitcnt vmcnt(0)):
-        // the (k16, tap) position simply wraps around, so refills past the end re-read valid, unused blocks.
-        // The walk over the nit = TAPS * n16 steps starts at a per-workgroup ROTATION: the workgroups that
-        // stream the same weight rows run in lockstep, and without it they all hit the same L2 channel with the
-        // same 1 KiB block at the same moment.  Summation order therefore depends on the tile index only
-        // (deterministic; fp32 rounding differs between tiles by the usual reassociation error).
-        const int kc16 = kc >> 4;
-        const int rot = SW > 0 ? 0 : (int)(((long)rest * nit) / p.rot_den) % nit;
-        int pf_tap = rot / n16;
-        int pf_c = rot - pf_tap * n16;
-        f32x4 ra0[PF], ra1[PF];
-        // fast path: byte address of this wave's block (tap 0, k16 = kc16) as a scalar; blocks follow linearly
-        const unsigned long long a0s =
-            (unsigned long long)(p.A + ((long)(mtile * 4 + wm * 2) * (TAPS * K16) + kc16) * 256);
-        const unsigned long long a1s = a0s + (unsigned long long)a_blk * 4;
-        unsigned long long an0 = a0s, an1 = a1s;            // base of the group the next refills belong to
-        const unsigned voff0 = lane * 16, voff1 = lane * 16 + 4096;
-        auto ring_issue = [&](f32x4& d0, f32x4& d1) {        // generic path
-#ifdef DSD_EXP_NOSTREAM
-            const long off = 0;      // diagnostic: every fragment load hits the same (L1-resident) block
-#else
-            const long off = (long)(pf_tap * K16 + kc16 + pf_c) * 256;
-#endif
-            ring_load(d0, a0p + off);
-            ring_load(d1, a1p + off);
-            const bool w = (++pf_c == n16);
-            pf_c = w ? 0 : pf_c;
-            pf_tap += w ? 1 : 0;
-            pf_tap = (pf_tap == TAPS) ? 0 : pf_tap;
-        };
-        auto ring_group_fast = [&](auto uc) {                // fast path: slot u of the group at an0/an1
-            constexpr int u = decltype(uc)::value;
-            ring_load_s<(u & 3) * 1024>(ra0[u], u < 4 ? voff0 : voff1, an0);
-            ring_load_s<(u & 3) * 1024>(ra1[u], u < 4 ? voff0 : voff1, an1);
-        };
-        auto ring_prologue = [&]() {
-            if constexpr (SW > 0) {
-                ring_group_fast(std::integral_constant<int, 0>{});
-                ring_group_fast(std::integral_constant<int, 1>{});
-                ring_group_fast(std::integral_constant<int, 2>{});
-                ring_group_fast(std::integral_constant<int, 3>{});
-                ring_group_fast(std::integral_constant<int, 4>{});
-                ring_group_fast(std::integral_constant<int, 5>{});
-                ring_group_fast(std::integral_constant<int, 6>{});
-                ring_group_fast(std::integral_constant<int, 7>{});
-                an0 += 8192;
-                an1 += 8192;
-            } else {
+    f32x4 ra0[PF], ra1[PF];
+    float bq[2][4][NB];
+    auto mfma_step = [&](const f32x4& A0, const f32x4& A1, const float (&bv)[4][NB]) {
 #pragma unroll
-                for (int u = 0; u < PF; ++u) ring_issue(ra0[u], ra1[u]);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], bv[j][n], acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], bv[j][n], acc[1][n], 0, 0, 0);
+            }
+    };
+    // Weights of this wave: two 16-row blocks, each a LINEAR stream of 1 KiB fragment blocks in exactly the
+    // order the K walk consumes them ([64-channel chunk][tap][k16 in chunk], dsd_finalize_weights packs it so).
+    const unsigned long long a0s = (unsigned long long)(p.A + (long)(mtile * 4 + wm * 2) * a_blk);
+    const unsigned long long a1s = a0s + (unsigned long long)a_blk * 4;
+
+    if constexpr (SW > 0) {
+        // =====================================================================================
+        // FAST PATH: software-pipelined over 64-channel chunks.
+        //   LDS: two chunk buffers [64][SW] (+ the FiLM vector / LayerNorm statistics of the tile).
+        //   chunk c+1 is fetched global -> VGPR (asm loads, hand-counted) while the MFMAs of chunk c run from
+        //   LDS, then transformed and written to the other buffer; ONE barrier per chunk.  The weight ring keeps
+        //   streaming linearly across chunk boundaries.  Chunks are walked in pairs so that every ring slot
+        //   index and every LDS offset is a compile-time constant (K a multiple of the chunk size).
+        // =====================================================================================
+        static_assert(PF == 8, "ring slots are addressed statically modulo 8");
+        // chunk = 64 channels (128-channel chunks for the 1x1 GEMMs were measured: the shorter K loop does not
+        // pay for the longer chunk-0 fill at B = 1)
+        constexpr int CR = 64;
+        constexpr int ITERS = TAPS * (CR / 16);         // k16 steps per chunk: 12, 8 or 4
+        constexpr int NU = CR * SW / 1024;              // float4 staged per lane and chunk (upper bound)
+        constexpr int BUF = CR * SW;                    // floats per chunk buffer
+        float* lds_film = lds + 2 * BUF;                // ST_FILM: [K]
+        float* lds_stat = lds + 2 * BUF;                // ST_LN: [2][BN] (mean | rstd), HL == 0
+        const int NC = p.K / CR;
+
+        // ---- per-lane staging geometry: lane's u-th float4 of a [64 x W4] chunk tile ----
+        unsigned s_voff[NU];                            // byte offset from the chunk's (row 0, frame t0-HL)
+        int s_loff[NU];                                 // float offset in a chunk buffer
+        int s_row[NU];
+        unsigned s_mask[NU];                            // bit e: frame of element e is inside [0, T)
+        bool s_valid[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = tid + 256 * u;
+            const bool valid = idx < CR * W4;
+            const int row = valid ? idx / W4 : CR - 1;
+            const int c4 = valid ? idx - row * W4 : 0;
+            s_valid[u] = valid;
+            s_row[u] = row;
+            s_voff[u] = (unsigned)((row * p.b_rstride + c4 * 4) * 4);
+            s_loff[u] = row * SW + c4 * 4;
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = t0 - HL + c4 * 4 + e;
+                m |= (t >= 0 && t < p.T) ? (1u << e) : 0u;
+            }
+            s_mask[u] = m;
+        }
+        unsigned long long sbase = (unsigned long long)(bsrc + (t0 - HL));      // chunk 0, row 0
+        const unsigned long long sstep = (unsigned long long)p.b_rstride * CR * 4;
+        f32x4 sv[NU];
+        auto stage_issue = [&]() {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) ring_load_s<0>(sv[u], s_voff[u], sbase);
+            sbase += sstep;
+        };
+        auto stage_write = [&](int chunk, float* buf) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                float add = 0.f;
+                if (STAGE == ST_FILM) add = lds_film[chunk * CR + s_row[u]];
+                f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, rstd = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (STAGE == ST_LN) {
+                    const int col = (s_loff[u] - s_row[u] * SW);
+                    mean = *reinterpret_cast<const f32x4*>(&lds_stat[col]);
+                    rstd = *reinterpret_cast<const f32x4*>(&lds_stat[BN + col]);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y = sv[u][e];
+                    if (STAGE == ST_FILM) y = y + add;
+                    else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
+                    else if (p.in_scale != 1.f) y = y / p.in_scale;       // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
+                    o[e] = ((s_mask[u] >> e) & 1u) ? y : 0.f;              // zero padding AFTER the FiLM add (wavenet.py:36-38)
+                }
+                if (s_valid[u]) *reinterpret_cast<f32x4*>(&buf[s_loff[u]]) = o;
             }
         };
-        if (kc > 0) __syncthreads();
-        DSD_STAMP(1);
-        // ---------------- stage B chunk: rows [kc, kc+kcn), frames [t0-HL, t0+BN+HL) ----------------
-        // 2^lpr_shift lanes walk one row (16-B loads along time), SU row-loads are issued back to back
-        // before the first one is consumed, so the L2/MALL latency is paid once per batch, not per row.
-        {
-            constexpr int SU = 8;       // row-loads in flight per lane and batch (16 would need ~280 VGPRs)
-            const int rows_per_it = 256 >> p.lpr_shift;
-            const int c4 = tid & ((1 << p.lpr_shift) - 1);
-            const int r_in = tid >> p.lpr_shift;
-            const bool col_ok = c4 < W4;
-            const int tcol = t0 - HL + c4 * 4;
-            f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, rstd = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (STAGE == ST_LN) {
-                const float* st = p.ln_stats + (long)b * 2 * p.ln_ts;
-                if (col_ok && tcol >= 0 && tcol + 3 < p.ln_ts) {
-                    mean = *reinterpret_cast<const f32x4*>(st + tcol);
-                    rstd = *reinterpret_cast<const f32x4*>(st + p.ln_ts + tcol);
-                }
-            }
-            // Branch-free on purpose: every lane always loads from a clamped (in-bounds) address and the mask is
-            // applied by select afterwards.  Predicated loads become exec-masked branches, and hipcc then parks an
-            // s_waitcnt vmcnt(0) between consecutive loads - the whole batch serialises on memory latency.
-            const int c4c = col_ok ? c4 : W4 - 1;
-            const int tcolc = t0 - HL + c4c * 4;
-            const int ch_last = p.Kreal - 1;
-            f32x4 v[SU];
-            float add[SU];
-            auto issue = [&](int r0) {
+
+        // ---- prologue: tile constants, epilogue operands and chunk 0, all in flight together ----
+        float cst[4];                                   // FiLM vector / LN statistics of this tile (compiler loads)
+        if (STAGE == ST_FILM) {
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int ch = min(kc + r0 + u * rows_per_it + r_in, ch_last);
-                    v[u] = *reinterpret_cast<const f32x4*>(bsrc + (long)ch * p.b_rstride + tcolc);
-                    add[u] = 0.f;
-                    if (STAGE == ST_FILM) add[u] = p.film[(long)ch * p.film_cstride + p.film_col0 + b * p.film_colb];
-                }
-            };
-            auto finish = [&](int r0) {
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int r = r0 + u * rows_per_it + r_in;
-                    const bool row_ok = (kc + r) < p.Kreal;
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int t = tcol + e;
-                        float y = v[u][e];
-                        if (STAGE == ST_FILM) y = y + add[u];
-                        else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
-                        else if (p.in_scale != 1.f) y = y / p.in_scale;   // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
-                        const bool ok = (t >= 0) && (t < p.T) && row_ok;
-                        o[e] = ok ? y : 0.f;       // zero padding applies AFTER the FiLM add (wavenet.py:36-38)
-                    }
-                    if (col_ok && r < kcn) *reinterpret_cast<f32x4*>(&lds[r * S + c4 * 4]) = o;
-                }
-            };
-            // 1. every activation load of the (first) batch is issued back to back and RETIRED with a
-            //    compiler-visible vmcnt(0): hipcc's own counted waits would otherwise also wait for the younger
-            //    asm loads issued next (it cannot see them), i.e. for the whole 64 KB weight ring;
-            // 2. the weight ring and the epilogue operands go out;  3. transform + LDS writes run under their flight.
-            const int batch = rows_per_it * SU;
-            issue(0);
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            ring_prologue();
-            if (kc == 0) epi_prefetch();
-            finish(0);
-            for (int r0 = batch; r0 < kcn; r0 += batch) {
-                issue(r0);
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                finish(r0);
+            for (int i = 0; i < 4; ++i) {
+                const int ch = min(tid + 256 * i, p.K - 1);
+                cst[i] = p.film[(long)ch * p.film_cstride + p.film_col0 + b * p.film_colb];
             }
         }
-        // The asm loads (weight ring prologue, epilogue operands) are retired here as well.  They must be:
-        // hipcc does not know their destinations are still in flight and is free to MOVE those registers
-        // (observed: wrong cond-proj / residual values, then a fault) - form (ii) of cdna_hip_programming.md
-        // 5.7 pins order, not register allocation.  The wait is cheap: the loads had the whole transform +
-        // LDS-write phase to land.
+        if (STAGE == ST_LN) {
+            const int col = min(t0 + (tid & (BN - 1)), p.ln_ts - 1);
+            cst[0] = p.ln_stats[(long)b * 2 * p.ln_ts + ((tid >> (NB == 1 ? 5 : 6)) & 1) * p.ln_ts + col];
+        }
+        epi_prefetch();
+        stage_issue();
+        DSD_STAMP(1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // retires everything issued so far (asm loads too)
+        // weight ring prologue: blocks 0..7 of both row blocks; in flight during the chunk-0 transform
+        unsigned long long an0 = a0s, an1 = a1s;        // base of the block the next refill of "step 0" loads
+        const unsigned voffA = lane * 16, voffB = lane * 16 + 4096, voffC = lane * 16 + 8192;
+#define DSD_RING_PRO(U)                                                              \
+    ring_load_s<((U) & 3) * 1024>(ra0[U], (U) < 4 ? voffA : voffB, an0);             \
+    ring_load_s<((U) & 3) * 1024>(ra1[U], (U) < 4 ? voffA : voffB, an1);
+        DSD_RING_PRO(0) DSD_RING_PRO(1) DSD_RING_PRO(2) DSD_RING_PRO(3)
+        DSD_RING_PRO(4) DSD_RING_PRO(5) DSD_RING_PRO(6) DSD_RING_PRO(7)
+#undef DSD_RING_PRO
+        an0 += 8192;
+        an1 += 8192;
+        if (STAGE == ST_FILM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tid + 256 * i < p.K) lds_film[tid + 256 * i] = cst[i];
+        }
+        if (STAGE == ST_LN) {
+            if (tid < 2 * BN) lds_stat[tid] = cst[0];
+        }
+        if (STAGE != ST_PLAIN) __syncthreads();         // the transform below reads the tile constants
+        stage_write(0, lds);
+        // the ring prologue is retired before the barrier: hipcc does not know those registers are in flight
+        // and may move them (5.7: form (ii) pins order, not allocation); it had the transform phase to land
         DSD_STAMP(2);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         DSD_STAMP(3);
         __syncthreads();
         DSD_STAMP(4);
 
-        // ---------------- MFMA over (tap, k16) ----------------
-        // B fragments are read one iteration ahead (two register sets), so the ds_read latency of step i+1
-        // hides under the 8*NB MFMAs of step i instead of draining the matrix pipe at every step.
-        int rtap = rot / n16;
-        int rc16 = rot - rtap * n16;
-        const float* bl0 = &lds[lrow * S + wn * (16 * NB) + lcol] + (HL - (TAPS == 3 ? p.dil : 0));
-        float bq[2][4][NB];
-        auto read_b = [&](float (&bv)[4][NB]) {
-            const float* blp = bl0 + rc16 * (16 * S) + (TAPS == 3 ? rtap * p.dil : 0);
+        // ---- B fragment addressing: one VGPR base per tap, everything else is an immediate ----
+        const float* bt0 = lds + lrow * SW + wn * (16 * NB) + lcol + HL - (TAPS == 3 ? p.dil : 0);
+        const float* bt1 = bt0 + p.dil;
+        const float* bt2 = bt1 + p.dil;
+        auto read_b = [&](float (&bv)[4][NB], auto ic, auto bufc) {
+            constexpr int i = decltype(ic)::value;       // step within the chunk: tap = i / KPC, k16 = i % KPC
+            constexpr int KPC = CR / 16;
+            constexpr int boff = decltype(bufc)::value * BUF;
+            const float* base = (TAPS == 1 || i / KPC == 0) ? bt0 : (i / KPC == 1 ? bt1 : bt2);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int n = 0; n < NB; ++n) bv[j][n] = blp[j * 4 * S + n * 16];
-            const bool w = (++rc16 == n16);
-            rc16 = w ? 0 : rc16;
-            rtap += w ? 1 : 0;
-            rtap = (rtap == TAPS) ? 0 : rtap;
+                for (int n = 0; n < NB; ++n) bv[j][n] = base[boff + ((i % KPC) * 16 + j * 4) * SW + n * 16];
         };
-        auto mfma_step = [&](const f32x4& A0, const f32x4& A1, const float (&bv)[4][NB]) {
+        // one k16 step: wait for ring slot, read the next step's B, MFMAs, refill the slot with the block 8 steps on
+#define DSD_STEP(I, SLOT, BUFI)                                                                        \
+    ring_wait<2 * (PF - 1)>(ra0[SLOT], ra1[SLOT]);                                                      \
+    if constexpr ((I) + 1 < ITERS)                                                                      \
+        read_b(bq[((I) + 1) & 1], std::integral_constant<int, ((I) + 1) % ITERS>{},                     \
+               std::integral_constant<int, BUFI>{});                                                    \
+    mfma_step(ra0[SLOT], ra1[SLOT], bq[(I) & 1]);                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    ring_load_s<((I) & 3) * 1024>(ra0[SLOT], (I) < 4 ? voffA : ((I) < 8 ? voffB : voffC), an0);         \
+    ring_load_s<((I) & 3) * 1024>(ra1[SLOT], (I) < 4 ? voffA : ((I) < 8 ? voffB : voffC), an1);
+#define DSD_CHUNK(S0, BUFI)                                                                            \
+    read_b(bq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, BUFI>{});               \
+    DSD_STEP(0, ((S0) + 0) & 7, BUFI) DSD_STEP(1, ((S0) + 1) & 7, BUFI)                                 \
+    DSD_STEP(2, ((S0) + 2) & 7, BUFI) DSD_STEP(3, ((S0) + 3) & 7, BUFI)                                 \
+    if constexpr (ITERS >= 8) {                                                                         \
+        DSD_STEP(4, ((S0) + 4) & 7, BUFI) DSD_STEP(5, ((S0) + 5) & 7, BUFI)                             \
+        DSD_STEP(6, ((S0) + 6) & 7, BUFI) DSD_STEP(7, ((S0) + 7) & 7, BUFI)                             \
+    }                                                                                                   \
+    if constexpr (ITERS >= 12) {                                                                        \
+        DSD_STEP(8, ((S0) + 8) & 7, BUFI) DSD_STEP(9, ((S0) + 9) & 7, BUFI)                             \
+        DSD_STEP(10, ((S0) + 10) & 7, BUFI) DSD_STEP(11, ((S0) + 11) & 7, BUFI)                         \
+    }                                                                                                   \
+    an0 += ITERS * 1024;                                                                                \
+    an1 += ITERS * 1024;
+        // after a chunk's ITERS steps exactly 2*ITERS refills are younger than the staged chunk's loads
+        auto stage_wait = [&]() {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ITERS) : "memory");
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], bv[j][n], acc[0][n], 0, 0, 0);
-                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], bv[j][n], acc[1][n], 0, 0, 0);
+            for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(sv[u])::"memory");   // consumers stay below the wait
+        };
+        for (int c = 0; c < NC; c += 2) {
+            // even chunk from buffer 0; chunk c+1 (if any) lands in buffer 1 meanwhile
+            const bool has1 = c + 1 < NC;
+            if (has1) stage_issue();
+            DSD_CHUNK(0, 0)
+            if (has1) {
+                stage_wait();
+                stage_write(c + 1, lds + BUF);
+            }
+            __syncthreads();
+            if (has1) {
+                // odd chunk from buffer 1; chunk c+2 (if any) lands in buffer 0
+                const bool has2 = c + 2 < NC;
+                if (has2) stage_issue();
+                DSD_CHUNK(ITERS & 7, 1)
+                if (has2) {
+                    stage_wait();
+                    stage_write(c + 2, lds);
                 }
-        };
-        if constexpr (SW > 0) {
-            static_assert(PF == 8, "fast path walks groups of 8 k16 steps");
-            const int groups = nit >> 3;
-            const int gpt = n16 >> 3;                         // groups per tap
-            int gt = 0;
-            auto read_bf = [&](float (&bv)[4][NB], const float* base, auto uc) {
-                constexpr int u = decltype(uc)::value;
+                __syncthreads();
+            }
+        }
+#undef DSD_CHUNK
+#undef DSD_STEP
+#pragma unroll
+        for (int u = 0; u < PF; ++u) ring_wait<0>(ra0[u], ra1[u]);     // drain the over-read refills
+    } else {
+        // =====================================================================================
+        // GENERIC PATH (any K multiple of 16, any dilation): runtime LDS stride, whole chunk staged then walked.
+        // A k=3 conv needs all its input channels resident (KC == K, checked on the host).
+        // =====================================================================================
+        const float* a0p = (const float*)a0s + lane * 4;
+        const float* a1p = (const float*)a1s + lane * 4;
+        long a_it = 0;                                          // linear block index of the next ring refill
+        for (int kc = 0; kc < p.K; kc += p.KC) {
+            const int kcn = min(p.KC, p.K - kc);
+            const int n16 = kcn >> 4;
+            const int nit = TAPS * n16;
+            auto ring_issue = [&](f32x4& d0, f32x4& d1) {
+                ring_load(d0, a0p + a_it * 256);
+                ring_load(d1, a1p + a_it * 256);
+                ++a_it;
+            };
+            if (kc > 0) __syncthreads();
+            DSD_STAMP(1);
+            // ---- stage rows [kc, kc+kcn), frames [t0-HL, t0+BN+HL): 2^lpr_shift lanes per row, SU rows in flight ----
+            {
+                constexpr int SU = 8;
+                const int rows_per_it = 256 >> p.lpr_shift;
+                const int c4 = tid & ((1 << p.lpr_shift) - 1);
+                const int r_in = tid >> p.lpr_shift;
+                const bool col_ok = c4 < W4;
+                const int tcol = t0 - HL + c4 * 4;
+                f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, rstd = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (STAGE == ST_LN) {
+                    const float* st = p.ln_stats + (long)b * 2 * p.ln_ts;
+                    if (col_ok && tcol >= 0 && tcol + 3 < p.ln_ts) {
+                        mean = *reinterpret_cast<const f32x4*>(st + tcol);
+                        rstd = *reinterpret_cast<const f32x4*>(st + p.ln_ts + tcol);
+                    }
+                }
+                // Branch-free on purpose: every lane always loads from a clamped (in-bounds) address and the mask
+                // is applied by select afterwards.  Predicated loads become exec-masked branches, and hipcc then
+                // parks an s_waitcnt vmcnt(0) between consecutive loads - the batch serialises on memory latency.
+                const int c4c = col_ok ? c4 : W4 - 1;
+                const int tcolc = t0 - HL + c4c * 4;
+                const int ch_last = p.Kreal - 1;
+                f32x4 v[SU];
+                float add[SU];
+                auto issue = [&](int r0) {
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int ch = min(kc + r0 + u * rows_per_it + r_in, ch_last);
+                        v[u] = *reinterpret_cast<const f32x4*>(bsrc + (long)ch * p.b_rstride + tcolc);
+                        add[u] = 0.f;
+                        if (STAGE == ST_FILM) add[u] = p.film[(long)ch * p.film_cstride + p.film_col0 + b * p.film_colb];
+                    }
+                };
+                auto finish = [&](int r0) {
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int r = r0 + u * rows_per_it + r_in;
+                        const bool row_ok = (kc + r) < p.Kreal;
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int t = tcol + e;
+                            float y = v[u][e];
+                            if (STAGE == ST_FILM) y = y + add[u];
+                            else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
+                            else if (p.in_scale != 1.f) y = y / p.in_scale;   // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
+                            const bool ok = (t >= 0) && (t < p.T) && row_ok;
+                            o[e] = ok ? y : 0.f;       // zero padding applies AFTER the FiLM add (wavenet.py:36-38)
+                        }
+                        if (col_ok && r < kcn) *reinterpret_cast<f32x4*>(&lds[r * S + c4 * 4]) = o;
+                    }
+                };
+                const int batch = rows_per_it * SU;
+                issue(0);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ring_issue(ra0[u], ra1[u]);
+                if (kc == 0) epi_prefetch();
+                finish(0);
+                for (int r0 = batch; r0 < kcn; r0 += batch) {
+                    issue(r0);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    finish(r0);
+                }
+            }
+            // asm loads (ring prologue, epilogue operands) are retired before the barrier: hipcc does not know
+            // their destinations are in flight and may move those registers (5.7: form (ii) pins order only)
+            DSD_STAMP(2);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            DSD_STAMP(3);
+            __syncthreads();
+            DSD_STAMP(4);
+            // ---- walk: [64-channel chunk][tap][k16 in chunk]; with TAPS == 1 that is plain k16 order ----
+            int k4 = 0, tap = 0, c64 = 0;
+            int nk = min(4, n16);
+            const float* bl0 = &lds[lrow * S + wn * (16 * NB) + lcol] + (HL - (TAPS == 3 ? p.dil : 0));
+            auto read_b = [&](float (&bv)[4][NB]) {
+                const float* blp = bl0 + (c64 * 4 + k4) * (16 * S) + (TAPS == 3 ? tap * p.dil : 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int n = 0; n < NB; ++n) bv[j][n] = base[(u * 16 + j * 4) * SW + n * 16];
+                    for (int n = 0; n < NB; ++n) bv[j][n] = blp[j * 4 * S + n * 16];
+                const bool wk = (++k4 == nk);
+                k4 = wk ? 0 : k4;
+                tap += wk ? 1 : 0;
+                const bool wt = (tap == TAPS);
+                tap = wt ? 0 : tap;
+                c64 += wt ? 1 : 0;
+                c64 = (c64 * 4 >= n16) ? 0 : c64;        // past the end: wrap to a valid, unused position
+                nk = min(4, n16 - c64 * 4);
             };
-            const float* bt = bl0;
-            read_bf(bq[0], bt, std::integral_constant<int, 0>{});
+            read_b(bq[0]);
+            const int groups = nit / PF, rem = nit - groups * PF;
             for (int g = 0; g < groups; ++g) {
-                const bool wrap = (++gt == gpt);
-                gt = wrap ? 0 : gt;
-                const float* btn = bt + (wrap ? (TAPS == 3 ? p.dil : 0) - (n16 - 8) * 16 * SW : 8 * 16 * SW);
-#define DSD_FAST_STEP(U)                                                                           \
-    ring_wait<2 * (PF - 1)>(ra0[U], ra1[U]);                                                        \
-    if constexpr (U < 7) read_bf(bq[(U + 1) & 1], bt, std::integral_constant<int, (U + 1) & 7>{}); \
-    else read_bf(bq[0], btn, std::integral_constant<int, 0>{});                                    \
-    mfma_step(ra0[U], ra1[U], bq[U & 1]);                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                              \
-    ring_group_fast(std::integral_constant<int, U>{});
-                DSD_FAST_STEP(0) DSD_FAST_STEP(1) DSD_FAST_STEP(2) DSD_FAST_STEP(3)
-                DSD_FAST_STEP(4) DSD_FAST_STEP(5) DSD_FAST_STEP(6) DSD_FAST_STEP(7)
-#undef DSD_FAST_STEP
-                bt = btn;
-                an0 += 8192;
-                an1 += 8192;
-            }
 #pragma unroll
-            for (int u = 0; u < PF; ++u) ring_wait<0>(ra0[u], ra1[u]);     // drain
-        } else {
-        read_b(bq[0]);
-        const int groups = nit / PF, rem = nit - groups * PF;
-        for (int g = 0; g < groups; ++g) {
+                for (int u = 0; u < PF; ++u) {
+                    ring_wait<2 * (PF - 1)>(ra0[u], ra1[u]);
+                    read_b(bq[(u + 1) & 1]);
+                    mfma_step(ra0[u], ra1[u], bq[u & 1]);
+                    __builtin_amdgcn_sched_barrier(0);      // refill only after the slot's last use has issued
+                    ring_issue(ra0[u], ra1[u]);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                ring_wait<2 * (PF - 1)>(ra0[u], ra1[u]);
-                read_b(bq[(u + 1) & 1]);                 // past the last step this wraps to a valid, unused block
-                mfma_step(ra0[u], ra1[u], bq[u & 1]);
-                __builtin_amdgcn_sched_barrier(0);      // refill only after the slot's last use has issued
-                ring_issue(ra0[u], ra1[u]);
+                ring_wait<0>(ra0[u], ra1[u]);       // drain: also keeps the compiler's own counting exact below
+                if (u < rem) {
+                    read_b(bq[(u + 1) & 1]);
+                    mfma_step(ra0[u], ra1[u], bq[u & 1]);
+                }
             }
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            ring_wait<0>(ra0[u], ra1[u]);       // drain: also keeps the compiler's own counting exact below
-            if (u < rem) {
-                read_b(bq[(u + 1) & 1]);
-                mfma_step(ra0[u], ra1[u], bq[u & 1]);
-            }
-        }
+            a_it -= PF - rem;    // the ring ran ahead of the blocks this chunk consumed
         }
     }
 
@@ -482,7 +597,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     DSD_STAMP(6);
 }
 
+// generic path: one resident chunk [KC][S]; fast path: two 64-row chunk buffers + the tile's FiLM vector / LN stats
 int gemm_lds_bytes(int KC, int S) { return KC * S * 4; }
+int gemm_fast_chunk_rows(int taps, int nb) { (void)taps; (void)nb; return 64; }
+int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb) {
+    return (2 * gemm_fast_chunk_rows(taps, nb) * S + (stage == ST_FILM ? K : 0) + (stage == ST_LN ? 2 * 32 * nb : 0)) * 4;
+}
 
 template <int STAGE, int TAPS, int EPI, int NB, int SW>
 static hipError_t set_attr() {
@@ -492,7 +612,7 @@ static hipError_t set_attr() {
 
 template <int STAGE, int TAPS, int EPI, int NB, int SW>
 static hipError_t launch_one(const GemmP& p, int batch, hipStream_t st) {
-    const int lds = gemm_lds_bytes(p.KC, p.S);
+    const int lds = p.lds_bytes;
     dim3 grid(batch * p.tiles_per_b * p.mtiles, 1, 1);
     hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW>), grid, dim3(256), lds, st, p);
     return hipGetLastError();

@@ -47,7 +47,7 @@ buf = np.zeros((8, 4096, 8), dtype=np.uint64)
 rc = _lib.lib().dsd_dbg_read_stamps(buf.ctypes.data_as(C.c_void_p))
 assert rc == 0
 names = {0: "BIAS_ACT", 1: "GATE (conv)", 2: "RESSKIP (outproj)", 3: "LINCOMB (tail2)"}
-labels = ["start->prologue issued", "staging issue+LDS write", "vmcnt(0)", "barrier", "K loop", "epilogue"]
+labels = ["start->first loads issued", "chunk-0 land + LDS write", "ring prologue drain", "barrier", "K loop (all chunks)", "epilogue"]
 for v, nm in names.items():
     st = buf[v].astype(np.int64)
     live = st[:, 0] > 0
