@@ -560,11 +560,11 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             (void)hipEventCreate(&b);
             h->ev_pool.emplace_back(a, b);
         }
-        (void)hipEventRecord(h->ev_pool[h->ev_used].first, st);
+        gemm_set_timing_events(h->ev_pool[h->ev_used].first, h->ev_pool[h->ev_used].second);
     };
     auto timed_end = [&]() {
         if (!h->timing) return;
-        (void)hipEventRecord(h->ev_pool[h->ev_used].second, st);
+        gemm_set_timing_events(nullptr, nullptr);
         ++h->ev_used;
     };
     if (h->timing) {      // one empty bracket per evaluation calibrates what a hipEvent pair itself costs

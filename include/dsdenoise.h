@@ -176,11 +176,11 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out);
 
 /*
  * Timing hook for bench.py: while enabled, every launch of the dominant kernel (WaveNet: dilated-conv +
- * FiLM + gate GEMM; LYNXNet: the LayerNorm -> C->4C -> SwiGLU GEMM) is bracketed by a hipEvent pair recorded
- * on the stream the kernel is launched on (graph replay is bypassed while enabled).  dsd_kernel_timing_read
- * returns the mean bracket time in milliseconds over the launches recorded since the last reset, their
- * count, and the mean time of EMPTY brackets (two events recorded back to back, one per backbone
- * evaluation): what a bracket costs by itself and must be subtracted to compare with a kernel trace.
+ * FiLM + gate GEMM; LYNXNet: the LayerNorm -> C->4C -> SwiGLU GEMM) carries a hipEvent start/stop pair
+ * attached to the dispatch itself (hipExtLaunchKernelGGL) on the stream the kernel is launched on; graph
+ * replay is bypassed while enabled.  dsd_kernel_timing_read returns the mean kernel duration in milliseconds
+ * over the launches recorded since the last reset and their count, plus - for reference - the mean time of
+ * an EMPTY hipEventRecord pair on that stream (what a plain event bracket would have added).
  */
 int dsd_kernel_timing(dsd_handle* h, int32_t enable);
 int dsd_kernel_timing_read(dsd_handle* h, double* mean_ms, double* empty_pair_ms, int64_t* launches);
