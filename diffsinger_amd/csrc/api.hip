@@ -509,6 +509,9 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     p.S = S;
     p.mtiles = mtiles;
     const int w4 = (BN + 2 * p.HL) / 4;
+    p.inv_mtiles = 1.0f / (float)mtiles;
+    p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
+    p.inv_w4 = 1.0f / (float)w4;
     p.lpr_shift = 3;
     while ((1 << p.lpr_shift) < w4) ++p.lpr_shift;
     // a k=3 conv keeps all its input channels resident on the generic path (its walk does not mix taps and chunks)

@@ -56,6 +56,7 @@ struct GemmP {
     int tiles_per_b;
     int mtiles;             // 64-row tiles (EP_GATE / EP_SWIGLU: 32 pairs each)
     int lds_bytes;          // dynamic LDS of this launch
+    float inv_mtiles, inv_tiles_per_b, inv_w4;   // reciprocals for the prologue's index arithmetic
     int lpr_shift;          // staging: 2^lpr_shift lanes per staged row (>= float4 per row)
     int dil;                // dilation (TAPS == 3)
     int HL;                 // halo columns staged on each side (multiple of 4, >= dil)

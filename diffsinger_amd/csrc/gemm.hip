@@ -59,6 +59,10 @@ extern "C" int dsd_dbg_read_stamps(unsigned long long* host_out) {
 #define DSD_STAMP(i)
 #endif
 
+// floor(x / d) for 0 <= x < 2^22 with inv = 1.0f / d: one cvt + mul + cvt instead of the ~40-instruction
+// integer-division expansion (the kernel prologue is on the latency-critical path at B = 1)
+__device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
 constexpr int PF = 8;   // A-fragment prefetch distance in k16 iterations (2 x 1 KiB loads each)
 
 // The weight-fragment ring is loaded with inline asm and waited for with hand-counted s_waitcnt vmcnt(N):
@@ -110,9 +114,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int mtile = work % p.mtiles;
-    const int rest = work / p.mtiles;
-    const int b = rest / p.tiles_per_b;
+    const int rest = fdiv_floor(work, p.inv_mtiles);
+    const int mtile = work - rest * p.mtiles;
+    const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int K16 = p.K >> 4;
     const int S = SW > 0 ? SW : p.S;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         for (int u = 0; u < NU; ++u) {
             const int idx = tid + 256 * u;
             const bool valid = idx < CR * W4;
-            const int row = valid ? idx / W4 : CR - 1;
+            const int row = valid ? fdiv_floor(idx, p.inv_w4) : CR - 1;
             const int c4 = valid ? idx - row * W4 : 0;
             s_valid[u] = valid;
             s_row[u] = row;
@@ -571,28 +575,63 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                             float* sp = p.skip + (long)b * p.o_bstride + (long)(row - p.C) * p.o_rstride + t;
                             *sp = p.first_layer ? v : (cpv[mb][n][r] + v);
                         }
-                    } else if (EPI == EP_LINCOMB) {
-                        float outv[kMaxOut];
-#pragma unroll
-                        for (int o = 0; o < kMaxOut; ++o) {
-                            outv[o] = 0.f;
-                            if (o < p.nout) {
-                                const LinOut& lo = p.lo[o];
-                                for (int k = 0; k < lo.nterms; ++k) {
-                                    const LinTerm& tm = lo.t[k];
-                                    float s;
-                                    if (tm.ptr == nullptr) s = v;
-                                    else if (tm.ext && t >= p.T) s = 0.f;
-                                    else s = tm.ptr[(long)b * tm.bstride + (long)row * tm.rstride + t];
-                                    outv[o] += tm.coef * s;
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int o = 0; o < kMaxOut; ++o)
-                            if (o < p.nout) p.lo[o].dst[(long)b * p.o_bstride + (long)row * p.o_rstride + t] = outv[o];
                     }
                 }
+            }
+        }
+    }
+    if (EPI == EP_LINCOMB) {
+        // Solver update fused into the last GEMM: dst_o = sum_k coef_k * src_k.  Terms are the OUTER loop and the
+        // wave's 8*NB output elements the inner, unrolled one: the loads of one term are issued back to back
+        // (branch-free: clamped frame index + select), so a term costs one memory latency, not one per element.
+        constexpr int E = 2 * NB * 4;
+        float ev[E];
+        int erow[E], et[E];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = (mb * NB + n) * 4 + r;
+                    const int row = mtile * 64 + (wm * 2 + mb) * 16 + rq + r;
+                    erow[e] = row;
+                    et[e] = t0 + wn * (16 * NB) + n * 16 + lcol;
+                    ev[e] = acc[mb][n][r] + ((p.bias && row < p.M) ? p.bias[min(row, p.M - 1)] : 0.f);
+                }
+        // every combination reads the PRE-evaluation buffers: all outputs are formed before any is stored
+        // (a destination may also be a source of another output, e.g. UniPC's model-value slots)
+        float outv[kMaxOut][E];
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) outv[o][e] = 0.f;
+            if (o < p.nout) {
+                const LinOut& lo = p.lo[o];
+                for (int k = 0; k < lo.nterms; ++k) {
+                    const LinTerm tm = lo.t[k];
+                    if (tm.ptr == nullptr) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) outv[o][e] += tm.coef * ev[e];
+                    } else {
+                        float sv[E];
+                        const int tlim = tm.ext ? p.T - 1 : 0x7fffffff;
+#pragma unroll
+                        for (int e = 0; e < E; ++e)
+                            sv[e] = tm.ptr[(long)b * tm.bstride + (long)min(erow[e], p.M - 1) * tm.rstride + min(et[e], tlim)];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) outv[o][e] += tm.coef * ((et[e] <= tlim) ? sv[e] : 0.f);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+            if (o < p.nout) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (erow[e] < p.M)
+                        p.lo[o].dst[(long)b * p.o_bstride + (long)erow[e] * p.o_rstride + et[e]] = outv[o][e];
             }
         }
     }
