@@ -130,55 +130,98 @@ hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const flo
 //   strong_cond:   x <- x + cp ;  xin = x + d          (residual taken AFTER the conditioner add)
 //   otherwise:     xin = x + cp + d                    (residual = untouched x)
 //   stats[b][0][t] = mean_c xin,  stats[b][1][t] = 1/sqrt(var_c xin + 1e-5)   (biased variance)
-// One workgroup owns 64 frames x all channels; lanes run along time (256-B row segments), the
-// channel reduction is a register loop per wave followed by a 4-wave LDS combine.  Two passes
-// (mean, then centred second moment) like torch's LayerNorm; the second pass re-reads the tile
-// this workgroup just wrote (L2-resident).
+// One workgroup = 16 waves owns 64 frames x all channels; lanes run along time (256-B row segments), wave w
+// takes channels w, w+16, ...  Up to 64 channels per wave stay in registers, so x / cp are read ONCE and the
+// centred second moment (two-pass, like torch's LayerNorm) needs no second trip to memory; loads are issued
+// 8 deep.  The per-(b,t) reduction over channels is a register loop + a 16-wave LDS combine.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lynx_pre_kernel(float* __restrict__ x, float* __restrict__ xin,
-                                                       const float* __restrict__ cp, long cp_bstride,
-                                                       const float* __restrict__ film, int film_cstride,
-                                                       int film_col0, int film_colb, long bstride, int rstride, int C,
-                                                       int T, int strong, float* __restrict__ stats, int ts) {
-    __shared__ float red[4][64];
+constexpr int LP_WAVES = 16;
+constexpr int LP_REG = 64;      // channels per wave kept in registers (C <= 1024); the rest is re-read
+__global__ __launch_bounds__(1024) void lynx_pre_kernel(float* __restrict__ x, float* __restrict__ xin,
+                                                        const float* __restrict__ cp, long cp_bstride,
+                                                        const float* __restrict__ film, int film_cstride,
+                                                        int film_col0, int film_colb, long bstride, int rstride, int C,
+                                                        int T, int strong, float* __restrict__ stats, int ts) {
+    __shared__ float red[LP_WAVES][64];
     __shared__ float mean_s[64];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + lane;
-    float* xb = x + (long)b * bstride;
-    float* xi = xin ? xin + (long)b * bstride : nullptr;
-    const float* cpb = cp ? cp + (long)b * cp_bstride : nullptr;
+    float* xb = x + (long)b * bstride + t;
+    float* xi = xin ? xin + (long)b * bstride + t : nullptr;
+    const float* cpb = cp ? cp + (long)b * cp_bstride + t : nullptr;
+    const int nper = (C + LP_WAVES - 1) / LP_WAVES;         // channels per wave
+    float keep[LP_REG];
     float sum = 0.f;
-    for (int c = wave; c < C; c += 4) {
-        float v = xb[(long)c * rstride + t];
-        if (cpb) {
-            const float w = v + cpb[(long)c * rstride + t];
-            if (strong) xb[(long)c * rstride + t] = w;
-            v = w;
+#pragma unroll
+    for (int i0 = 0; i0 < LP_REG; i0 += 8) {
+        float a[8], c8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = min(wave + (i0 + j) * LP_WAVES, C - 1);        // clamped: branch-free loads
+            a[j] = xb[(long)c * rstride];
+            c8[j] = cpb ? cpb[(long)c * rstride] : 0.f;
         }
-        if (film) v = v + film[(long)c * film_cstride + film_col0 + b * film_colb];
-        if (xi) xi[(long)c * rstride + t] = v;
-        sum += v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = wave + (i0 + j) * LP_WAVES;
+            const bool ok = (i0 + j) < nper && c < C;
+            float v = a[j] + c8[j];
+            if (ok && cpb && strong) xb[(long)c * rstride] = v;
+            if (film && ok) v = v + film[(long)c * film_cstride + film_col0 + b * film_colb];
+            if (ok && xi) xi[(long)c * rstride] = v;
+            keep[i0 + j] = ok ? v : 0.f;
+            sum += ok ? v : 0.f;
+        }
+    }
+    for (int i = LP_REG; i < nper; ++i) {                    // C > 1024: beyond the register window
+        const int c = wave + i * LP_WAVES;
+        if (c < C) {
+            float v = xb[(long)c * rstride];
+            if (cpb) {
+                v += cpb[(long)c * rstride];
+                if (strong) xb[(long)c * rstride] = v;
+            }
+            if (film) v = v + film[(long)c * film_cstride + film_col0 + b * film_colb];
+            if (xi) xi[(long)c * rstride] = v;
+            sum += v;
+        }
     }
     red[wave][lane] = sum;
     __syncthreads();
-    if (wave == 0) mean_s[lane] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    if (wave == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < LP_WAVES; ++w) s += red[w][lane];
+        mean_s[lane] = s / (float)C;
+    }
     __syncthreads();
     const float mean = mean_s[lane];
-    const float* rd = xi ? xi : xb;
     float sq = 0.f;
-    for (int c = wave; c < C; c += 4) {
-        const float dlt = rd[(long)c * rstride + t] - mean;
-        sq += dlt * dlt;
+#pragma unroll
+    for (int i = 0; i < LP_REG; ++i) {
+        const bool ok = i < nper && (wave + i * LP_WAVES) < C;
+        const float dlt = keep[i] - mean;
+        sq += ok ? dlt * dlt : 0.f;
+    }
+    const float* rd = xi ? xi : xb;
+    for (int i = LP_REG; i < nper; ++i) {
+        const int c = wave + i * LP_WAVES;
+        if (c < C) {
+            const float dlt = rd[(long)c * rstride] - mean;
+            sq += dlt * dlt;
+        }
     }
     __syncthreads();
     red[wave][lane] = sq;
     __syncthreads();
     if (wave == 0 && t < ts) {
-        const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < LP_WAVES; ++w) s += red[w][lane];
         float* st = stats + (long)b * 2 * ts;
         st[t] = mean;
-        st[ts + t] = 1.f / sqrtf(var + 1e-5f);
+        st[ts + t] = 1.f / sqrtf(s / (float)C + 1e-5f);
     }
 }
 
@@ -186,8 +229,8 @@ hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstrid
                            int film_cstride, int film_col0, int film_colb, long bstride, int rstride, int C, int B,
                            int T, int strong, float* stats, int ts, hipStream_t stream) {
     dim3 grid(round_up(T, 64) / 64, B);
-    hipLaunchKernelGGL(lynx_pre_kernel, grid, dim3(256), 0, stream, x, xin, cp, cp_bstride, film, film_cstride,
-                       film_col0, film_colb, bstride, rstride, C, T, strong, stats, ts);
+    hipLaunchKernelGGL(lynx_pre_kernel, grid, dim3(64 * LP_WAVES), 0, stream, x, xin, cp, cp_bstride, film,
+                       film_cstride, film_col0, film_colb, bstride, rstride, C, T, strong, stats, ts);
     return hipGetLastError();
 }
 
