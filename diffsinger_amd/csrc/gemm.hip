@@ -97,7 +97,7 @@ __device__ __forceinline__ void ring_load_s(f32x4& dst, unsigned voff, unsigned 
 // k16 step is 8*NB MFMAs + 4*NB ds_read + 2 loads + 1 counted wait and nothing else.  SW == 0: generic
 // instantiation (runtime S, any K multiple of 16, rotation-free wraparound walk) for every other shape.
 template <int STAGE, int TAPS, int EPI, int NB, int SW>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BN = 32 * NB;
     const int tid = threadIdx.x;
