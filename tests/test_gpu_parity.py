@@ -278,6 +278,42 @@ def test_headline_config_properties_full_size():
     net.release_native()
 
 
+def test_headline_config_full_size_vs_oracle():
+    """BASELINE config 2 exactly (20x256 WaveNet, DPM-Solver++ 1000->50, B=1, T=1000) against the numpy oracle
+    run on the host cores (~50 backbone evaluations); tolerance: 5e-4 of the output range after 50 solver steps."""
+    set_hp(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    d = _gd(1000, in_dims=128, args=args, wseed=42)
+    t_len = 1000
+    cond = synth.synth_normal((1, t_len, 256), 0)
+    noise = synth.synth_normal((1, 1, 128, t_len), 1)
+    out = d(dev(cond), infer=True, noise=dev(noise))
+    params = synth_params("wavenet", 128, 1, args, 42)
+    fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=4)
+    o = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
+    want = o.forward(cond, noise, diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
+    err = rel_err(out, want)
+    assert err < TOL_SAMPLER, err
+    d.denoise_fn.release_native()
+
+
+def test_long_utterance_single_nfe_vs_oracle():
+    """T = 4128 (the longest .ds segment in the reference's samples), B = 2: many tiles per
+    utterance, 64-frame-tile kernels."""
+    set_hp()
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    net, params = make_backbone("wavenet", 128, 1, args, 42)
+    bsz, t_len = 2, 4128
+    x = synth.synth_normal((bsz, 1, 128, t_len), 31)
+    cond = synth.synth_normal((bsz, 256, t_len), 32)
+    t = np.array([17.0, 940.5], np.float32)
+    want = ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=4)
+    with torch.no_grad():
+        out = net(dev(x), dev(t), dev(cond))
+    assert rel_err(out, want) < TOL_NFE
+    net.release_native()
+
+
 def test_reference_error_behaviour():
     from diffsinger_amd.diffusion import RectifiedFlow
     set_hp(diff_accelerator="nope", diff_speedup=10, K_step_infer=1000)
