@@ -518,6 +518,8 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     if (g.taps == 3) p.KC = g.K;
     c.fast = (g.K % gemm_fast_chunk_rows(g.taps, c.nb) == 0) && (g.Kreal == g.K) && gemm_has_fast(g.taps, c.nb, S);
     p.lds_bytes = c.fast ? gemm_lds_bytes_fast(S, stage, g.taps, g.K, c.nb) : gemm_lds_bytes(p.KC, S);
+    if (epi == EP_GATE || epi == EP_RESSKIP)        // the LDS-staged epilogue tile [64][BN + 4]
+        p.lds_bytes = std::max(p.lds_bytes, 64 * (BN + 4) * 4);
     return c;
 }
 

@@ -138,41 +138,36 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
 
     // EP_GATE: the hoisted conditioner projection of this wave's outputs is fetched now and consumed in the
     // epilogue, so its latency hides under the whole K loop.
-    float cpv[2][NB][4];
+    // Epilogue operands (EP_GATE: hoisted conditioner projection; EP_RESSKIP: residual stream / running skip sum)
+    // are fetched at kernel start and consumed after the K loop, so their latency hides under it.  They are
+    // fetched in the ROW-MAJOR thread mapping of the LDS-staged epilogue below: lane -> 4 consecutive frames,
+    // i.e. full 256-B (BN = 64) / 128-B row segments per 16 / 8 lanes instead of 64-B fragment-shaped pieces.
+    constexpr int EQ = BN / 4;                      // float4 per output row
+    constexpr int EROWS = 256 / EQ;                 // rows covered per pass of the 256 threads
+    const int e_c4 = tid % EQ, e_r0 = tid / EQ;
+    constexpr int NPRE = (EPI == EP_GATE) ? 2 * (32 / EROWS) : (EPI == EP_RESSKIP ? 64 / EROWS : 1);
+    f32x4 pre[NPRE];
     auto epi_prefetch = [&]() {
+        const long colo = (long)b * (EPI == EP_GATE ? p.aux_bstride : p.o_bstride) + t0 + e_c4 * 4;
         if (EPI == EP_RESSKIP) {
-            // residual stream / running skip sum of this wave's outputs, fetched before the K loop.
-            // A 16-row block lies entirely in the residual half or in the skip half (C % 16 == 0): the base
-            // pointer is chosen with integer arithmetic on values already in SGPRs (a select between the two
-            // struct FIELDS makes hipcc load the pointer itself through a dependent vector load).
+            // rows of this workgroup: [mtile*64, +64) of the 2C outputs; residual half -> x, skip half -> skip sum
+            // (pointer chosen with integer arithmetic: a select between the struct FIELDS makes hipcc load the
+            // pointer itself through a dependent vector load)
             const unsigned long long xa = (unsigned long long)p.x, sa = (unsigned long long)p.skip;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const int row0 = mtile * 64 + (wm * 2 + mb) * 16;
-                const bool is_res = row0 < p.C;
-                const unsigned long long ba = is_res ? xa : sa;
-                const int rowb = (is_res ? row0 : row0 - p.C) + (lane >> 4) * 4;
-                const float* base = (const float*)ba;
-#pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    const long col = (long)b * p.o_bstride + t0 + wn * (16 * NB) + n * 16 + lcol;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        pre_load(cpv[mb][n][r], base + col + (long)(rowb + r) * p.o_rstride);
-                }
+            for (int k = 0; k < 64 / EROWS; ++k) {
+                const int row = min(mtile * 64 + e_r0 + k * EROWS, p.M - 1);
+                const bool is_res = row < p.C;
+                const float* base = (const float*)(is_res ? xa : sa);
+                ring_load(pre[k], base + colo + (long)(is_res ? row : row - p.C) * p.o_rstride);
             }
         }
         if (EPI == EP_GATE) {
-            const int chb = (mtile * 2 + wm) * 16 + (lane >> 4) * 4;
-    #pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const float* cp = p.aux + (long)b * p.aux_bstride + t0 + wn * (16 * NB) + n * 16 + lcol;
-    #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ch = min(chb + r, p.C - 1);
-                    pre_load(cpv[0][n][r], cp + (long)ch * p.aux_rstride);
-                    pre_load(cpv[1][n][r], cp + (long)(ch + p.C) * p.aux_rstride);
-                }
+#pragma unroll
+            for (int k = 0; k < 32 / EROWS; ++k) {
+                const int ch = min(mtile * 32 + e_r0 + k * EROWS, p.C - 1);
+                ring_load(pre[2 * k], p.aux + colo + (long)ch * p.aux_rstride);
+                ring_load(pre[2 * k + 1], p.aux + colo + (long)(ch + p.C) * p.aux_rstride);
             }
         }
     };
@@ -519,38 +514,81 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         }
     }
 
-    if (EPI == EP_GATE || EPI == EP_RESSKIP) {      // prefetched operands: retired by the ring drain (vmcnt(0)) above
+    if (EPI == EP_GATE || EPI == EP_RESSKIP) {      // prefetched operands: retired by a vmcnt(0) drain above
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int n = 0; n < NB; ++n) pre_wait4(cpv[i][n]);
+        for (int k = 0; k < NPRE; ++k) asm volatile("" : "+v"(pre[k])::"memory");
     }
     DSD_STAMP(5);
     // ---------------------------------------- epilogue ----------------------------------------
     // C/D layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + reg.
     const int rq = (lane >> 4) * 4;
+    if constexpr (EPI == EP_GATE || EPI == EP_RESSKIP) {
+        // LDS-staged: accumulators go to a [64 rows][BN + 4] tile (the chunk buffers are dead by now), then every
+        // thread handles whole float4s of a row: the gate / residual arithmetic runs on row-major data and the
+        // global stores are 16 B per lane, full lines per row - 4x fewer store instructions than the
+        // fragment-shaped (4 rows x 64 B) stores of the accumulator layout.
+        constexpr int ES = BN + 4;
+        __syncthreads();                               // all waves are done reading the staged activations
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // EP_GATE: rows [0,32) = gate, [32,64) = filter of channel wm*16 + rq + r;  else packed row
+                    const int trow = (EPI == EP_GATE) ? mb * 32 + wm * 16 + rq + r : (wm * 2 + mb) * 16 + rq + r;
+                    lds[trow * ES + wn * (16 * NB) + n * 16 + lcol] = acc[mb][n][r];
+                }
+        __syncthreads();
+        const long colo = (long)b * p.o_bstride + t0 + e_c4 * 4;
+        if constexpr (EPI == EP_GATE) {
+#pragma unroll
+            for (int k = 0; k < 32 / EROWS; ++k) {
+                const int cw = e_r0 + k * EROWS;           // channel within the workgroup's 32
+                const int ch = mtile * 32 + cw;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(&lds[cw * ES + e_c4 * 4]);
+                const f32x4 f = *reinterpret_cast<const f32x4*>(&lds[(32 + cw) * ES + e_c4 * 4]);
+                f32x4 z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    z[e] = sigmoid_f(g[e] + pre[2 * k][e]) * tanhf(f[e] + pre[2 * k + 1][e]);     // wavenet.py:41-42
+                if (ch < p.C) *reinterpret_cast<f32x4*>(p.out + colo + (long)ch * p.o_rstride) = z;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 64 / EROWS; ++k) {
+                const int pr = e_r0 + k * EROWS;
+                const int row = mtile * 64 + pr;
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&lds[pr * ES + e_c4 * 4]);
+                if (row < p.M) {
+                    const float bv = p.bias ? p.bias[row] : 0.f;
+                    f32x4 o;
+                    if (row < p.C) {                                   // residual half (wavenet.py:47-48)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (pre[k][e] + (a4[e] + bv)) / 1.41421356237309504880f;
+                        *reinterpret_cast<f32x4*>(p.x + colo + (long)row * p.o_rstride) = o;
+                    } else {                                           // skip half: running sum replaces stack+sum (wavenet.py:96)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = p.first_layer ? (a4[e] + bv) : (pre[k][e] + (a4[e] + bv));
+                        *reinterpret_cast<f32x4*>(p.skip + colo + (long)(row - p.C) * p.o_rstride) = o;
+                    }
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         const int t = t0 + wn * (16 * NB) + n * 16 + lcol;
-        if (EPI == EP_GATE || EPI == EP_SWIGLU) {
-            // packed pair block: acc[0] = first-half rows (gate / out), acc[1] = second-half rows (filter / gate)
+        if (EPI == EP_SWIGLU) {
+            // packed pair block: acc[0] = first-half rows (out), acc[1] = second-half rows (gate)
             const int chb = (mtile * 2 + wm) * 16 + rq;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ch = chb + r;
                 if (ch < p.C) {
-                    float u0 = acc[0][n][r], u1 = acc[1][n][r];
-                    float y;
-                    if (EPI == EP_GATE) {
-                        u0 += cpv[0][n][r];
-                        u1 += cpv[1][n][r];
-                        y = sigmoid_f(u0) * tanhf(u1);                 // wavenet.py:41-42
-                    } else {
-                        u0 += p.bias[ch];
-                        u1 += p.bias[ch + p.C];
-                        y = u0 * (u1 * sigmoid_f(u1));                 // out * silu(gate), common_layers.py:116-117
-                    }
-                    p.out[(long)b * p.o_bstride + (long)ch * p.o_rstride + t] = y;
+                    const float u0 = acc[0][n][r] + p.bias[ch];
+                    const float u1 = acc[1][n][r] + p.bias[ch + p.C];
+                    p.out[(long)b * p.o_bstride + (long)ch * p.o_rstride + t] = u0 * (u1 * sigmoid_f(u1));   // out * silu(gate)
                 }
             }
         } else {
@@ -561,24 +599,17 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
                 for (int r = 0; r < 4; ++r) {
                     const int row = rowb + r;
                     if (row >= p.M) continue;
-                    float v = acc[mb][n][r] + (p.bias ? p.bias[row] : 0.f);
+                    const float v = acc[mb][n][r] + (p.bias ? p.bias[row] : 0.f);
                     if (EPI == EP_BIAS_ACT) {
                         p.out[(long)b * p.o_bstride + (long)row * p.o_rstride + t] = act_apply(v, p.act);
                     } else if (EPI == EP_BIAS_RES) {
                         const float res = p.aux[(long)b * p.aux_bstride + (long)row * p.aux_rstride + t];
                         p.out[(long)b * p.o_bstride + (long)row * p.o_rstride + t] = v + res;
-                    } else if (EPI == EP_RESSKIP) {
-                        if (row < p.C) {                               // residual half (wavenet.py:47-48)
-                            float* xp = p.x + (long)b * p.o_bstride + (long)row * p.o_rstride + t;
-                            *xp = (cpv[mb][n][r] + v) / 1.41421356237309504880f;
-                        } else {                                       // skip half: running sum replaces stack+sum (wavenet.py:96)
-                            float* sp = p.skip + (long)b * p.o_bstride + (long)(row - p.C) * p.o_rstride + t;
-                            *sp = p.first_layer ? v : (cpv[mb][n][r] + v);
-                        }
                     }
                 }
             }
         }
+    }
     }
     if (EPI == EP_LINCOMB) {
         // Solver update fused into the last GEMM: dst_o = sum_k coef_k * src_k.  Terms are the OUTER loop and the
