@@ -11,15 +11,20 @@
 //
 // Mapping to CDNA4:
 //   * v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD).  A = weights, B = activations.
-//   * A is pre-packed on the host in fragment order, so a wave fetches the fragments of 4 k-steps
-//     of one 16-row block with ONE coalesced 1 KiB global_load_dwordx4 straight into VGPRs
-//     (weights are L2/MALL resident; no LDS round trip), software-pipelined PF iterations ahead.
-//   * B: a [KC channels x (BN + 2*halo) frames] tile is staged in LDS once per K-chunk with 16-B
-//     loads along the time axis; fragments are read with ds_read_b32 (row stride S = 16 mod 32
-//     floats -> the 4 k-rows x 16 columns of a fragment hit 64 distinct banks).
+//   * A is pre-packed on the host in fragment order AND in the order the K walk consumes it
+//     ([64-channel chunk][tap][k16]), so a wave streams ONE linear sequence of coalesced 1 KiB
+//     global_load_dwordx4 blocks straight into VGPRs (weights are L2/MALL resident; no LDS round trip)
+//     through an 8-deep register ring: inline-asm loads (SGPR base + lane offset + immediate) waited
+//     for with hand-counted s_waitcnt vmcnt(N).
+//   * B (fast path): 64-channel chunks [64][BN + 2*halo] double-buffered in LDS; chunk c+1 travels
+//     global -> VGPR (asm loads) under the MFMAs of chunk c, gets the FiLM / LayerNorm / [0,T) mask
+//     transform and is written to the other buffer; one barrier per chunk.  Row stride S = 16 (mod 32)
+//     floats: the 4 k-rows x 16 columns of a fragment read hit 64 distinct banks; S is a template
+//     constant, so every fragment read is "base VGPR + immediate".
 //   * workgroup = 4 waves (one per SIMD) as 2 (rows) x 2 (frames); tile = 64 rows x 32*NB frames.
-//     Gate/SwiGLU pairs (row r and row r + C) are packed into the same wave so the nonlinearity
-//     is a pure register epilogue.
+//     Gate / SwiGLU pairs (row r and row r + C) are packed into the same wave.
+//   * epilogues: accumulators -> LDS tile -> row-major float4 arithmetic and 16-B coalesced stores
+//     (gate, residual/skip), or straight from registers (bias+activation, SwiGLU, solver update).
 #include <hip/hip_ext.h>
 
 #include <type_traits>
@@ -78,12 +83,6 @@ constexpr int PF = 8;   // A-fragment prefetch distance in k16 iterations (2 x 1
 __device__ __forceinline__ void ring_load(f32x4& dst, const float* ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
 }
-__device__ __forceinline__ void pre_load(float& dst, const float* ptr) {
-    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
-}
-__device__ __forceinline__ void pre_wait4(float (&a)[4]) {      // after a vmcnt(0) drain: orders the consumers
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) :: "memory");
-}
 template <int N>
 __device__ __forceinline__ void ring_wait(f32x4& a, f32x4& b) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
@@ -100,7 +99,7 @@ __device__ __forceinline__ void ring_load_s(f32x4& dst, unsigned voff, unsigned 
 // SW > 0: "fast" instantiation - LDS row stride S == SW is a compile-time constant (every B-fragment read is
 // base + immediate), the K walk is linear in groups of 8 steps (K % 128 == 0 and no tap/chunk mixing), so a
 // k16 step is 8*NB MFMAs + 4*NB ds_read + 2 loads + 1 counted wait and nothing else.  SW == 0: generic
-// instantiation (runtime S, any K multiple of 16, rotation-free wraparound walk) for every other shape.
+// instantiation (runtime S, any K multiple of 16, whole chunk staged then walked) for every other shape.
 template <int STAGE, int TAPS, int EPI, int NB, int SW>
 __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
