@@ -79,6 +79,29 @@ def lynxnet_param_shapes(in_dims, n_feats, num_layers=6, num_channels=512, expan
     return shapes
 
 
+def convnext_param_shapes(in_dims, out_dims, num_channels=512, num_layers=6, kernel_size=7, prefix=""):
+    """state_dict of modules/aux_decoder/convnext.py:58-76 (ConvNeXtDecoder); `prefix="decoder."` gives the
+    AuxDecoderAdaptor layout (aux_decoder/__init__.py:33-37)."""
+    c = num_channels
+    shapes = OrderedDict()
+    shapes[prefix + "inconv.weight"] = (c, in_dims, kernel_size)
+    shapes[prefix + "inconv.bias"] = (c,)
+    for l in range(num_layers):
+        p = f"{prefix}conv.{l}."
+        shapes[p + "gamma"] = (c,)
+        shapes[p + "dwconv.weight"] = (c, 1, 7)
+        shapes[p + "dwconv.bias"] = (c,)
+        shapes[p + "norm.weight"] = (c,)
+        shapes[p + "norm.bias"] = (c,)
+        shapes[p + "pwconv1.weight"] = (4 * c, c)
+        shapes[p + "pwconv1.bias"] = (4 * c,)
+        shapes[p + "pwconv2.weight"] = (c, 4 * c)
+        shapes[p + "pwconv2.bias"] = (c,)
+    shapes[prefix + "outconv.weight"] = (out_dims, c, kernel_size)
+    shapes[prefix + "outconv.bias"] = (out_dims,)
+    return shapes
+
+
 def backbone_param_shapes(kind, in_dims, n_feats, hidden_size=256, **args):
     if kind == "wavenet":
         return wavenet_param_shapes(in_dims, n_feats, num_layers=args.get("num_layers", 20),
@@ -101,11 +124,13 @@ def synth_state_dict(shapes, seed=42):
     for name, shape in shapes.items():
         z = rng.standard_normal(shape, dtype=np.float32)
         leaf = name.rsplit(".", 1)[-1]
-        is_ln = name.startswith("norm.") or ".convmodule.net.0." in name
+        is_ln = name.startswith("norm.") or ".convmodule.net.0." in name or ".norm." in name
         if is_ln and leaf == "weight":
             w = 1.0 + 0.1 * z
         elif ".convmodule.net.5." in name:
             w = 0.25 + 0.05 * z
+        elif leaf == "gamma":                      # ConvNeXt layer scale (reference init 1e-6; O(1) here so it matters)
+            w = 0.5 + 0.1 * z
         elif leaf == "bias":
             w = 0.1 * z
         else:

@@ -403,8 +403,94 @@ def g6_wrappers():
     save("g6_wrappers", **out)
 
 
+# --------------------------------------------------------------------------- G7: aux decoder + acoustic glue
+AUX_CASES = {
+    # tag: (in_dims(hidden), out_dims, decoder args, B, T, weight seed)
+    "default": (256, 128, dict(num_channels=512, num_layers=6, kernel_size=7, dropout_rate=0.1), 2, 150, 70),
+    "small": (256, 32, dict(num_channels=64, num_layers=2, kernel_size=7, dropout_rate=0.1), 3, 37, 71),
+    "k5": (192, 80, dict(num_channels=128, num_layers=3, kernel_size=5, dropout_rate=0.0), 1, 64, 72),
+}
+
+
+def g7_aux_decoder():
+    from modules.aux_decoder import AuxDecoderAdaptor  # (reference)
+    out = {}
+    set_hp()
+    for tag, (hsz, m, args, bsz, t_len, wseed) in AUX_CASES.items():
+        rng = np.random.Generator(np.random.PCG64(wseed))
+        smin = (-12.0 + rng.random(m)).astype(np.float32)
+        smax = (0.0 + rng.random(m)).astype(np.float32)
+        a = AuxDecoderAdaptor(hsz, m, 1, smin.tolist(), smax.tolist(), "convnext", dict(args))
+        shapes = synth.convnext_param_shapes(hsz, m, num_channels=args["num_channels"], num_layers=args["num_layers"],
+                                             kernel_size=args["kernel_size"], prefix="decoder.")
+        sd = synth.synth_state_dict(shapes, seed=wseed)
+        a.load_state_dict({k: to_t(v) for k, v in sd.items()}, strict=True)
+        a.eval()
+        cond = synth.synth_normal((bsz, t_len, hsz), wseed + 100)
+        with torch.no_grad():
+            raw = a(to_t(cond), infer=False).numpy()
+            mel = a(to_t(cond), infer=True).numpy()
+        # keep the default case small: a strided subset of the raw output plus the full denormed one for small nets
+        out[f"{tag}_meta"] = np.array([hsz, m, args["num_channels"], args["num_layers"], args["kernel_size"],
+                                       bsz, t_len, wseed], dtype=np.int64)
+        out[f"{tag}_smin"], out[f"{tag}_smax"] = smin, smax
+        out[f"{tag}_raw"] = raw[:, ::3] if tag == "default" else raw
+        out[f"{tag}_mel"] = mel[:, ::3] if tag == "default" else mel
+        print(f"  aux {tag}: raw absmax={np.abs(raw).max():.3f} mel range=({mel.min():.2f},{mel.max():.2f})")
+
+    # the glue of DiffSingerAcoustic.forward(infer=True) after the encoder (toplevel.py:84-105), with the small nets
+    sn = SAMPLER_NET
+    hsz, m, args, _, _, wseed = AUX_CASES["small"]
+    bsz, t_len = 2, 50
+    rng = np.random.Generator(np.random.PCG64(99))
+    smin = (-12.0 + rng.random(m)).astype(np.float32)
+    smax = (0.0 + rng.random(m)).astype(np.float32)
+    mel2ph = np.ones((bsz, t_len), dtype=np.int64)
+    mel2ph[0, 41:] = 0
+    mel2ph[1, 48:] = 0
+    out["glue_smin"], out["glue_smax"], out["glue_mel2ph"] = smin, smax, mel2ph
+    out["glue_meta"] = np.array([bsz, t_len, 7000], dtype=np.int64)
+
+    def glue(tag, build_diff):
+        a = AuxDecoderAdaptor(hsz, m, 1, smin.tolist(), smax.tolist(), "convnext", dict(args))
+        shapes = synth.convnext_param_shapes(hsz, m, num_channels=args["num_channels"],
+                                             num_layers=args["num_layers"], kernel_size=args["kernel_size"],
+                                             prefix="decoder.")
+        a.load_state_dict({k: to_t(v) for k, v in synth.synth_state_dict(shapes, seed=wseed).items()}, strict=True)
+        a.eval()
+        d = build_diff()
+        cond = to_t(synth.synth_normal((bsz, t_len, hsz), 7500))
+        mask = (to_t(mel2ph) > 0).float()[:, :, None]
+        with InjectRandn(7000) as inj, torch.no_grad():
+            aux = a(cond, infer=True)
+            aux *= mask
+            mel = d(cond, src_spec=aux, infer=True)
+            mel *= mask
+        out[f"glue_{tag}_aux"], out[f"glue_{tag}_mel"] = aux.numpy(), mel.numpy()
+        out[f"glue_{tag}_nrandn"] = np.array(len(inj.seeds), dtype=np.int64)
+        print(f"  glue {tag}: randn calls={len(inj.seeds)} mel absmax={mel.abs().max():.3f}")
+
+    def build_gd():
+        set_hp(use_shallow_diffusion=True, diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=400)
+        d = ref_ddpm.GaussianDiffusion(m, 1, timesteps=1000, k_step=400, backbone_type="wavenet",
+                                       backbone_args=sn["args"], spec_min=smin.tolist(), spec_max=smax.tolist())
+        load_synth(d.denoise_fn, "wavenet", m, 1, sn["args"], sn["wseed"])
+        return d
+
+    def build_rf():
+        set_hp(use_shallow_diffusion=True, sampling_algorithm="euler", sampling_steps=20, T_start_infer=0.4)
+        r = ref_reflow.RectifiedFlow(m, 1, t_start=0.4, time_scale_factor=1000, backbone_type="wavenet",
+                                     backbone_args=sn["args"], spec_min=smin.tolist(), spec_max=smax.tolist())
+        load_synth(r.velocity_fn, "wavenet", m, 1, sn["args"], sn["wseed"])
+        return r
+
+    glue("ddpm_dpm", build_gd)
+    glue("reflow_euler", build_rf)
+    save("g7_aux_decoder", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -415,3 +501,5 @@ if __name__ == "__main__":
         g5_samplers()
     if "g6" in which:
         g6_wrappers()
+    if "g7" in which:
+        g7_aux_decoder()

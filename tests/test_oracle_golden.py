@@ -291,3 +291,54 @@ def test_g6_norm_denorm_wrappers():
                                rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(od.multivar_denorm(m1, g["mv1_x"], [(-96.0, 0.0)])[0], g["mv1_denorm0"],
                                rtol=1e-5, atol=1e-4)
+
+
+# --------------------------------------------------------------------------- G7 (section 8(f) rank 1)
+from oracle import aux_decoder as oa  # noqa: E402
+
+AUX_TAGS = ("default", "small", "k5")
+
+
+def aux_params(g, tag):
+    hsz, m, c, nl, ks, bsz, t_len, wseed = (int(v) for v in g[f"{tag}_meta"])
+    shapes = synth.convnext_param_shapes(hsz, m, num_channels=c, num_layers=nl, kernel_size=ks, prefix="decoder.")
+    return synth.synth_state_dict(shapes, seed=wseed), (hsz, m, bsz, t_len, wseed)
+
+
+@pytest.mark.parametrize("tag", AUX_TAGS)
+def test_g7_convnext_aux_decoder(tag):
+    """ConvNeXt aux decoder restatement vs reference AuxDecoderAdaptor; tolerance 2e-5 of the output range."""
+    g = load("g7_aux_decoder")
+    params, (hsz, m, bsz, t_len, wseed) = aux_params(g, tag)
+    cond = synth.synth_normal((bsz, t_len, hsz), wseed + 100)
+    raw = oa.aux_adaptor_forward(params, cond, m, 1, g[f"{tag}_smin"], g[f"{tag}_smax"], infer=False)
+    mel = oa.aux_adaptor_forward(params, cond, m, 1, g[f"{tag}_smin"], g[f"{tag}_smax"], infer=True)
+    if tag == "default":
+        raw, mel = raw[:, ::3], mel[:, ::3]
+    assert rel_err(raw, g[f"{tag}_raw"]) < 2e-5
+    assert rel_err(mel, g[f"{tag}_mel"]) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ("ddpm_dpm", "reflow_euler"))
+def test_g7_acoustic_glue(tag):
+    """aux decoder -> padding mask -> shallow diffusion -> padding mask (toplevel.py:84-105)."""
+    g = load("g7_aux_decoder")
+    params, (hsz, m, _, _, _) = aux_params(g, "small")
+    bsz, t_len, nseed = (int(v) for v in g["glue_meta"])
+    smin, smax = g["glue_smin"], g["glue_smax"]
+    net_params = synth_params("wavenet", m, 1, SN_ARGS, 45)
+    net = lambda x, t, c: ob.wavenet_forward(net_params, x, t, c, dilation_cycle_length=2)  # noqa: E731
+    if tag == "ddpm_dpm":
+        d = od.GaussianDiffusion(net, m, 1, timesteps=1000, k_step=400, spec_min=smin.tolist(),
+                                 spec_max=smax.tolist(), use_shallow_diffusion=True)
+        kw = dict(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=400)
+    else:
+        d = od.RectifiedFlow(net, m, 1, t_start=0.4, time_scale_factor=1000, spec_min=smin.tolist(),
+                             spec_max=smax.tolist(), use_shallow_diffusion=True)
+        kw = dict(T_start_infer=0.4, sampling_algorithm="euler", sampling_steps=20)
+    cond = synth.synth_normal((bsz, t_len, hsz), 7500)
+    noise = synth.synth_normal((bsz, 1, m, t_len), nseed)
+    aux, mel = oa.acoustic_infer(params, d, cond, g["glue_mel2ph"], noise, smin, smax, m, **kw)
+    assert rel_err(aux, g[f"glue_{tag}_aux"]) < 2e-5
+    assert rel_err(mel, g[f"glue_{tag}_mel"]) < 2e-4
+    assert np.all(mel[0, 41:] == 0) and np.all(mel[1, 48:] == 0)
