@@ -18,12 +18,13 @@ DSD_SRC_NOISE_BASE = -1000
 DSD_SAMPLE_GRAPH = 1
 DSD_SAMPLE_TRANSPOSE = 2
 BACKBONE_IDS = {"wavenet": 0, "lynxnet": 1}
+AUX_CONVNEXT = 2
 ACT_IDS = {"PReLU": 0, "SiLU": 1, "ReLU": 2}
 
 EXPORTS = [
     "dsd_api_version", "dsd_create", "dsd_destroy", "dsd_last_error", "dsd_load_weight",
     "dsd_finalize_weights", "dsd_prepare_cond", "dsd_denoise", "dsd_sample", "dsd_get_stats",
-    "dsd_kernel_timing", "dsd_kernel_timing_read",
+    "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_aux_decode",
 ]
 
 
@@ -84,12 +85,13 @@ def _load():
     lib.dsd_prepare_cond.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp]
     lib.dsd_denoise.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.dsd_sample.argtypes = [vp, C.POINTER(DsdProgram), vp, vp, vp, vp, vp, C.c_uint32, vp]
+    lib.dsd_aux_decode.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, vp, vp, vp]
     lib.dsd_get_stats.argtypes = [vp, C.POINTER(DsdStats)]
     lib.dsd_kernel_timing.argtypes = [vp, i32]
     lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     for name in EXPORTS:
         getattr(lib, name)
-    if lib.dsd_api_version() != 1:
+    if lib.dsd_api_version() != 2:
         raise NativeLibraryError("libdsdenoise.so API version mismatch")
     return lib
 

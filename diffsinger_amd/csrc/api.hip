@@ -57,7 +57,8 @@ struct dsd_handle {
     PackedGemm g_inproj, g_emb0, g_emb1, g_dproj, g_cp, g_tail1, g_out;
     std::vector<PackedGemm> g_conv, g_outp;          // WaveNet per layer
     std::vector<PackedGemm> g_pw1, g_pw2;            // LYNXNet per layer
-    std::vector<size_t> dw_w, dw_b, dw_prelu;        // LYNXNet depthwise params (float offsets)
+    std::vector<size_t> dw_w, dw_b, dw_prelu;        // LYNXNet / ConvNeXt depthwise params (float offsets)
+    PackedGemm g_ain, g_aout;                        // ConvNeXt aux decoder: dense k-tap in/out convs
     size_t freqs_off = 0;
     int emb_act = ACT_MISH;
 
@@ -113,6 +114,7 @@ inline int FM_of(const dsd_handle* h) { return h->cfg.in_dims * h->cfg.n_feats; 
 inline int L_of(const dsd_handle* h) { return h->cfg.num_layers; }
 inline int inner_of(const dsd_handle* h) { return h->cfg.num_channels * h->cfg.expansion_factor; }
 inline bool is_wavenet(const dsd_handle* h) { return h->cfg.backbone == DSD_BACKBONE_WAVENET; }
+inline bool is_aux(const dsd_handle* h) { return h->cfg.backbone == DSD_AUX_CONVNEXT; }
 inline int cp_rows(const dsd_handle* h) { return is_wavenet(h) ? 2 * C_of(h) : C_of(h); }
 
 // ------------------------------------------------------------------------------------------
@@ -122,6 +124,26 @@ std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params(const 
     std::vector<std::pair<std::string, std::vector<int64_t>>> v;
     const int64_t C = c.num_channels, M = (int64_t)c.in_dims * c.n_feats, H = c.hidden_size;
     auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
+    if (c.backbone == DSD_AUX_CONVNEXT) {      // modules/aux_decoder/convnext.py:58-76
+        const int64_t ks = c.kernel_size;
+        add("inconv.weight", {C, H, ks});
+        add("inconv.bias", {C});
+        for (int l = 0; l < c.num_layers; ++l) {
+            const std::string p = "conv." + std::to_string(l) + ".";
+            add(p + "gamma", {C});
+            add(p + "dwconv.weight", {C, 1, 7});
+            add(p + "dwconv.bias", {C});
+            add(p + "norm.weight", {C});
+            add(p + "norm.bias", {C});
+            add(p + "pwconv1.weight", {4 * C, C});
+            add(p + "pwconv1.bias", {4 * C});
+            add(p + "pwconv2.weight", {C, 4 * C});
+            add(p + "pwconv2.bias", {C});
+        }
+        add("outconv.weight", {M, C, ks});
+        add("outconv.bias", {M});
+        return v;
+    }
     add("input_projection.weight", {C, M, 1});
     add("input_projection.bias", {C});
     if (c.backbone == DSD_BACKBONE_WAVENET) {
@@ -232,7 +254,56 @@ PackedGemm pack_gemm(dsd_handle* h, int M, int Kreal, int taps, int pairC, const
 
 const HostTensor& W(dsd_handle* h, const std::string& n) { return h->raw.at(n); }
 
+// ConvNeXt aux decoder (convnext.py:17-85).  LayerNorm affine folded into pwconv1, the layer scale gamma folded
+// into pwconv2:  x + gamma * (W2 g + b2) = x + (diag(gamma) W2) g + gamma * b2.
+int build_packed_aux(dsd_handle* h) {
+    const dsd_config& c = h->cfg;
+    const int C = c.num_channels, M = FM_of(h), H = c.hidden_size, L = c.num_layers, ks = c.kernel_size;
+    h->blob_host.clear();
+    auto dense = [&](const std::string& name, int rows, int cin) {
+        const HostTensor* t = &W(h, name + ".weight");
+        const HostTensor* b = &W(h, name + ".bias");
+        WGet w = [t, cin, ks](int r, int k, int tap) { return (double)t->data[((size_t)r * cin + k) * ks + tap]; };
+        std::function<double(int)> bf = [b](int i) { return (double)b->data[i]; };
+        return pack_gemm(h, rows, cin, ks, 0, w, &bf);
+    };
+    h->g_ain = dense("inconv", C, H);
+    h->g_aout = dense("outconv", M, C);
+    h->g_pw1.resize(L);
+    h->g_pw2.resize(L);
+    h->dw_w.resize(L);
+    h->dw_b.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "conv." + std::to_string(l) + ".";
+        const HostTensor* w1 = &W(h, p + "pwconv1.weight");
+        const HostTensor* b1 = &W(h, p + "pwconv1.bias");
+        const HostTensor* g = &W(h, p + "norm.weight");
+        const HostTensor* be = &W(h, p + "norm.bias");
+        WGet wf = [w1, g, C](int r, int k, int) { return (double)w1->data[(size_t)r * C + k] * (double)g->data[k]; };
+        std::function<double(int)> bf = [w1, b1, be, C](int r) {
+            double s = b1->data[r];
+            for (int k = 0; k < C; ++k) s += (double)w1->data[(size_t)r * C + k] * (double)be->data[k];
+            return s;
+        };
+        h->g_pw1[l] = pack_gemm(h, 4 * C, C, 1, 0, wf, &bf);
+        const HostTensor* w2 = &W(h, p + "pwconv2.weight");
+        const HostTensor* b2 = &W(h, p + "pwconv2.bias");
+        const HostTensor* ga = &W(h, p + "gamma");
+        WGet w2f = [w2, ga, C](int r, int k, int) { return (double)ga->data[r] * (double)w2->data[(size_t)r * 4 * C + k]; };
+        std::function<double(int)> b2f = [b2, ga](int r) { return (double)ga->data[r] * (double)b2->data[r]; };
+        h->g_pw2[l] = pack_gemm(h, C, 4 * C, 1, 0, w2f, &b2f);
+        const auto& dw = W(h, p + "dwconv.weight").data;
+        h->dw_w[l] = blob_reserve(h, (size_t)C * 7);
+        memcpy(h->blob_host.data() + h->dw_w[l], dw.data(), sizeof(float) * C * 7);
+        const auto& db = W(h, p + "dwconv.bias").data;
+        h->dw_b[l] = blob_reserve(h, (size_t)C);
+        memcpy(h->blob_host.data() + h->dw_b[l], db.data(), sizeof(float) * C);
+    }
+    return DSD_OK;
+}
+
 int build_packed(dsd_handle* h) {
+    if (is_aux(h)) return build_packed_aux(h);
     const dsd_config& c = h->cfg;
     const int C = c.num_channels, M = FM_of(h), H = c.hidden_size, L = c.num_layers;
     h->blob_host.clear();
@@ -386,10 +457,14 @@ int ensure_workspace(dsd_handle* h, int B, int T) {
         return o;
     };
     const size_t per = (size_t)B * Ts;
-    const size_t o_cond = take(per * H), o_cp = take(per * L * cp_rows(h)), o_xh = take(per * C);
-    const size_t o_in = take(per * FM), o_out = take(per * FM);
+    const size_t o_cond = take(per * H), o_cp = is_aux(h) ? 0 : take(per * L * cp_rows(h)), o_xh = take(per * C);
+    const size_t o_in = is_aux(h) ? 0 : take(per * FM), o_out = take(per * FM);
     size_t o_z = 0, o_skip = 0, o_h = 0, o_xin = 0, o_u = 0, o_v = 0, o_st = 0;
-    if (is_wavenet(h)) {
+    if (is_aux(h)) {
+        o_xin = take(per * C);
+        o_u = take(per * 4 * C);
+        o_st = take(per * 2);
+    } else if (is_wavenet(h)) {
         o_z = take(per * C);
         o_skip = take(per * C);
         o_h = take(per * C);
@@ -492,7 +567,8 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     p.KC = g.K < 256 ? g.K : 256;       // re-decided below once the LDS row stride is known
     p.T = T;
     p.dil = dil;
-    p.HL = g.taps == 3 ? round_up(dil, 4) : 0;
+    p.taps = g.taps;
+    p.HL = g.taps > 1 ? round_up((g.taps / 2) * dil, 4) : 0;
     p.in_scale = 1.f;
     c.stage = stage;
     c.taps = g.taps;
@@ -502,6 +578,8 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     const int mtiles = g.pairC > 0 ? (g.pairC + 31) / 32 : (g.M + 63) / 64;
     const long wg64 = (long)batch * ((T + 63) / 64) * mtiles;
     c.nb = wg64 >= 512 ? 2 : 1;
+    // a k > 3 conv keeps all input channels resident (generic path): 64-frame tiles only while that fits in LDS
+    if (g.taps > 3 && (size_t)g.K * (64 + 2 * round_up((g.taps / 2) * dil, 4) + 16) * 4 > 150 * 1024) c.nb = 1;
     const int BN = 32 * c.nb;
     p.tiles_per_b = (T + BN - 1) / BN;
     int S = BN + 2 * p.HL;
@@ -515,8 +593,9 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     p.lpr_shift = 3;
     while ((1 << p.lpr_shift) < w4) ++p.lpr_shift;
     // a k=3 conv keeps all its input channels resident on the generic path (its walk does not mix taps and chunks)
-    if (g.taps == 3) p.KC = g.K;
-    c.fast = (g.K % gemm_fast_chunk_rows(g.taps, c.nb) == 0) && (g.Kreal == g.K) && gemm_has_fast(g.taps, c.nb, S);
+    if (g.taps > 1) p.KC = g.K;
+    c.fast = (g.taps == 1 || g.taps == 3) && (g.K % gemm_fast_chunk_rows(g.taps, c.nb) == 0) && (g.Kreal == g.K) &&
+             gemm_has_fast(g.taps, c.nb, S);
     p.lds_bytes = c.fast ? gemm_lds_bytes_fast(S, stage, g.taps, g.K, c.nb) : gemm_lds_bytes(p.KC, S);
     if (epi == EP_GATE || epi == EP_RESSKIP)        // the LDS-staged epilogue tile [64][BN + 4]
         p.lds_bytes = std::max(p.lds_bytes, 64 * (BN + 4) * 4);
@@ -622,7 +701,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
     hipError_t e;
     for (int l = 0; l < L; ++l) {
         e = launch_lynx_pre(h->xh, h->xin, h->cp + (long)l * C * Ts, cps, h->D + (long)l * C * Ns, Ns, film_col0,
-                            film_colb, xs, Ts, C, B, T, h->cfg.strong_cond, h->stats, Ts, st);
+                            film_colb, xs, Ts, C, B, T, h->cfg.strong_cond, h->stats, Ts, 1e-5f, st);
         if (e != hipSuccess) return fail(h, DSD_EHIP, "lynx_pre launch failed: %s", hipGetErrorString(e));
         GemmCall g = make_gemm(h, h->g_pw1[l], h->xin, xs, Ts, B, T, ST_LN, EP_SWIGLU, 0);
         g.p.ln_stats = h->stats; g.p.ln_ts = Ts;
@@ -640,7 +719,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
         o.p.out = h->xh; o.p.o_bstride = xs; o.p.o_rstride = Ts;
         if ((rc = run_gemm(h, o, st))) return rc;
     }
-    e = launch_lynx_pre(h->xh, nullptr, nullptr, 0, nullptr, 0, 0, 0, xs, Ts, C, B, T, 0, h->stats, Ts, st);
+    e = launch_lynx_pre(h->xh, nullptr, nullptr, 0, nullptr, 0, 0, 0, xs, Ts, C, B, T, 0, h->stats, Ts, 1e-5f, st);
     if (e != hipSuccess) return fail(h, DSD_EHIP, "final LayerNorm stats launch failed: %s", hipGetErrorString(e));
     GemmCall f = make_gemm(h, h->g_out, h->xh, xs, Ts, B, T, ST_LN, EP_LINCOMB, 0);
     f.p.ln_stats = h->stats; f.p.ln_ts = Ts;
@@ -673,14 +752,18 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
     if (!cfg || !out) return fail(nullptr, DSD_EINVAL, "dsd_create: null argument");
     if (cfg->struct_size != (int32_t)sizeof(dsd_config))
         return fail(nullptr, DSD_EINVAL, "dsd_create: struct_size %d != %zu", cfg->struct_size, sizeof(dsd_config));
-    if (cfg->backbone != DSD_BACKBONE_WAVENET && cfg->backbone != DSD_BACKBONE_LYNXNET)
+    if (cfg->backbone != DSD_BACKBONE_WAVENET && cfg->backbone != DSD_BACKBONE_LYNXNET && cfg->backbone != DSD_AUX_CONVNEXT)
         return fail(nullptr, DSD_EINVAL, "dsd_create: unknown backbone %d", cfg->backbone);
     if (cfg->in_dims < 1 || cfg->n_feats < 1 || cfg->num_layers < 1 || cfg->hidden_size < 1)
         return fail(nullptr, DSD_EINVAL, "dsd_create: non-positive dimension");
     if (cfg->num_channels < 32 || cfg->num_channels % 32 != 0)
         return fail(nullptr, DSD_EINVAL, "dsd_create: num_channels must be a positive multiple of 32 (got %d)",
                     cfg->num_channels);
-    if (cfg->backbone == DSD_BACKBONE_WAVENET) {
+    if (cfg->backbone == DSD_AUX_CONVNEXT) {
+        if (cfg->n_feats != 1) return fail(nullptr, DSD_EINVAL, "dsd_create: the aux decoder has n_feats == 1 (toplevel.py:50)");
+        if (cfg->kernel_size < 1 || cfg->kernel_size % 2 == 0 || cfg->kernel_size > 15)
+            return fail(nullptr, DSD_EINVAL, "dsd_create: ConvNeXt aux decoder needs an odd kernel_size <= 15");
+    } else if (cfg->backbone == DSD_BACKBONE_WAVENET) {
         if (cfg->dilation_cycle_length < 1 || cfg->dilation_cycle_length > 8)
             return fail(nullptr, DSD_EINVAL, "dsd_create: dilation_cycle_length must be in [1, 8]");
     } else {
@@ -790,6 +873,7 @@ int dsd_finalize_weights(dsd_handle* h) {
 int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64_t stride_b, int64_t stride_h,
                      int64_t stride_t, void* stream) {
     if (!h || !cond) return fail(h, DSD_EINVAL, "dsd_prepare_cond: null argument");
+    if (is_aux(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is an aux decoder (use dsd_aux_decode)");
     if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_prepare_cond: weights are not finalized");
     if (B < 1 || T < 1) return fail(h, DSD_EINVAL, "dsd_prepare_cond: B and T must be positive (B=%d, T=%d)", B, T);
     if (stride_t != 1 && stride_h != 1)
@@ -807,6 +891,52 @@ int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int
     rc = run_gemm(h, g, st);
     if (rc) return rc;
     h->cond_ready = true;
+    return DSD_OK;
+}
+
+int dsd_aux_decode(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64_t stride_b, int64_t stride_h,
+                   int64_t stride_t, float* out, const float* out_scale, const float* out_shift, void* stream) {
+    if (!h || !cond || !out) return fail(h, DSD_EINVAL, "dsd_aux_decode: null argument");
+    if (!is_aux(h)) return fail(h, DSD_ESTATE, "dsd_aux_decode: this handle is a denoiser backbone");
+    if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_aux_decode: weights are not finalized");
+    if (B < 1 || T < 1) return fail(h, DSD_EINVAL, "dsd_aux_decode: B and T must be positive (B=%d, T=%d)", B, T);
+    if (stride_t != 1 && stride_h != 1)
+        return fail(h, DSD_EINVAL, "dsd_aux_decode: cond must be contiguous along T ([B,H,T]) or along H ([B,T,H])");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_workspace(h, B, T);
+    if (rc) return rc;
+    const int H = h->cfg.hidden_size, Ts = h->Ts, L = L_of(h), C = C_of(h), M = FM_of(h);
+    const long xs = (long)C * Ts, us = (long)4 * C * Ts;
+    hipError_t e = launch_pack(cond, stride_b, stride_h, stride_t, h->cond_i, B, H, T, Ts, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "pack(cond) launch failed: %s", hipGetErrorString(e));
+    {   // inconv: Conv1d(H, C, k, padding=(k-1)//2)   convnext.py:63-66,80
+        GemmCall g = make_gemm(h, h->g_ain, h->cond_i, (long)H * Ts, Ts, B, T, ST_PLAIN, EP_BIAS_ACT, 1);
+        g.p.act = ACT_NONE; g.p.out = h->xh; g.p.o_bstride = xs; g.p.o_rstride = Ts;
+        if ((rc = run_gemm(h, g, st))) return rc;
+    }
+    for (int l = 0; l < L; ++l) {      // ConvNeXtBlock.forward   convnext.py:40-56
+        e = launch_dwconv(h->xh, h->xin, xs, Ts, C, B, T, h->blob + h->dw_w[l], h->blob + h->dw_b[l], 7, 3, nullptr, st);
+        if (e != hipSuccess) return fail(h, DSD_EHIP, "dwconv launch failed: %s", hipGetErrorString(e));
+        e = launch_lynx_pre(h->xin, nullptr, nullptr, 0, nullptr, 0, 0, 0, xs, Ts, C, B, T, 0, h->stats, Ts, 1e-6f, st);
+        if (e != hipSuccess) return fail(h, DSD_EHIP, "LayerNorm stats launch failed: %s", hipGetErrorString(e));
+        GemmCall g = make_gemm(h, h->g_pw1[l], h->xin, xs, Ts, B, T, ST_LN, EP_BIAS_ACT, 0);
+        g.p.ln_stats = h->stats; g.p.ln_ts = Ts;
+        g.p.act = ACT_GELU; g.p.out = h->ubuf; g.p.o_bstride = us; g.p.o_rstride = Ts;
+        if ((rc = run_gemm(h, g, st))) return rc;
+        GemmCall o = make_gemm(h, h->g_pw2[l], h->ubuf, us, Ts, B, T, ST_PLAIN, EP_BIAS_RES, 0);
+        o.p.aux = h->xh; o.p.aux_bstride = xs; o.p.aux_rstride = Ts;
+        o.p.out = h->xh; o.p.o_bstride = xs; o.p.o_rstride = Ts;
+        if ((rc = run_gemm(h, o, st))) return rc;
+    }
+    {   // outconv: Conv1d(C, M, k)   convnext.py:73-76,83
+        GemmCall g = make_gemm(h, h->g_aout, h->xh, xs, Ts, B, T, ST_PLAIN, EP_BIAS_ACT, 1);
+        g.p.act = ACT_NONE; g.p.out = h->io_out; g.p.o_bstride = (long)M * Ts; g.p.o_rstride = Ts;
+        if ((rc = run_gemm(h, g, st))) return rc;
+    }
+    // [B][M][Ts] -> [B,T,M] with the denorm affine of AuxDecoderAdaptor.denorm_spec (aux_decoder/__init__.py:53-56)
+    e = launch_unpack(h->io_out, Ts, out, B, 1, M, T, 1, out_scale, out_shift, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "unpack launch failed: %s", hipGetErrorString(e));
     return DSD_OK;
 }
 
@@ -962,7 +1092,12 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
     const int64_t C = C_of(h), M = FM_of(h), L = L_of(h);
     out->weight_bytes = (int64_t)h->blob_floats * 4;
     out->workspace_bytes = (int64_t)h->arena_floats * 4;
-    if (is_wavenet(h)) {
+    if (is_aux(h)) {        // one pass per utterance, not per NFE: the "_nfe" fields are per decoder pass here
+        const int64_t H = h->cfg.hidden_size, ks = h->cfg.kernel_size;
+        out->flops_per_frame_nfe = 2 * (ks * H * C + L * (7 * C + C * 4 * C + 4 * C * C) + ks * C * M);
+        out->bytes_per_frame_nfe = 4 * (H + M);
+        out->kernels_per_nfe = 2 + 4 * (int)L + 2;
+    } else if (is_wavenet(h)) {
         // 2*(M*C + L*(3*C*2C + C*2C) + C*C + C*M); bytes L*24C + 2*4*M
         out->flops_per_frame_nfe = 2 * (M * C + L * (3 * C * 2 * C + C * 2 * C) + C * C + C * M);
         out->bytes_per_frame_nfe = L * 24 * C + 8 * M;

@@ -129,7 +129,7 @@ hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const flo
 // LYNXNet layer prologue (lynxnet.py:76-84) + LayerNorm statistics (lynxnet.py:53, :151):
 //   strong_cond:   x <- x + cp ;  xin = x + d          (residual taken AFTER the conditioner add)
 //   otherwise:     xin = x + cp + d                    (residual = untouched x)
-//   stats[b][0][t] = mean_c xin,  stats[b][1][t] = 1/sqrt(var_c xin + 1e-5)   (biased variance)
+//   stats[b][0][t] = mean_c xin,  stats[b][1][t] = 1/sqrt(var_c xin + eps)   (biased variance)
 // One workgroup = 16 waves owns 64 frames x all channels; lanes run along time (256-B row segments), wave w
 // takes channels w, w+16, ...  Up to 64 channels per wave stay in registers, so x / cp are read ONCE and the
 // centred second moment (two-pass, like torch's LayerNorm) needs no second trip to memory; loads are issued
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(1024) void lynx_pre_kernel(float* __restrict__ x, f
                                                         const float* __restrict__ cp, long cp_bstride,
                                                         const float* __restrict__ film, int film_cstride,
                                                         int film_col0, int film_colb, long bstride, int rstride, int C,
-                                                        int T, int strong, float* __restrict__ stats, int ts) {
+                                                        int T, int strong, float* __restrict__ stats, int ts,
+                                                        float eps) {
     __shared__ float red[LP_WAVES][64];
     __shared__ float mean_s[64];
     const int b = blockIdx.y;
@@ -221,16 +222,16 @@ __global__ __launch_bounds__(1024) void lynx_pre_kernel(float* __restrict__ x, f
         for (int w = 0; w < LP_WAVES; ++w) s += red[w][lane];
         float* st = stats + (long)b * 2 * ts;
         st[t] = mean;
-        st[ts + t] = 1.f / sqrtf(s / (float)C + 1e-5f);
+        st[ts + t] = 1.f / sqrtf(s / (float)C + eps);
     }
 }
 
 hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstride, const float* film,
                            int film_cstride, int film_col0, int film_colb, long bstride, int rstride, int C, int B,
-                           int T, int strong, float* stats, int ts, hipStream_t stream) {
+                           int T, int strong, float* stats, int ts, float eps, hipStream_t stream) {
     dim3 grid(round_up(T, 64) / 64, B);
     hipLaunchKernelGGL(lynx_pre_kernel, grid, dim3(64 * LP_WAVES), 0, stream, x, xin, cp, cp_bstride, film,
-                       film_cstride, film_col0, film_colb, bstride, rstride, C, T, strong, stats, ts);
+                       film_cstride, film_col0, film_colb, bstride, rstride, C, T, strong, stats, ts, eps);
     return hipGetLastError();
 }
 
@@ -280,7 +281,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ s
         float v = acc[e];
         if (act == 0) v = v >= 0.f ? v : v * slope;                 // PReLU(per channel)
         else if (act == 1) v = v * (1.f / (1.f + expf(-v)));        // SiLU
-        else v = fmaxf(v, 0.f);                                     // ReLU
+        else if (act == 2) v = fmaxf(v, 0.f);                       // ReLU
+                                                                    // act == 3: none (ConvNeXt dwconv, convnext.py:42)
         o[e] = v;
     }
     if (t0 + lane * 4 < rstride - 3) *reinterpret_cast<f32x4*>(d) = o;

@@ -58,8 +58,9 @@ struct GemmP {
     int lds_bytes;          // dynamic LDS of this launch
     float inv_mtiles, inv_tiles_per_b, inv_w4;   // reciprocals for the prologue's index arithmetic
     int lpr_shift;          // staging: 2^lpr_shift lanes per staged row (>= float4 per row)
-    int dil;                // dilation (TAPS == 3)
-    int HL;                 // halo columns staged on each side (multiple of 4, >= dil)
+    int dil;                // dilation (taps > 1)
+    int taps;               // kernel size along time (1, 3, or any odd k on the generic path)
+    int HL;                 // halo columns staged on each side (multiple of 4, >= (taps / 2) * dil)
     int S;                  // LDS row stride in floats, S % 32 == 16
     float in_scale;         // ST_PLAIN: staged value DIVIDED by this (1 = identity)
     // ST_FILM: y = x + film[c * film_cstride + film_col0 + b * film_colb]
@@ -101,7 +102,7 @@ hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const flo
                          hipStream_t stream);
 hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstride, const float* film,
                            int film_cstride, int film_col0, int film_colb, long bstride, int rstride, int C, int B,
-                           int T, int strong, float* stats, int ts, hipStream_t stream);
+                           int T, int strong, float* stats, int ts, float eps, hipStream_t stream);
 hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T,
                          const float* w, const float* bias, int ksz, int act, const float* prelu, hipStream_t stream);
 

@@ -133,8 +133,10 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // packed A: [mblk][TAPS*K16][64 lanes][4]; this wave owns packed m-blocks 4*mtile + 2*wm + {0,1}
-    const long a_blk = (long)(TAPS * K16) * 256;
+    // TAPS == 0: kernel size taken from p.taps at run time (dense k-tap convs of the aux decoder; generic path only)
+    const int taps = TAPS > 0 ? TAPS : p.taps;
+    // packed A: [mblk][taps*K16][64 lanes][4]; this wave owns packed m-blocks 4*mtile + 2*wm + {0,1}
+    const long a_blk = (long)(taps * K16) * 256;
 
     const float* bsrc = p.B + (long)b * p.b_bstride;
     const int W4 = (BN + 2 * HL) >> 2;      // float4 per staged row
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         for (int kc = 0; kc < p.K; kc += p.KC) {
             const int kcn = min(p.KC, p.K - kc);
             const int n16 = kcn >> 4;
-            const int nit = TAPS * n16;
+            const int nit = taps * n16;
             auto ring_issue = [&](f32x4& d0, f32x4& d1) {
                 ring_load(d0, a0p + a_it * 256);
                 ring_load(d1, a1p + a_it * 256);
@@ -478,9 +480,9 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
             // ---- walk: [64-channel chunk][tap][k16 in chunk]; with TAPS == 1 that is plain k16 order ----
             int k4 = 0, tap = 0, c64 = 0;
             int nk = min(4, n16);
-            const float* bl0 = &lds[lrow * S + wn * (16 * NB) + lcol] + (HL - (TAPS == 3 ? p.dil : 0));
+            const float* bl0 = &lds[lrow * S + wn * (16 * NB) + lcol] + (HL - (taps >> 1) * p.dil);
             auto read_b = [&](float (&bv)[4][NB]) {
-                const float* blp = bl0 + (c64 * 4 + k4) * (16 * S) + (TAPS == 3 ? tap * p.dil : 0);
+                const float* blp = bl0 + (c64 * 4 + k4) * (16 * S) + (TAPS == 1 ? 0 : tap * p.dil);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
                 const bool wk = (++k4 == nk);
                 k4 = wk ? 0 : k4;
                 tap += wk ? 1 : 0;
-                const bool wt = (tap == TAPS);
+                const bool wt = (tap == taps);
                 tap = wt ? 0 : tap;
                 c64 += wt ? 1 : 0;
                 c64 = (c64 * 4 >= n16) ? 0 : c64;        // past the end: wrap to a valid, unused position
@@ -752,6 +754,9 @@ hipError_t gemm_init_all() {
     if ((e = attr_all<ST_LN, 1, EP_SWIGLU>()) != hipSuccess) return e;
     if ((e = attr_all<ST_PLAIN, 1, EP_BIAS_RES>()) != hipSuccess) return e;
     if ((e = attr_all<ST_LN, 1, EP_LINCOMB>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_LN, 1, EP_BIAS_ACT>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -766,6 +771,10 @@ hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int
     DSD_CASE(ST_LN, 1, EP_SWIGLU)
     DSD_CASE(ST_PLAIN, 1, EP_BIAS_RES)
     DSD_CASE(ST_LN, 1, EP_LINCOMB)
+    DSD_CASE(ST_LN, 1, EP_BIAS_ACT)
+    if (stage == ST_PLAIN && epi == EP_BIAS_ACT && taps > 1 && taps == p.taps && !fast)     // dense k-tap conv
+        return nb == 1 ? launch_one<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0>(p, batch, st)
+                       : launch_one<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0>(p, batch, st);
     return hipErrorInvalidValue;
 }
 

@@ -1,0 +1,89 @@
+"""The decoder half of `DiffSingerAcoustic` (modules/toplevel.py:32-120): everything after the FastSpeech2
+encoder has produced `condition`.  Same attribute names as the reference (`aux_decoder`, `diffusion`), so the
+matching slices of an acoustic checkpoint load with strict=True; same hparams read at construction
+(toplevel.py:44-83) and the same infer-branch behaviour (:90-105).  The encoder itself is outside the hot path
+(SURVEY.md section 8 "out of scope") and stays on the reference.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+from .aux_decoder import AuxDecoderAdaptor
+from .diffusion import GaussianDiffusion, RectifiedFlow
+from .hparams import hparams
+
+
+@dataclass
+class ShallowDiffusionOutput:          # toplevel.py:26-29
+    aux_out: torch.Tensor = None
+    diff_out: torch.Tensor = None
+
+
+def get_backbone_type(hp):             # modules/compat.py: older configs name the backbone differently
+    if 'backbone_type' in hp:
+        return hp['backbone_type']
+    if 'diff_decoder_type' in hp:
+        return hp['diff_decoder_type']
+    return 'wavenet'
+
+
+def get_backbone_args(hp, backbone_type):
+    args = hp.get('backbone_args')
+    if args is not None:
+        return args
+    if backbone_type == 'wavenet':
+        return {'num_layers': hp.get('residual_layers'), 'num_channels': hp.get('residual_channels'),
+                'dilation_cycle_length': hp.get('dilation_cycle_length')}
+    return None
+
+
+class AcousticDecoder(nn.Module):
+    """`DiffSingerAcoustic` minus `fs2`: aux decoder (shallow diffusion) + denoise loop."""
+
+    def __init__(self, out_dims):
+        super().__init__()
+        self.use_shallow_diffusion = hparams.get('use_shallow_diffusion', False)
+        self.shallow_args = hparams.get('shallow_diffusion_args', {})
+        if self.use_shallow_diffusion:
+            self.aux_decoder = AuxDecoderAdaptor(
+                in_dims=hparams['hidden_size'], out_dims=out_dims, num_feats=1,
+                spec_min=hparams['spec_min'], spec_max=hparams['spec_max'],
+                aux_decoder_arch=self.shallow_args['aux_decoder_arch'],
+                aux_decoder_args=self.shallow_args['aux_decoder_args'])
+        self.diffusion_type = hparams.get('diffusion_type', 'ddpm')
+        self.backbone_type = get_backbone_type(hparams)
+        self.backbone_args = get_backbone_args(hparams, self.backbone_type)
+        if self.diffusion_type == 'ddpm':
+            self.diffusion = GaussianDiffusion(
+                out_dims=out_dims, num_feats=1, timesteps=hparams['timesteps'], k_step=hparams['K_step'],
+                backbone_type=self.backbone_type, backbone_args=self.backbone_args,
+                spec_min=hparams['spec_min'], spec_max=hparams['spec_max'])
+        elif self.diffusion_type == 'reflow':
+            self.diffusion = RectifiedFlow(
+                out_dims=out_dims, num_feats=1, t_start=hparams['T_start'],
+                time_scale_factor=hparams['time_scale_factor'],
+                backbone_type=self.backbone_type, backbone_args=self.backbone_args,
+                spec_min=hparams['spec_min'], spec_max=hparams['spec_max'])
+        else:
+            raise NotImplementedError(self.diffusion_type)
+
+    def forward(self, condition, mel2ph, gt_mel=None, infer=True, **diffusion_kwargs) -> ShallowDiffusionOutput:
+        """toplevel.py:90-105 with `condition = self.fs2(...)` already evaluated."""
+        if not infer:
+            raise NotImplementedError("training (toplevel.py:106-120) stays on the reference modules")
+        mask = (mel2ph > 0).float()[:, :, None]
+        if self.use_shallow_diffusion:
+            aux_mel_pred = self.aux_decoder(condition, infer=True)
+            aux_mel_pred *= mask
+            if gt_mel is not None and self.shallow_args['val_gt_start']:
+                src_mel = gt_mel
+            else:
+                src_mel = aux_mel_pred
+        else:
+            aux_mel_pred = src_mel = None
+        mel_pred = self.diffusion(condition, src_spec=src_mel, infer=True, **diffusion_kwargs)
+        mel_pred *= mask
+        return ShallowDiffusionOutput(aux_out=aux_mel_pred, diff_out=mel_pred)

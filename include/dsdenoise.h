@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSD_API_VERSION 1
+#define DSD_API_VERSION 2
 
 /* error codes */
 #define DSD_OK 0
@@ -37,7 +37,10 @@ extern "C" {
 typedef struct dsd_handle dsd_handle;
 
 /* modules/backbones/__init__.py:6-9  BACKBONES = {'wavenet': WaveNet, 'lynxnet': LYNXNet} */
-enum { DSD_BACKBONE_WAVENET = 0, DSD_BACKBONE_LYNXNET = 1 };
+enum { DSD_BACKBONE_WAVENET = 0, DSD_BACKBONE_LYNXNET = 1,
+       /* modules/aux_decoder/__init__.py:7-9  AUX_DECODERS = {'convnext': ConvNeXtDecoder}: not a denoiser - the
+          shallow-diffusion aux decoder that produces the loop's start point (see dsd_aux_decode) */
+       DSD_AUX_CONVNEXT = 2 };
 /* modules/backbones/lynxnet.py:38-42  activation_classes */
 enum { DSD_ACT_PRELU = 0, DSD_ACT_SILU = 1, DSD_ACT_RELU = 2 };
 
@@ -58,7 +61,7 @@ typedef struct dsd_config {
     int32_t hidden_size;            /* H: encoder hidden size of `cond`                     */
     int32_t dilation_cycle_length;  /* WaveNet only                                         */
     int32_t expansion_factor;       /* LYNXNet only                                         */
-    int32_t kernel_size;            /* LYNXNet only (depthwise conv, odd)                   */
+    int32_t kernel_size;            /* LYNXNet: depthwise conv (odd); aux decoder: in/out conv */
     int32_t activation;             /* LYNXNet only: DSD_ACT_*                              */
     int32_t strong_cond;            /* LYNXNet only: 0/1                                    */
     int32_t device;                 /* HIP device ordinal                                   */
@@ -104,6 +107,21 @@ int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int
  * reflow.py:135); integer steps are passed as their float value (common_layers.py:277).
  */
 int dsd_denoise(dsd_handle* h, const float* x, const float* t, int32_t t_len, float* out, void* stream);
+
+/*
+ * Shallow-diffusion aux decoder (the step right before the loop: it produces the `src_spec` the loop starts
+ * from).  A handle created with backbone == DSD_AUX_CONVNEXT takes
+ *   in_dims = mel bins M (`out_dims`), n_feats = 1, hidden_size = H (`in_dims` of the decoder),
+ *   num_channels / num_layers / kernel_size = ConvNeXtDecoder's keyword arguments
+ * and the state_dict of ConvNeXtDecoder (modules/aux_decoder/convnext.py:58-76: inconv.*, conv.N.{gamma,
+ * dwconv.*, norm.*, pwconv1.*, pwconv2.*}, outconv.*) through dsd_load_weight / dsd_finalize_weights.
+ * Replaces: AuxDecoderAdaptor.forward(condition, infer)  (modules/aux_decoder/__init__.py:58-71) =
+ * ConvNeXtDecoder.forward (convnext.py:78-85) + denorm_spec (:53-56).
+ *   cond  element (b, h, t) at cond[b*stride_b + h*stride_h + t*stride_t]  ([B,T,H] `condition` or [B,H,T])
+ *   out   [B, T, M] contiguous;  out = y * out_scale[m] + out_shift[m]   (NULL, NULL = raw decoder output)
+ */
+int dsd_aux_decode(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64_t stride_b, int64_t stride_h,
+                   int64_t stride_t, float* out, const float* out_scale, const float* out_shift, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sampling programs.  Every sampler of the reference (ddpm.py:149-204,221-351 p_sample /

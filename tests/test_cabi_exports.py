@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert _lib.lib().dsd_api_version() == 1
+    assert _lib.lib().dsd_api_version() == 2
 
 
 def test_struct_sizes_match_header():
@@ -93,3 +93,29 @@ def test_state_dict_names_match_reference_layout():
         assert list(sd) == list(shapes) or set(sd) == set(shapes)
         for k, v in shapes.items():
             assert tuple(sd[k].shape) == tuple(v), k
+
+
+def test_aux_decoder_state_dict_and_host_checks():
+    """ConvNeXt aux decoder shim: reference state_dict layout (convnext.py:24-35,63-76), registry behaviour of
+    modules/aux_decoder/__init__.py:7-21 and the loud CPU refusal."""
+    import torch
+    from diffsinger_amd import synth
+    from diffsinger_amd.aux_decoder import AUX_DECODERS, AuxDecoderAdaptor, build_aux_decoder
+    assert list(AUX_DECODERS) == ["convnext"]
+    dec = build_aux_decoder(256, 128, "convnext", dict(num_channels=64, num_layers=2, kernel_size=7,
+                                                        dropout_rate=0.1, not_an_argument=3))
+    shapes = synth.convnext_param_shapes(256, 128, num_channels=64, num_layers=2, kernel_size=7)
+    sd = dec.state_dict()
+    assert set(sd) == set(shapes)
+    for k, v in shapes.items():
+        assert tuple(sd[k].shape) == tuple(v), k
+    a = AuxDecoderAdaptor(256, 128, 1, [-12.0], [0.0], "convnext", dict(num_channels=64, num_layers=2))
+    assert all(k.startswith("decoder.") for k in a.state_dict())          # spec_min/max are non-persistent
+    assert tuple(a.spec_min.shape) == (1, 1, 1)
+    x = torch.tensor([[[-12.0, -6.0, 0.0]]])
+    assert torch.allclose(a.norm_spec(x), torch.tensor([[[-1.0, 0.0, 1.0]]]))
+    assert torch.allclose(a.denorm_spec(a.norm_spec(x)), x)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path"):
+        a(torch.zeros(1, 4, 256), infer=True)
+    with pytest.raises(ValueError):
+        build_aux_decoder(256, 128, "convnext", dict(kernel_size=6))
