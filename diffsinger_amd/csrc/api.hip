@@ -685,7 +685,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             o.p.o_bstride = xs; o.p.o_rstride = Ts;
             if ((rc = run_gemm(h, o, st))) return rc;
         }
-        GemmCall t1 = make_gemm(h, h->g_tail1, h->skip, xs, Ts, B, T, ST_PLAIN, EP_BIAS_ACT, 0);
+        GemmCall t1 = make_gemm(h, h->g_tail1, h->skip, xs, Ts, B, T, ST_SCALE, EP_BIAS_ACT, 0);
         t1.p.in_scale = sqrtf((float)L);      // staged value is DIVIDED by in_scale (wavenet.py:96)
         t1.p.act = ACT_RELU; t1.p.out = h->hbuf; t1.p.o_bstride = xs; t1.p.o_rstride = Ts;
         if ((rc = run_gemm(h, t1, st))) return rc;

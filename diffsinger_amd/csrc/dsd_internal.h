@@ -16,7 +16,7 @@ namespace dsd {
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int padded_ts(int T) { return round_up(T, 64) + 32; }
 
-enum Stage { ST_PLAIN = 0, ST_FILM = 1, ST_LN = 2 };
+enum Stage { ST_PLAIN = 0, ST_FILM = 1, ST_LN = 2, ST_SCALE = 3 };
 enum Epi { EP_BIAS_ACT = 0, EP_GATE = 1, EP_RESSKIP = 2, EP_LINCOMB = 3, EP_SWIGLU = 4, EP_BIAS_RES = 5 };
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3 };
 
@@ -62,7 +62,7 @@ struct GemmP {
     int taps;               // kernel size along time (1, 3, or any odd k on the generic path)
     int HL;                 // halo columns staged on each side (multiple of 4, >= (taps / 2) * dil)
     int S;                  // LDS row stride in floats, S % 32 == 16
-    float in_scale;         // ST_PLAIN: staged value DIVIDED by this (1 = identity)
+    float in_scale;         // ST_SCALE: staged value DIVIDED by this
     // ST_FILM: y = x + film[c * film_cstride + film_col0 + b * film_colb]
     const float* film;
     int film_cstride, film_col0, film_colb;

@@ -62,11 +62,25 @@ __device__ unsigned long long g_stamps[8][4096][8];
             __builtin_amdgcn_sched_barrier(0);                                                    \
         }                                                                                         \
     } while (0)
+// finer stamps inside the first chunk pair of the pipelined K loop
+__device__ unsigned long long g_stamps2[8][4096][16];
+#define DSD_STAMP2(i)                                                                             \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < 4096 && c == 0) {                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            g_stamps2[EPI][blockIdx.x][i] = __builtin_amdgcn_s_memtime();                         \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+        }                                                                                         \
+    } while (0)
 extern "C" int dsd_dbg_read_stamps(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
 }
+extern "C" int dsd_dbg_read_stamps2(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps2), sizeof(g_stamps2));
+}
 #else
 #define DSD_STAMP(i)
+#define DSD_STAMP2(i)
 #endif
 
 // floor(x / d) for 0 <= x < 2^22 with inv = 1.0f / d: one cvt + mul + cvt instead of the ~40-instruction
@@ -210,12 +224,12 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         constexpr int ITERS = TAPS * (CR / 16);         // k16 steps per chunk: 12, 8 or 4
         constexpr int NU = CR * SW / 1024;              // float4 staged per lane and chunk (upper bound)
         constexpr int BUF = CR * SW;                    // floats per chunk buffer
-        float* lds_film = lds + 2 * BUF;                // ST_FILM: [K]
         float* lds_stat = lds + 2 * BUF;                // ST_LN: [2][BN] (mean | rstd), HL == 0
         const int NC = p.K / CR;
 
         // ---- per-lane staging geometry: lane's u-th float4 of a [64 x W4] chunk tile ----
         unsigned s_voff[NU];                            // byte offset from the chunk's (row 0, frame t0-HL)
+        unsigned f_voff[NU];                            // ST_FILM: byte offset of the row's FiLM scalar
         int s_loff[NU];                                 // float offset in a chunk buffer
         int s_row[NU];
         unsigned s_mask[NU];                            // bit e: frame of element e is inside [0, T)
@@ -229,6 +243,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
             s_valid[u] = valid;
             s_row[u] = row;
             s_voff[u] = (unsigned)((row * p.b_rstride + c4 * 4) * 4);
+            f_voff[u] = (unsigned)(row * p.film_cstride * 4);
             s_loff[u] = row * SW + c4 * 4;
             unsigned m = 0;
 #pragma unroll
@@ -241,16 +256,33 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         unsigned long long sbase = (unsigned long long)(bsrc + (t0 - HL));      // chunk 0, row 0
         const unsigned long long sstep = (unsigned long long)p.b_rstride * CR * 4;
         f32x4 sv[NU];
+        // ST_FILM: the step-embedding scalar of each staged row travels with the row itself (one dword per staged
+        // float4, same SGPR-base + lane-offset form, covered by the same counted wait): the transform below is
+        // then pure VALU on landed registers - no LDS round trip between the wait and the ds_write.
+        float fadd[NU];
+        unsigned long long fbase = 0;
+        unsigned long long fstep = 0;
+        if (STAGE == ST_FILM) {
+            fbase = (unsigned long long)(p.film + p.film_col0 + b * p.film_colb);
+            fstep = (unsigned long long)p.film_cstride * CR * 4;
+        }
         auto stage_issue = [&]() {
 #pragma unroll
             for (int u = 0; u < NU; ++u) ring_load_s<0>(sv[u], s_voff[u], sbase);
             sbase += sstep;
+            if (STAGE == ST_FILM) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(fadd[u]) : "v"(f_voff[u]), "s"(fbase) : "memory");
+                fbase += fstep;
+            }
         };
         auto stage_write = [&](int chunk, float* buf) {
+            (void)chunk;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 float add = 0.f;
-                if (STAGE == ST_FILM) add = lds_film[chunk * CR + s_row[u]];
+                if (STAGE == ST_FILM) add = fadd[u];
                 f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, rstd = f32x4{1.f, 1.f, 1.f, 1.f};
                 if (STAGE == ST_LN) {
                     const int col = (s_loff[u] - s_row[u] * SW);
@@ -263,7 +295,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
                     float y = sv[u][e];
                     if (STAGE == ST_FILM) y = y + add;
                     else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
-                    else if (p.in_scale != 1.f) y = y / p.in_scale;       // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
+                    else if (STAGE == ST_SCALE) y = y / p.in_scale;        // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
                     o[e] = ((s_mask[u] >> e) & 1u) ? y : 0.f;              // zero padding AFTER the FiLM add (wavenet.py:36-38)
                 }
                 if (s_valid[u]) *reinterpret_cast<f32x4*>(&buf[s_loff[u]]) = o;
@@ -271,14 +303,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         };
 
         // ---- prologue: tile constants, epilogue operands and chunk 0, all in flight together ----
-        float cst[4];                                   // FiLM vector / LN statistics of this tile (compiler loads)
-        if (STAGE == ST_FILM) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ch = min(tid + 256 * i, p.K - 1);
-                cst[i] = p.film[(long)ch * p.film_cstride + p.film_col0 + b * p.film_colb];
-            }
-        }
+        float cst[1];                                   // LN statistics of this tile (compiler loads)
         if (STAGE == ST_LN) {
             const int col = min(t0 + (tid & (BN - 1)), p.ln_ts - 1);
             cst[0] = p.ln_stats[(long)b * 2 * p.ln_ts + ((tid >> (NB == 1 ? 5 : 6)) & 1) * p.ln_ts + col];
@@ -298,15 +323,10 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
 #undef DSD_RING_PRO
         an0 += 8192;
         an1 += 8192;
-        if (STAGE == ST_FILM) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (tid + 256 * i < p.K) lds_film[tid + 256 * i] = cst[i];
-        }
         if (STAGE == ST_LN) {
             if (tid < 2 * BN) lds_stat[tid] = cst[0];
+            __syncthreads();                            // the transform below reads the tile statistics
         }
-        if (STAGE != ST_PLAIN) __syncthreads();         // the transform below reads the tile constants
         stage_write(0, lds);
         // the ring prologue is retired before the barrier: hipcc does not know those registers are in flight
         // and may move them (5.7: form (ii) pins order, not allocation); it had the transform phase to land
@@ -359,27 +379,40 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ITERS) : "memory");
 #pragma unroll
             for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(sv[u])::"memory");   // consumers stay below the wait
+            if (STAGE == ST_FILM) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(fadd[u])::"memory");
+            }
         };
         for (int c = 0; c < NC; c += 2) {
             // even chunk from buffer 0; chunk c+1 (if any) lands in buffer 1 meanwhile
             const bool has1 = c + 1 < NC;
+            DSD_STAMP2(0);
             if (has1) stage_issue();
             DSD_CHUNK(0, 0)
+            DSD_STAMP2(1);
             if (has1) {
                 stage_wait();
+                DSD_STAMP2(2);
                 stage_write(c + 1, lds + BUF);
             }
+            DSD_STAMP2(3);
             __syncthreads();
+            DSD_STAMP2(4);
             if (has1) {
                 // odd chunk from buffer 1; chunk c+2 (if any) lands in buffer 0
                 const bool has2 = c + 2 < NC;
                 if (has2) stage_issue();
                 DSD_CHUNK(ITERS & 7, 1)
+                DSD_STAMP2(5);
                 if (has2) {
                     stage_wait();
+                    DSD_STAMP2(6);
                     stage_write(c + 2, lds);
                 }
+                DSD_STAMP2(7);
                 __syncthreads();
+                DSD_STAMP2(8);
             }
         }
 #undef DSD_CHUNK
@@ -450,7 +483,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
                             float y = v[u][e];
                             if (STAGE == ST_FILM) y = y + add[u];
                             else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
-                            else if (p.in_scale != 1.f) y = y / p.in_scale;   // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
+                            else if (STAGE == ST_SCALE) y = y / p.in_scale;   // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
                             const bool ok = (t >= 0) && (t < p.T) && row_ok;
                             o[e] = ok ? y : 0.f;       // zero padding applies AFTER the FiLM add (wavenet.py:36-38)
                         }
@@ -679,7 +712,8 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
 int gemm_lds_bytes(int KC, int S) { return KC * S * 4; }
 int gemm_fast_chunk_rows(int taps, int nb) { (void)taps; (void)nb; return 64; }
 int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb) {
-    return (2 * gemm_fast_chunk_rows(taps, nb) * S + (stage == ST_FILM ? K : 0) + (stage == ST_LN ? 2 * 32 * nb : 0)) * 4;
+    (void)K;
+    return (2 * gemm_fast_chunk_rows(taps, nb) * S + (stage == ST_LN ? 2 * 32 * nb : 0)) * 4;
 }
 
 template <int STAGE, int TAPS, int EPI, int NB, int SW>
@@ -748,6 +782,7 @@ static hipError_t attr_all() {
 hipError_t gemm_init_all() {
     hipError_t e;
     if ((e = attr_all<ST_PLAIN, 1, EP_BIAS_ACT>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_SCALE, 1, EP_BIAS_ACT>()) != hipSuccess) return e;
     if ((e = attr_all<ST_FILM, 3, EP_GATE>()) != hipSuccess) return e;
     if ((e = attr_all<ST_PLAIN, 1, EP_RESSKIP>()) != hipSuccess) return e;
     if ((e = attr_all<ST_PLAIN, 1, EP_LINCOMB>()) != hipSuccess) return e;
@@ -765,6 +800,7 @@ hipError_t gemm_init_all() {
 
 hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int fast, int batch, hipStream_t st) {
     DSD_CASE(ST_PLAIN, 1, EP_BIAS_ACT)
+    DSD_CASE(ST_SCALE, 1, EP_BIAS_ACT)
     DSD_CASE(ST_FILM, 3, EP_GATE)
     DSD_CASE(ST_PLAIN, 1, EP_RESSKIP)
     DSD_CASE(ST_PLAIN, 1, EP_LINCOMB)

@@ -60,3 +60,18 @@ for v, nm in names.items():
           f"mean WG life {(st[:,6]-st[:,0]).mean():.0f} cyc")
     for lb, m, mx in zip(labels, d.mean(axis=0), d.max(axis=0)):
         print(f"    {lb:28s} mean {m:8.0f}  max {mx:8.0f}")
+
+buf2 = np.zeros((8, 4096, 16), dtype=np.uint64)
+assert _lib.lib().dsd_dbg_read_stamps2(buf2.ctypes.data_as(C.c_void_p)) == 0
+lab2 = ["chunk0: issue + 1 chunk of MFMA steps", "wait staged loads", "transform + LDS write", "barrier",
+        "chunk1: issue + MFMA steps", "wait staged loads", "transform + LDS write", "barrier"]
+print("first chunk pair of the pipelined K loop (wave 0):")
+for v, nm in names.items():
+    st = buf2[v].astype(np.int64)
+    live = (st[:, 0] > 0) & (st[:, 8] > 0)
+    if not live.any():
+        continue
+    d = np.diff(st[live][:, :9], axis=1)
+    print(f"  {nm}")
+    for lb, m, mx in zip(lab2, d.mean(axis=0), d.max(axis=0)):
+        print(f"    {lb:40s} mean {m:8.0f}  max {mx:8.0f}")
