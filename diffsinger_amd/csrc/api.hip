@@ -596,7 +596,9 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     if (g.taps > 1) p.KC = g.K;
     c.fast = (g.taps == 1 || g.taps == 3) && (g.K % gemm_fast_chunk_rows(g.taps, c.nb) == 0) && (g.Kreal == g.K) &&
              gemm_has_fast(g.taps, c.nb, S);
-    p.lds_bytes = c.fast ? gemm_lds_bytes_fast(S, stage, g.taps, g.K, c.nb) : gemm_lds_bytes(p.KC, S);
+    // small grids (one workgroup per CU, one wave per SIMD): all <= 4 chunks resident, no barrier in the K walk
+    if (c.fast && c.nb == 1 && g.K <= 256 && g.taps == 1) c.fast = 2;
+    p.lds_bytes = c.fast ? gemm_lds_bytes_fast(S, stage, g.taps, g.K, c.nb, c.fast == 2) : gemm_lds_bytes(p.KC, S);
     if (epi == EP_GATE || epi == EP_RESSKIP)        // the LDS-staged epilogue tile [64][BN + 4]
         p.lds_bytes = std::max(p.lds_bytes, 64 * (BN + 4) * 4);
     return c;

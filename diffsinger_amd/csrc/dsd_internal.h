@@ -89,7 +89,7 @@ hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int
 bool gemm_has_fast(int taps, int nb, int S);
 void gemm_set_timing_events(hipEvent_t start, hipEvent_t stop);   // next launches on this thread; (nullptr, nullptr) = off
 int gemm_lds_bytes(int KC, int S);
-int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb);
+int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb, int resident);
 int gemm_fast_chunk_rows(int taps, int nb);
 hipError_t gemm_init_all();
 

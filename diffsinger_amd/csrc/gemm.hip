@@ -114,7 +114,7 @@ __device__ __forceinline__ void ring_load_s(f32x4& dst, unsigned voff, unsigned 
 // base + immediate), the K walk is linear in groups of 8 steps (K % 128 == 0 and no tap/chunk mixing), so a
 // k16 step is 8*NB MFMAs + 4*NB ds_read + 2 loads + 1 counted wait and nothing else.  SW == 0: generic
 // instantiation (runtime S, any K multiple of 16, whole chunk staged then walked) for every other shape.
-template <int STAGE, int TAPS, int EPI, int NB, int SW>
+template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0>
 __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BN = 32 * NB;
@@ -224,16 +224,22 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         constexpr int ITERS = TAPS * (CR / 16);         // k16 steps per chunk: 12, 8 or 4
         constexpr int NU = CR * SW / 1024;              // float4 staged per lane and chunk (upper bound)
         constexpr int BUF = CR * SW;                    // floats per chunk buffer
-        float* lds_stat = lds + 2 * BUF;                // ST_LN: [2][BN] (mean | rstd), HL == 0
+        // RES: all (<= 4) chunks resident - staged in one batch in the prologue, no barrier inside the K loop.  One
+        // wave per SIMD cannot hide the wait -> transform -> ds_write -> barrier -> ds_read chain of a chunk
+        // boundary behind another wave's MFMAs, so for small grids (B = 1) the boundaries are removed instead.
+        constexpr int NBUF = RES ? 4 : 2;
+        float* lds_stat = lds + NBUF * BUF;             // ST_LN: [2][BN] (mean | rstd), HL == 0
         const int NC = p.K / CR;
 
         // ---- per-lane staging geometry: lane's u-th float4 of a [64 x W4] chunk tile ----
+        // Only what the loads need is computed before they are issued (the prologue is latency-critical at B = 1:
+        // the first activation loads of a kernel take ~1 us to land); masks and LDS offsets follow in their shadow.
         unsigned s_voff[NU];                            // byte offset from the chunk's (row 0, frame t0-HL)
         unsigned f_voff[NU];                            // ST_FILM: byte offset of the row's FiLM scalar
-        int s_loff[NU];                                 // float offset in a chunk buffer
-        int s_row[NU];
-        unsigned s_mask[NU];                            // bit e: frame of element e is inside [0, T)
+        int s_row[NU], s_c4[NU];
         bool s_valid[NU];
+        int s_loff[NU];                                 // float offset in a chunk buffer        (filled below,
+        unsigned s_mask[NU];                            // bit e: frame of element e in [0, T)     after the loads)
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int idx = tid + 256 * u;
@@ -242,47 +248,42 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
             const int c4 = valid ? idx - row * W4 : 0;
             s_valid[u] = valid;
             s_row[u] = row;
+            s_c4[u] = c4;
             s_voff[u] = (unsigned)((row * p.b_rstride + c4 * 4) * 4);
             f_voff[u] = (unsigned)(row * p.film_cstride * 4);
-            s_loff[u] = row * SW + c4 * 4;
-            unsigned m = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int t = t0 - HL + c4 * 4 + e;
-                m |= (t >= 0 && t < p.T) ? (1u << e) : 0u;
-            }
-            s_mask[u] = m;
         }
         unsigned long long sbase = (unsigned long long)(bsrc + (t0 - HL));      // chunk 0, row 0
         const unsigned long long sstep = (unsigned long long)p.b_rstride * CR * 4;
-        f32x4 sv[NU];
+        constexpr int NSV = RES ? 4 : 1;
+        f32x4 sv[NSV][NU];
         // ST_FILM: the step-embedding scalar of each staged row travels with the row itself (one dword per staged
         // float4, same SGPR-base + lane-offset form, covered by the same counted wait): the transform below is
         // then pure VALU on landed registers - no LDS round trip between the wait and the ds_write.
-        float fadd[NU];
+        float fadd[NSV][NU];
         unsigned long long fbase = 0;
         unsigned long long fstep = 0;
         if (STAGE == ST_FILM) {
             fbase = (unsigned long long)(p.film + p.film_col0 + b * p.film_colb);
             fstep = (unsigned long long)p.film_cstride * CR * 4;
         }
-        auto stage_issue = [&]() {
+        auto stage_issue = [&](auto slotc) {
+            constexpr int q = decltype(slotc)::value;
 #pragma unroll
-            for (int u = 0; u < NU; ++u) ring_load_s<0>(sv[u], s_voff[u], sbase);
+            for (int u = 0; u < NU; ++u) ring_load_s<0>(sv[q][u], s_voff[u], sbase);
             sbase += sstep;
             if (STAGE == ST_FILM) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
-                    asm volatile("global_load_dword %0, %1, %2" : "=v"(fadd[u]) : "v"(f_voff[u]), "s"(fbase) : "memory");
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(fadd[q][u]) : "v"(f_voff[u]), "s"(fbase) : "memory");
                 fbase += fstep;
             }
         };
-        auto stage_write = [&](int chunk, float* buf) {
-            (void)chunk;
+        auto stage_write = [&](auto slotc, float* buf) {
+            constexpr int q = decltype(slotc)::value;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 float add = 0.f;
-                if (STAGE == ST_FILM) add = fadd[u];
+                if (STAGE == ST_FILM) add = fadd[q][u];
                 f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, rstd = f32x4{1.f, 1.f, 1.f, 1.f};
                 if (STAGE == ST_LN) {
                     const int col = (s_loff[u] - s_row[u] * SW);
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float y = sv[u][e];
+                    float y = sv[q][u][e];
                     if (STAGE == ST_FILM) y = y + add;
                     else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
                     else if (STAGE == ST_SCALE) y = y / p.in_scale;        // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
@@ -302,17 +303,29 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
             }
         };
 
-        // ---- prologue: tile constants, epilogue operands and chunk 0, all in flight together ----
-        float cst[1];                                   // LN statistics of this tile (compiler loads)
+        // ---- prologue: chunk 0, the weight ring, tile constants and epilogue operands all in flight together ----
+        float cst[1];                                   // LN statistics of this tile
         if (STAGE == ST_LN) {
             const int col = min(t0 + (tid & (BN - 1)), p.ln_ts - 1);
-            cst[0] = p.ln_stats[(long)b * 2 * p.ln_ts + ((tid >> (NB == 1 ? 5 : 6)) & 1) * p.ln_ts + col];
+            const float* sp = p.ln_stats + (long)b * 2 * p.ln_ts + ((tid >> (NB == 1 ? 5 : 6)) & 1) * p.ln_ts + col;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(cst[0]) : "v"(sp) : "memory");
         }
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, RES ? 1 : 0>;
+        using I2 = std::integral_constant<int, RES ? 2 : 0>;
+        using I3 = std::integral_constant<int, RES ? 3 : 0>;
+        stage_issue(I0{});
+        if constexpr (RES) {
+            if (NC > 1) stage_issue(I1{});
+            if (NC > 2) stage_issue(I2{});
+            if (NC > 3) stage_issue(I3{});
+        }
+#ifndef DSD_EXP_NOEPI
         epi_prefetch();
-        stage_issue();
-        DSD_STAMP(1);
-        __builtin_amdgcn_s_waitcnt(0x0F70);             // retires everything issued so far (asm loads too)
-        // weight ring prologue: blocks 0..7 of both row blocks; in flight during the chunk-0 transform
+#endif
+        // weight ring prologue: blocks 0..7 of both row blocks.  Issued LAST: the vector-memory pipe of a CU moves
+        // 64 B/clk, so these 16 KiB per wave take ~1 k cycles to issue - in the shadow of the activation latency -
+        // and the counted wait below does not include them.
         unsigned long long an0 = a0s, an1 = a1s;        // base of the block the next refill of "step 0" loads
         const unsigned voffA = lane * 16, voffB = lane * 16 + 4096, voffC = lane * 16 + 8192;
 #define DSD_RING_PRO(U)                                                              \
@@ -323,14 +336,48 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
 #undef DSD_RING_PRO
         an0 += 8192;
         an1 += 8192;
+        DSD_STAMP(1);
+        // LDS offsets and padding masks, computed while the loads fly
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            s_loff[u] = s_row[u] * SW + s_c4[u] * 4;
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = t0 - HL + s_c4[u] * 4 + e;
+                m |= (t >= 0 && t < p.T) ? (1u << e) : 0u;
+            }
+            s_mask[u] = m;
+        }
+        __builtin_amdgcn_sched_barrier(0);              // keep the geometry above the wait, in the loads' shadow
+        // Staged activations, FiLM scalars and epilogue operands have landed once all but the 16 ring loads are
+        // retired (in-order return).  The LN statistics (compiler load, older than all of them) are covered too.
+        {
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < NSV; ++q)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    asm volatile("" : "+v"(sv[q][u])::"memory");
+                    if (STAGE == ST_FILM) asm volatile("" : "+v"(fadd[q][u])::"memory");
+                }
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) asm volatile("" : "+v"(pre[k])::"memory");
+            if (STAGE == ST_LN) asm volatile("" : "+v"(cst[0])::"memory");
+        }
         if (STAGE == ST_LN) {
             if (tid < 2 * BN) lds_stat[tid] = cst[0];
             __syncthreads();                            // the transform below reads the tile statistics
         }
-        stage_write(0, lds);
-        // the ring prologue is retired before the barrier: hipcc does not know those registers are in flight
-        // and may move them (5.7: form (ii) pins order, not allocation); it had the transform phase to land
+        stage_write(I0{}, lds);
+        if constexpr (RES) {
+            if (NC > 1) stage_write(I1{}, lds + BUF);
+            if (NC > 2) stage_write(I2{}, lds + 2 * BUF);
+            if (NC > 3) stage_write(I3{}, lds + 3 * BUF);
+        }
         DSD_STAMP(2);
+        // the ring prologue is retired before the barrier: hipcc does not know those registers are in flight and
+        // may move them once the K walk's register pressure starts (5.7: form (ii) pins order, not allocation)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         DSD_STAMP(3);
         __syncthreads();
@@ -378,23 +425,30 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         auto stage_wait = [&]() {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ITERS) : "memory");
 #pragma unroll
-            for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(sv[u])::"memory");   // consumers stay below the wait
+            for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(sv[0][u])::"memory");   // consumers stay below the wait
             if (STAGE == ST_FILM) {
 #pragma unroll
-                for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(fadd[u])::"memory");
+                for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(fadd[0][u])::"memory");
             }
         };
+        if constexpr (RES) {
+            // every chunk is in LDS already: the K walk is one uninterrupted run of k16 steps
+            DSD_CHUNK(0, 0)
+            if (NC > 1) { DSD_CHUNK(ITERS & 7, 1) }
+            if (NC > 2) { DSD_CHUNK(0, 2) }
+            if (NC > 3) { DSD_CHUNK(ITERS & 7, 3) }
+        } else
         for (int c = 0; c < NC; c += 2) {
             // even chunk from buffer 0; chunk c+1 (if any) lands in buffer 1 meanwhile
             const bool has1 = c + 1 < NC;
             DSD_STAMP2(0);
-            if (has1) stage_issue();
+            if (has1) stage_issue(I0{});
             DSD_CHUNK(0, 0)
             DSD_STAMP2(1);
             if (has1) {
                 stage_wait();
                 DSD_STAMP2(2);
-                stage_write(c + 1, lds + BUF);
+                stage_write(I0{}, lds + BUF);
             }
             DSD_STAMP2(3);
             __syncthreads();
@@ -402,13 +456,13 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
             if (has1) {
                 // odd chunk from buffer 1; chunk c+2 (if any) lands in buffer 0
                 const bool has2 = c + 2 < NC;
-                if (has2) stage_issue();
+                if (has2) stage_issue(I0{});
                 DSD_CHUNK(ITERS & 7, 1)
                 DSD_STAMP2(5);
                 if (has2) {
                     stage_wait();
                     DSD_STAMP2(6);
-                    stage_write(c + 2, lds);
+                    stage_write(I0{}, lds);
                 }
                 DSD_STAMP2(7);
                 __syncthreads();
@@ -711,14 +765,14 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
 // generic path: one resident chunk [KC][S]; fast path: two 64-row chunk buffers + the tile's FiLM vector / LN stats
 int gemm_lds_bytes(int KC, int S) { return KC * S * 4; }
 int gemm_fast_chunk_rows(int taps, int nb) { (void)taps; (void)nb; return 64; }
-int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb) {
+int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb, int resident) {
     (void)K;
-    return (2 * gemm_fast_chunk_rows(taps, nb) * S + (stage == ST_LN ? 2 * 32 * nb : 0)) * 4;
+    return ((resident ? 4 : 2) * gemm_fast_chunk_rows(taps, nb) * S + (stage == ST_LN ? 2 * 32 * nb : 0)) * 4;
 }
 
-template <int STAGE, int TAPS, int EPI, int NB, int SW>
+template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0>
 static hipError_t set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<STAGE, TAPS, EPI, NB, SW>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -731,15 +785,15 @@ void gemm_set_timing_events(hipEvent_t start, hipEvent_t stop) {
     g_ev_stop = stop;
 }
 
-template <int STAGE, int TAPS, int EPI, int NB, int SW>
+template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0>
 static hipError_t launch_one(const GemmP& p, int batch, hipStream_t st) {
     const int lds = p.lds_bytes;
     dim3 grid(batch * p.tiles_per_b * p.mtiles, 1, 1);
     if (g_ev_start && g_ev_stop)
-        hipExtLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW>), grid, dim3(256), lds, st, g_ev_start, g_ev_stop,
-                              0, p);
+        hipExtLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES>), grid, dim3(256), lds, st, g_ev_start,
+                              g_ev_stop, 0, p);
     else
-        hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW>), grid, dim3(256), lds, st, p);
+        hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES>), grid, dim3(256), lds, st, p);
     return hipGetLastError();
 }
 
@@ -753,6 +807,8 @@ bool gemm_has_fast(int taps, int nb, int S) {
 template <int STAGE, int TAPS, int EPI>
 static hipError_t dispatch(const GemmP& p, int nb, int fast, int batch, hipStream_t st) {
     if (nb == 1) {
+        if constexpr (TAPS == 1)        // resident variant: 1x1 GEMMs only (measured: no gain for the k=3 conv)
+            if (fast == 2 && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48, 1>(p, batch, st);
         if (fast && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48>(p, batch, st);
         if constexpr (TAPS == 3)
             if (fast && p.S == 80) return launch_one<STAGE, TAPS, EPI, 1, 80>(p, batch, st);
@@ -770,6 +826,8 @@ static hipError_t attr_all() {
     if ((e = set_attr<STAGE, TAPS, EPI, 1, 0>()) != hipSuccess) return e;
     if ((e = set_attr<STAGE, TAPS, EPI, 2, 0>()) != hipSuccess) return e;
     if ((e = set_attr<STAGE, TAPS, EPI, 1, 48>()) != hipSuccess) return e;
+    if constexpr (TAPS == 1)
+        if ((e = set_attr<STAGE, TAPS, EPI, 1, 48, 1>()) != hipSuccess) return e;
     if ((e = set_attr<STAGE, TAPS, EPI, 2, 80>()) != hipSuccess) return e;
     if constexpr (TAPS == 3) {
         if ((e = set_attr<STAGE, TAPS, EPI, 1, 80>()) != hipSuccess) return e;
