@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output directories (gpurun_out/, scratch) into the small committed summaries under
 profiles/.  Usage: python tools/summarize_profile.py <tag> <trace_dir> [<fetch_dir> <write_dir> [<mfma_dir>]]
+                   [--traffic <workload/B../T..> <dominant kernel name prefix>] [--bench <dir with bench*.json>]
+(`tools/collect_profiles.sh <tag> ...` produces gpurun_out/prof_<tag>/{trace,FETCH_SIZE,WRITE_SIZE,MFMA}.)
 
 FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  On gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e.
 it reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section): the summary stores the
@@ -15,8 +17,18 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag, trace = sys.argv[1], sys.argv[2]
-extra = sys.argv[3:]
+argv = sys.argv[1:]
+traffic_key = traffic_kernel = bench_dir = None
+if "--traffic" in argv:
+    i = argv.index("--traffic")
+    traffic_key, traffic_kernel = argv[i + 1], argv[i + 2]
+    del argv[i:i + 3]
+if "--bench" in argv:
+    i = argv.index("--bench")
+    bench_dir = argv[i + 1]
+    del argv[i:i + 2]
+tag, trace = argv[0], argv[1]
+extra = argv[2:]
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 
 
@@ -26,7 +38,7 @@ def one(pattern):
 
 
 def find(d, suffix):
-    hits = glob.glob(os.path.join(d, "*", "*" + suffix))
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
     assert hits, (d, suffix)
     return hits[0]
 
@@ -64,3 +76,33 @@ for k, e in summary["kernels"].items():
 out = os.path.join(ROOT, "profiles", f"{tag}_summary.json")
 json.dump(summary, open(out, "w"), indent=1)
 print(out)
+
+if bench_dir:
+    for name in ("bench.json", "bench_under_rocprof.json"):
+        src = os.path.join(bench_dir, name)
+        if os.path.exists(src):
+            line = [l for l in open(src) if l.startswith("{")][-1]
+            open(os.path.join(ROOT, "profiles", f"{tag}_{name}"), "w").write(line)
+if traffic_key:
+    hits = [k for k in summary["kernels"] if traffic_kernel in k]
+    assert len(hits) == 1, hits
+    e = summary["kernels"][hits[0]]
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    tj[traffic_key] = {
+        "kernel": hits[0], "traffic_bytes_per_launch": int(round(e["fabric_bytes_per_launch_corrected"])),
+        "fetch_size_kib_raw": e["FETCH_SIZE_mean"], "write_size_kib": e["WRITE_SIZE_mean"],
+        "rocprof_avg_ns": e["avg_ns"], "mfma_busy_frac_profiled": round(e.get("mfma_busy_frac_profiled", 0.0), 4),
+        "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x2 "
+                  "gfx950 correction; fabric-side counters, Infinity-Cache hits included)"}
+    if bench_dir and os.path.exists(os.path.join(bench_dir, "trace_split.txt")):
+        txt = open(os.path.join(bench_dir, "trace_split.txt")).read()
+        shutil.copy(os.path.join(bench_dir, "trace_split.txt"), os.path.join(ROOT, "profiles", f"{tag}_trace_split.txt"))
+        import re
+        g = re.search(r"graph replay: mean ([0-9.]+) ns", txt)
+        t = re.search(r"timing pass : mean ([0-9.]+) ns", txt)
+        if g and t:
+            tj[traffic_key]["rocprof_split_ns"] = None
+            tj[traffic_key]["rocprof_split_ns"] = {"graph_replay": float(g.group(1)), "timing_pass": float(t.group(1))}
+    json.dump(tj, open(tpath, "w"), indent=1)
+    print(tpath, traffic_key)
