@@ -46,10 +46,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(params, t_len, cycle):
+def cpu_baseline(kind, params, bargs, bsz, t_len):
     """The numpy oracle (a port of the reference algorithm, parity-pinned by tests/golden) timed on the host
-    cores of this box on a bounded sample of the same workload: NFE evaluations of the 20x256 WaveNet at
-    B=1, T=t_len - including, like the reference, the per-NFE conditioner projections."""
+    cores of this box on a bounded sample of the same workload: backbone evaluations (NFE) of the same network at
+    the same (B, T) - including, like the reference, the per-NFE conditioner projections.  10-15 s of CPU work."""
     import numpy as np
     from oracle import backbones as ob
     from diffsinger_amd import synth
@@ -60,20 +60,25 @@ def cpu_baseline(params, t_len, cycle):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))          # the GPU box gives one GPU a 16-core CPU share
     limiter = threadpool_limits(limits=cores)
-    x = synth.synth_normal((1, 1, 128, t_len), 1)
-    cond = synth.synth_normal((1, 256, t_len), 0)
-    t = np.array([500.0], np.float32)
-    ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=cycle)       # warm-up
+    x = synth.synth_normal((bsz, 1, 128, t_len), 1)
+    cond = synth.synth_normal((bsz, 256, t_len), 0)
+    t = np.full((bsz,), 500.0, np.float32)
+    if kind == "wavenet":
+        fwd = lambda: ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=bargs["dilation_cycle_length"])  # noqa: E731
+    else:
+        fwd = lambda: ob.lynxnet_forward(params, x, t, cond, activation=bargs["activation"],  # noqa: E731
+                                         strong_cond=bargs["strong_cond"])
+    fwd()       # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=cycle)
+        fwd()
         n += 1
         el = time.perf_counter() - t0
-        if el > 12.0 or n >= 40:
+        if el > 12.0 or n >= 1000:
             break
     limiter.unregister() if hasattr(limiter, "unregister") else None
-    return {"value": round(t_len * n / el, 1), "unit": "mel-frames/s per denoise step", "cores": int(cores),
-            "kind": "port", "sample": f"{n} backbone evaluations (NFE) of the same WaveNet at B=1, T={t_len}, "
+    return {"value": round(bsz * t_len * n / el, 1), "unit": "mel-frames/s per denoise step", "cores": int(cores),
+            "kind": "port", "sample": f"{n} backbone evaluations (NFE) of the same {kind} at B={bsz}, T={t_len}, "
                                       f"numpy fp32 oracle, {el:.1f} s"}
 
 
@@ -230,8 +235,8 @@ def main():
                               "algorithmic_flops_per_launch": kflops, "algorithmic_bytes_per_launch": kbytes,
                               "hbm_achieved_GBps": round(kbytes / sec / 1e9, 1) if sec > 0 else 0.0,
                               "hbm_frac": round(kbytes / sec / 1e9 / PEAK_HBM_GBPS, 5) if sec > 0 else 0.0}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind == "wavenet":
-        result["cpu_baseline"] = cpu_baseline(params, T, bargs["dilation_cycle_length"])
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(kind, params, bargs, B, T)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:
