@@ -136,47 +136,59 @@ hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const flo
 // 8 deep.  The per-(b,t) reduction over channels is a register loop + a 16-wave LDS combine.
 // ---------------------------------------------------------------------------------------------
 constexpr int LP_WAVES = 16;
-constexpr int LP_REG = 64;      // channels per wave kept in registers (C <= 1024); the rest is re-read
+constexpr int LP_REG = 64;      // channels per lane kept in registers; the rest is re-read
+// FT = frames per workgroup: 64 (one lane per frame, wave w takes channels w, w+16, ...) or 16 (a wave covers
+// 16 frames x 4 channel sub-groups: 4x the workgroups for small B*T, where 64-frame tiles leave most CUs idle -
+// B=1, T=1000 is 16 workgroups otherwise)
+template <int FT>
 __global__ __launch_bounds__(1024) void lynx_pre_kernel(float* __restrict__ x, float* __restrict__ xin,
                                                         const float* __restrict__ cp, long cp_bstride,
                                                         const float* __restrict__ film, int film_cstride,
                                                         int film_col0, int film_colb, long bstride, int rstride, int C,
                                                         int T, int strong, float* __restrict__ stats, int ts,
                                                         float eps) {
-    __shared__ float red[LP_WAVES][64];
-    __shared__ float mean_s[64];
+    constexpr int CG = 64 / FT;                  // channel sub-groups inside a wave
+    constexpr int NPART = LP_WAVES * CG;         // partial sums per frame
+    __shared__ float red[NPART][FT];
+    __shared__ float mean_s[FT];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + lane;
+    const int f = lane % FT, part = wave * CG + lane / FT;
+    const int t = blockIdx.x * FT + f;
     float* xb = x + (long)b * bstride + t;
     float* xi = xin ? xin + (long)b * bstride + t : nullptr;
     const float* cpb = cp ? cp + (long)b * cp_bstride + t : nullptr;
-    const int nper = (C + LP_WAVES - 1) / LP_WAVES;         // channels per wave
+    const int nper = (C + NPART - 1) / NPART;               // channels per lane
     float keep[LP_REG];
     float sum = 0.f;
 #pragma unroll
     for (int i0 = 0; i0 < LP_REG; i0 += 8) {
-        float a[8], c8[8];
+        if (i0 < nper) {                                     // uniform: skips the unused part of the register window
+            float a[8], c8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = min(wave + (i0 + j) * LP_WAVES, C - 1);        // clamped: branch-free loads
-            a[j] = xb[(long)c * rstride];
-            c8[j] = cpb ? cpb[(long)c * rstride] : 0.f;
-        }
+            for (int j = 0; j < 8; ++j) {
+                const int c = min(part + (i0 + j) * NPART, C - 1);        // clamped: branch-free loads
+                a[j] = xb[(long)c * rstride];
+                c8[j] = cpb ? cpb[(long)c * rstride] : 0.f;
+            }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = wave + (i0 + j) * LP_WAVES;
-            const bool ok = (i0 + j) < nper && c < C;
-            float v = a[j] + c8[j];
-            if (ok && cpb && strong) xb[(long)c * rstride] = v;
-            if (film && ok) v = v + film[(long)c * film_cstride + film_col0 + b * film_colb];
-            if (ok && xi) xi[(long)c * rstride] = v;
-            keep[i0 + j] = ok ? v : 0.f;
-            sum += ok ? v : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int c = part + (i0 + j) * NPART;
+                const bool ok = (i0 + j) < nper && c < C;
+                float v = a[j] + c8[j];
+                if (ok && cpb && strong) xb[(long)c * rstride] = v;
+                if (film && ok) v = v + film[(long)c * film_cstride + film_col0 + b * film_colb];
+                if (ok && xi) xi[(long)c * rstride] = v;
+                keep[i0 + j] = ok ? v : 0.f;
+                sum += ok ? v : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) keep[i0 + j] = 0.f;
         }
     }
-    for (int i = LP_REG; i < nper; ++i) {                    // C > 1024: beyond the register window
-        const int c = wave + i * LP_WAVES;
+    for (int i = LP_REG; i < nper; ++i) {                    // beyond the register window
+        const int c = part + i * NPART;
         if (c < C) {
             float v = xb[(long)c * rstride];
             if (cpb) {
@@ -188,38 +200,38 @@ __global__ __launch_bounds__(1024) void lynx_pre_kernel(float* __restrict__ x, f
             sum += v;
         }
     }
-    red[wave][lane] = sum;
+    red[part][f] = sum;
     __syncthreads();
-    if (wave == 0) {
+    if (part == 0) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < LP_WAVES; ++w) s += red[w][lane];
-        mean_s[lane] = s / (float)C;
+        for (int w = 0; w < NPART; ++w) s += red[w][f];
+        mean_s[f] = s / (float)C;
     }
     __syncthreads();
-    const float mean = mean_s[lane];
+    const float mean = mean_s[f];
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < LP_REG; ++i) {
-        const bool ok = i < nper && (wave + i * LP_WAVES) < C;
+        const bool ok = i < nper && (part + i * NPART) < C;
         const float dlt = keep[i] - mean;
         sq += ok ? dlt * dlt : 0.f;
     }
     const float* rd = xi ? xi : xb;
     for (int i = LP_REG; i < nper; ++i) {
-        const int c = wave + i * LP_WAVES;
+        const int c = part + i * NPART;
         if (c < C) {
             const float dlt = rd[(long)c * rstride] - mean;
             sq += dlt * dlt;
         }
     }
     __syncthreads();
-    red[wave][lane] = sq;
+    red[part][f] = sq;
     __syncthreads();
-    if (wave == 0 && t < ts) {
+    if (part == 0 && t < ts) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < LP_WAVES; ++w) s += red[w][lane];
+        for (int w = 0; w < NPART; ++w) s += red[w][f];
         float* st = stats + (long)b * 2 * ts;
         st[t] = mean;
         st[ts + t] = 1.f / sqrtf(s / (float)C + eps);
@@ -229,9 +241,16 @@ __global__ __launch_bounds__(1024) void lynx_pre_kernel(float* __restrict__ x, f
 hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstride, const float* film,
                            int film_cstride, int film_col0, int film_colb, long bstride, int rstride, int C, int B,
                            int T, int strong, float* stats, int ts, float eps, hipStream_t stream) {
-    dim3 grid(round_up(T, 64) / 64, B);
-    hipLaunchKernelGGL(lynx_pre_kernel, grid, dim3(64 * LP_WAVES), 0, stream, x, xin, cp, cp_bstride, film,
-                       film_cstride, film_col0, film_colb, bstride, rstride, C, T, strong, stats, ts, eps);
+    const int tiles64 = round_up(T, 64) / 64;
+    if ((long)tiles64 * B >= 256) {
+        dim3 grid(tiles64, B);
+        hipLaunchKernelGGL(lynx_pre_kernel<64>, grid, dim3(64 * LP_WAVES), 0, stream, x, xin, cp, cp_bstride, film,
+                           film_cstride, film_col0, film_colb, bstride, rstride, C, T, strong, stats, ts, eps);
+    } else {
+        dim3 grid(round_up(T, 16) / 16, B);
+        hipLaunchKernelGGL(lynx_pre_kernel<16>, grid, dim3(64 * LP_WAVES), 0, stream, x, xin, cp, cp_bstride, film,
+                           film_cstride, film_col0, film_colb, bstride, rstride, C, T, strong, stats, ts, eps);
+    }
     return hipGetLastError();
 }
 
