@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1000, help="mel frames per utterance (T)")
-    ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100"])
+    ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100", "acoustic_default"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -117,14 +117,38 @@ def main():
                                       activation="PReLU", strong_cond=True)
         hp = dict(diff_accelerator="ddim", diff_speedup=10, K_step_infer=1000)
         nfe, wname = 100, "LYNXNet 6x1024 (k31, strong_cond), DDIM 1000->100"
-    hparams.clear()
-    hparams.update(hidden_size=256, schedule_type="linear", use_shallow_diffusion=False, infer=False, **hp)
     shapes = synth.backbone_param_shapes(kind, 128, 1, hidden_size=256, **bargs)
     params = synth.synth_state_dict(shapes, seed=42)
-    d = GaussianDiffusion(128, 1, timesteps=1000, k_step=1000, backbone_type=kind, backbone_args=bargs,
-                          spec_min=[-12.0], spec_max=[0.0])
-    d.denoise_fn.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
-    d = d.to(device).eval()
+    hparams.clear()
+    acoustic = None
+    if args.workload == "acoustic_default":
+        # configs/acoustic.yaml:61-99 of the reference fork: shallow reflow (euler, 20 steps from t = 0.4) on the
+        # LYNXNet above, started from the ConvNeXt aux decoder's mel - DiffSingerAcoustic.forward after the encoder
+        from diffsinger_amd.toplevel import AcousticDecoder
+        aux_args = dict(num_channels=512, num_layers=6, kernel_size=7, dropout_rate=0.1)
+        hparams.update(hidden_size=256, schedule_type="linear", infer=False, use_shallow_diffusion=True,
+                       diffusion_type="reflow", T_start=0.4, T_start_infer=0.4, time_scale_factor=1000,
+                       sampling_algorithm="euler", sampling_steps=20, timesteps=1000, K_step=400, K_step_infer=400,
+                       backbone_type=kind, backbone_args=bargs, spec_min=[-12.0], spec_max=[0.0],
+                       shallow_diffusion_args=dict(aux_decoder_arch="convnext", aux_decoder_args=aux_args,
+                                                   val_gt_start=False))
+        acoustic = AcousticDecoder(128)
+        sd = dict(acoustic.state_dict())
+        sd.update({"diffusion.velocity_fn." + k: torch.from_numpy(v) for k, v in params.items()})
+        aux_sd = synth.synth_state_dict(synth.convnext_param_shapes(256, 128, prefix="aux_decoder.decoder."), seed=43)
+        sd.update({k: torch.from_numpy(v) for k, v in aux_sd.items()})
+        acoustic.load_state_dict(sd, strict=True)
+        acoustic = acoustic.to(device).eval()
+        d = acoustic.diffusion
+        d.denoise_fn = d.velocity_fn          # one name for the backbone below
+        nfe, wname = 20, ("ConvNeXt aux decoder 6x512 -> shallow reflow euler 20 (t 0.4 -> 1) on LYNXNet 6x1024 "
+                          "(configs/acoustic.yaml of the reference fork)")
+    else:
+        hparams.update(hidden_size=256, schedule_type="linear", use_shallow_diffusion=False, infer=False, **hp)
+        d = GaussianDiffusion(128, 1, timesteps=1000, k_step=1000, backbone_type=kind, backbone_args=bargs,
+                              spec_min=[-12.0], spec_max=[0.0])
+        d.denoise_fn.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        d = d.to(device).eval()
     d.use_graph = not args.no_graph
 
     n_utt = world * B
@@ -135,12 +159,19 @@ def main():
     noise = sharding.utterance_noise((1, 128, T), mine, seed=1, device=device)      # x_T, resident before timing
     cond_local = cond_all if not use_dist else None
 
+    mel2ph = torch.ones((len(mine), T), dtype=torch.long, device=device)
+
+    def run(c):
+        if acoustic is not None:
+            with torch.no_grad():       # as DiffSingerAcousticInfer.forward_model does (ds_acoustic.py:136)
+                return acoustic(c, mel2ph, infer=True, noise=noise).diff_out
+        return d(c, infer=True, noise=noise)
+
     def step():
         if not use_dist:
-            return d(cond_local, infer=True, noise=noise)
+            return run(cond_local)
         c = sharding.scatter_condition(cond_all, n_utt, T, 256, device)
-        mel = d(c, infer=True, noise=noise)
-        return sharding.gather_mels(mel, n_utt)
+        return sharding.gather_mels(run(c), n_utt)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -192,7 +223,7 @@ def main():
         h = d.denoise_fn._handle
         _lib.check(h, _lib.lib().dsd_kernel_timing(h, 1), "dsd_kernel_timing")
         t_pass = time.perf_counter()
-        d(cond_all[:len(mine)] if use_dist else cond_local, infer=True, noise=noise)
+        run(cond_all[:len(mine)] if use_dist else cond_local)
         torch.cuda.synchronize(device)
         t_pass = (time.perf_counter() - t_pass) * 1e3
         raw_ms, empty_ms, n = C.c_double(), C.c_double(), C.c_int64()
