@@ -253,8 +253,14 @@ def main():
             pass
         sec = mean_ms.value / 1e3
         ach = kflops / sec / 1e12 if sec > 0 else 0.0
+        meas = None
+        try:   # sustained v_mfma_f32_16x16x4_f32 rate measured on an MI355X of this pool (tools/peak_bench.hip)
+            meas = json.load(open(os.path.join(ROOT, "profiles", "r01_measured_peaks.json")))["mfma_f32_16x16x4_tflops"]
+        except Exception:
+            pass
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                              "peak_measured": meas, "frac_of_measured": None if not meas else round(ach / meas, 4),
                               "traffic_source": traffic_src,
                               "kernel": kname, "launches_timed": int(n.value),
                               "avg_launch_us": round(mean_ms.value * 1e3, 3), "timing_pass_ms": round(t_pass, 2),
