@@ -582,7 +582,18 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     c.nb = wg64 >= 512 ? 2 : 1;
     // a k > 3 conv keeps all input channels resident (generic path): 64-frame tiles only while that fits in LDS
     if (g.taps > 3 && (size_t)g.K * (64 + 2 * round_up((g.taps / 2) * dil, 4) + 16) * 4 > 150 * 1024) c.nb = 1;
-    const int BN = 32 * c.nb;
+    // narrow tiles (64 rows x 16 frames, c.nb == 0): when 32-frame tiles would put at most ~1.5 workgroups on a CU,
+    // twice as many half-size workgroups share each SIMD between two waves and halve the latency of a lone one
+    if (c.nb == 1) {
+        static const int force = getenv("DSD_NARROW") ? atoi(getenv("DSD_NARROW")) : -1;      // diagnostic override
+        const long wg32 = (long)batch * ((T + 31) / 32) * mtiles;
+        int s16 = 16 + 2 * p.HL;
+        while (s16 % 32 != 16) s16 += 4;
+        const bool ok = (g.taps == 1 || g.taps == 3) && g.K % 64 == 0 && g.Kreal == g.K && stage != ST_LN &&
+                        epi != EP_SWIGLU && gemm_has_fast(g.taps, 0, s16);
+        if (ok && (force == 1 || (force != 0 && wg32 <= 192))) c.nb = 0;
+    }
+    const int BN = c.nb == 0 ? 16 : 32 * c.nb;
     p.tiles_per_b = (T + BN - 1) / BN;
     int S = BN + 2 * p.HL;
     while (S % 32 != 16) S += 4;
@@ -599,7 +610,7 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     c.fast = (g.taps == 1 || g.taps == 3) && (g.K % gemm_fast_chunk_rows(g.taps, c.nb) == 0) && (g.Kreal == g.K) &&
              gemm_has_fast(g.taps, c.nb, S);
     // small grids (one workgroup per CU, one wave per SIMD): all <= 4 chunks resident, no barrier in the K walk
-    if (c.fast && c.nb == 1 && g.K <= 256 && g.taps == 1) c.fast = 2;
+    if (c.fast && c.nb <= 1 && g.K <= 256 && g.taps == 1) c.fast = 2;
     p.lds_bytes = c.fast ? gemm_lds_bytes_fast(S, stage, g.taps, g.K, c.nb, c.fast == 2) : gemm_lds_bytes(p.KC, S);
     if (epi == EP_GATE || epi == EP_RESSKIP)        // the LDS-staged epilogue tile [64][BN + 4]
         p.lds_bytes = std::max(p.lds_bytes, 64 * (BN + 4) * 4);

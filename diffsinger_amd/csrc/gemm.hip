@@ -114,14 +114,23 @@ __device__ __forceinline__ void ring_load_s(f32x4& dst, unsigned voff, unsigned 
 // base + immediate), the K walk is linear in groups of 8 steps (K % 128 == 0 and no tap/chunk mixing), so a
 // k16 step is 8*NB MFMAs + 4*NB ds_read + 2 loads + 1 counted wait and nothing else.  SW == 0: generic
 // instantiation (runtime S, any K multiple of 16, whole chunk staged then walked) for every other shape.
-template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0>
-__global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(const GemmP p) {
+// WN = waves along time: 2 (waves as 2 rows x 2 frames, each 2 row blocks x NB frame blocks, tile 64 x 32*NB) or
+// 1 (waves as 4 rows x 1, each ONE 16-row block x NB frame blocks, tile 64 rows x 16*NB frames).  WN = 1, NB = 1 is
+// the "narrow" 16-frame tile for grids that would otherwise leave most CUs without a workgroup (T <= ~750 at B = 1:
+// 17.4 -> 12.8 ms per 50-NFE utterance at T = 256).  WN = 1, NB = 2 - the same 64 x 32 tile with no weight block
+// streamed by two waves - was measured too: halving the weight traffic does not pay for doubling each wave's LDS
+// fragment reads (17.5 -> 18.8 ms at B = 1), so 32- and 64-frame tiles keep the 2 x 2 layout.
+template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2>
+__global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int BN = 32 * NB;
+    static_assert(WN == 2 || (WN == 1 && SW > 0 && EPI != EP_SWIGLU && STAGE != ST_LN), "4x1 wave layout: fast path only");
+    constexpr int WM = 4 / WN;                  // waves along rows
+    constexpr int MB = 4 / WM;                  // 16-row blocks per wave
+    constexpr int BN = 16 * NB * WN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (SGPR)
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // 1-D grid with an XCD-aware remap (speed only, bijective for any grid size): the dispatcher deals
     // workgroups round-robin over the 8 XCDs, so blocks b and b+8 share an L2.  Work items are numbered with the
     // row tile fastest, and XCD k takes a CONTIGUOUS range of them: the workgroups that stage the SAME activation
@@ -141,9 +150,9 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
     const int HL = p.HL;
     DSD_STAMP(0);
 
-    f32x4 acc[2][NB];
+    f32x4 acc[MB][NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -165,7 +174,9 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
     constexpr int EQ = BN / 4;                      // float4 per output row
     constexpr int EROWS = 256 / EQ;                 // rows covered per pass of the 256 threads
     const int e_c4 = tid % EQ, e_r0 = tid / EQ;
-    constexpr int NPRE = (EPI == EP_GATE) ? 2 * (32 / EROWS) : (EPI == EP_RESSKIP ? 64 / EROWS : 1);
+    constexpr int NGATE = (32 + EROWS - 1) / EROWS;         // gate epilogue: channel passes per thread (32 pairs / tile)
+    constexpr int NRES = (64 + EROWS - 1) / EROWS;          // res/skip epilogue: row passes per thread
+    constexpr int NPRE = (EPI == EP_GATE) ? 2 * NGATE : (EPI == EP_RESSKIP ? NRES : 1);
     f32x4 pre[NPRE];
     auto epi_prefetch = [&]() {
         const long colo = (long)b * (EPI == EP_GATE ? p.aux_bstride : p.o_bstride) + t0 + e_c4 * 4;
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
             // pointer itself through a dependent vector load)
             const unsigned long long xa = (unsigned long long)p.x, sa = (unsigned long long)p.skip;
 #pragma unroll
-            for (int k = 0; k < 64 / EROWS; ++k) {
+            for (int k = 0; k < NRES; ++k) {
                 const int row = min(mtile * 64 + e_r0 + k * EROWS, p.M - 1);
                 const bool is_res = row < p.C;
                 const float* base = (const float*)(is_res ? xa : sa);
@@ -184,8 +195,8 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         }
         if (EPI == EP_GATE) {
 #pragma unroll
-            for (int k = 0; k < 32 / EROWS; ++k) {
-                const int ch = min(mtile * 32 + e_r0 + k * EROWS, p.C - 1);
+            for (int k = 0; k < NGATE; ++k) {
+                const int ch = min(mtile * 32 + min(e_r0 + k * EROWS, 31), p.C - 1);
                 ring_load(pre[2 * k], p.aux + colo + (long)ch * p.aux_rstride);
                 ring_load(pre[2 * k + 1], p.aux + colo + (long)(ch + p.C) * p.aux_rstride);
             }
@@ -200,12 +211,13 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
                 acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], bv[j][n], acc[0][n], 0, 0, 0);
-                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], bv[j][n], acc[1][n], 0, 0, 0);
+                if constexpr (MB == 2)
+                    acc[MB - 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], bv[j][n], acc[MB - 1][n], 0, 0, 0);
             }
     };
     // Weights of this wave: two 16-row blocks, each a LINEAR stream of 1 KiB fragment blocks in exactly the
     // order the K walk consumes them ([64-channel chunk][tap][k16 in chunk], dsd_finalize_weights packs it so).
-    const unsigned long long a0s = (unsigned long long)(p.A + (long)(mtile * 4 + wm * 2) * a_blk);
+    const unsigned long long a0s = (unsigned long long)(p.A + (long)(mtile * 4 + wm * MB) * a_blk);
     const unsigned long long a1s = a0s + (unsigned long long)a_blk * 4;
 
     if constexpr (SW > 0) {
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         const unsigned voffA = lane * 16, voffB = lane * 16 + 4096, voffC = lane * 16 + 8192;
 #define DSD_RING_PRO(U)                                                              \
     ring_load_s<((U) & 3) * 1024>(ra0[U], (U) < 4 ? voffA : voffB, an0);             \
-    ring_load_s<((U) & 3) * 1024>(ra1[U], (U) < 4 ? voffA : voffB, an1);
+    if constexpr (MB == 2) ring_load_s<((U) & 3) * 1024>(ra1[U], (U) < 4 ? voffA : voffB, an1);
         DSD_RING_PRO(0) DSD_RING_PRO(1) DSD_RING_PRO(2) DSD_RING_PRO(3)
         DSD_RING_PRO(4) DSD_RING_PRO(5) DSD_RING_PRO(6) DSD_RING_PRO(7)
 #undef DSD_RING_PRO
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         // Staged activations, FiLM scalars and epilogue operands have landed once all but the 16 ring loads are
         // retired (in-order return).  The LN statistics (compiler load, older than all of them) are covered too.
         {
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * MB) : "memory");
 #pragma unroll
             for (int q = 0; q < NSV; ++q)
 #pragma unroll
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         DSD_STAMP(4);
 
         // ---- B fragment addressing: one VGPR base per tap, everything else is an immediate ----
-        const float* bt0 = lds + lrow * SW + wn * (16 * NB) + lcol + HL - (TAPS == 3 ? p.dil : 0);
+        const float* bt0 = lds + lrow * SW + wn * (16 * NB) + lcol + HL - (TAPS == 3 ? p.dil : 0);   // wn == 0 when WN == 1
         const float* bt1 = bt0 + p.dil;
         const float* bt2 = bt1 + p.dil;
         auto read_b = [&](float (&bv)[4][NB], auto ic, auto bufc) {
@@ -399,14 +411,15 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         };
         // one k16 step: wait for ring slot, read the next step's B, MFMAs, refill the slot with the block 8 steps on
 #define DSD_STEP(I, SLOT, BUFI)                                                                        \
-    ring_wait<2 * (PF - 1)>(ra0[SLOT], ra1[SLOT]);                                                      \
+    ring_wait<MB * (PF - 1)>(ra0[SLOT], ra1[SLOT]);                                                     \
     if constexpr ((I) + 1 < ITERS)                                                                      \
         read_b(bq[((I) + 1) & 1], std::integral_constant<int, ((I) + 1) % ITERS>{},                     \
                std::integral_constant<int, BUFI>{});                                                    \
     mfma_step(ra0[SLOT], ra1[SLOT], bq[(I) & 1]);                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     ring_load_s<((I) & 3) * 1024>(ra0[SLOT], (I) < 4 ? voffA : ((I) < 8 ? voffB : voffC), an0);         \
-    ring_load_s<((I) & 3) * 1024>(ra1[SLOT], (I) < 4 ? voffA : ((I) < 8 ? voffB : voffC), an1);
+    if constexpr (MB == 2)                                                                              \
+        ring_load_s<((I) & 3) * 1024>(ra1[SLOT], (I) < 4 ? voffA : ((I) < 8 ? voffB : voffC), an1);
 #define DSD_CHUNK(S0, BUFI)                                                                            \
     read_b(bq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, BUFI>{});               \
     DSD_STEP(0, ((S0) + 0) & 7, BUFI) DSD_STEP(1, ((S0) + 1) & 7, BUFI)                                 \
@@ -423,7 +436,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
     an1 += ITERS * 1024;
         // after a chunk's ITERS steps exactly 2*ITERS refills are younger than the staged chunk's loads
         auto stage_wait = [&]() {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ITERS) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MB * ITERS) : "memory");
 #pragma unroll
             for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(sv[0][u])::"memory");   // consumers stay below the wait
             if (STAGE == ST_FILM) {
@@ -623,21 +636,24 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         constexpr int ES = BN + 4;
         __syncthreads();                               // all waves are done reading the staged activations
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int n = 0; n < NB; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // EP_GATE: rows [0,32) = gate, [32,64) = filter of channel wm*16 + rq + r;  else packed row
-                    const int trow = (EPI == EP_GATE) ? mb * 32 + wm * 16 + rq + r : (wm * 2 + mb) * 16 + rq + r;
+                    // packed 16-row block j of the tile; EP_GATE: even j = gate, odd j = filter of channels (j/2)*16..
+                    // -> tile rows [0,32) = gate, [32,64) = filter;  else the packed row itself
+                    const int j = wm * MB + mb;
+                    const int trow = (EPI == EP_GATE) ? (j & 1) * 32 + (j >> 1) * 16 + rq + r : j * 16 + rq + r;
                     lds[trow * ES + wn * (16 * NB) + n * 16 + lcol] = acc[mb][n][r];
                 }
         __syncthreads();
         const long colo = (long)b * p.o_bstride + t0 + e_c4 * 4;
         if constexpr (EPI == EP_GATE) {
 #pragma unroll
-            for (int k = 0; k < 32 / EROWS; ++k) {
+            for (int k = 0; k < NGATE; ++k) {
                 const int cw = e_r0 + k * EROWS;           // channel within the workgroup's 32
+                if (cw >= 32) continue;                    // narrow tiles: half the threads carry a channel
                 const int ch = mtile * 32 + cw;
                 const f32x4 g = *reinterpret_cast<const f32x4*>(&lds[cw * ES + e_c4 * 4]);
                 const f32x4 f = *reinterpret_cast<const f32x4*>(&lds[(32 + cw) * ES + e_c4 * 4]);
@@ -649,7 +665,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 64 / EROWS; ++k) {
+            for (int k = 0; k < NRES; ++k) {
                 const int pr = e_r0 + k * EROWS;
                 const int row = mtile * 64 + pr;
                 const f32x4 a4 = *reinterpret_cast<const f32x4*>(&lds[pr * ES + e_c4 * 4]);
@@ -680,14 +696,14 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
                 const int ch = chb + r;
                 if (ch < p.C) {
                     const float u0 = acc[0][n][r] + p.bias[ch];
-                    const float u1 = acc[1][n][r] + p.bias[ch + p.C];
+                    const float u1 = acc[MB - 1][n][r] + p.bias[ch + p.C];
                     p.out[(long)b * p.o_bstride + (long)ch * p.o_rstride + t] = u0 * (u1 * sigmoid_f(u1));   // out * silu(gate)
                 }
             }
         } else {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const int rowb = mtile * 64 + (wm * 2 + mb) * 16 + rq;
+            for (int mb = 0; mb < MB; ++mb) {
+                const int rowb = mtile * 64 + (wm * MB + mb) * 16 + rq;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = rowb + r;
@@ -708,17 +724,17 @@ __global__ __launch_bounds__(256, (SW > 0 && NB == 2) ? 3 : 1) void gemm_kernel(
         // Solver update fused into the last GEMM: dst_o = sum_k coef_k * src_k.  Terms are the OUTER loop and the
         // wave's 8*NB output elements the inner, unrolled one: the loads of one term are issued back to back
         // (branch-free: clamped frame index + select), so a term costs one memory latency, not one per element.
-        constexpr int E = 2 * NB * 4;
+        constexpr int E = MB * NB * 4;
         float ev[E];
         int erow[E], et[E];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int n = 0; n < NB; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int e = (mb * NB + n) * 4 + r;
-                    const int row = mtile * 64 + (wm * 2 + mb) * 16 + rq + r;
+                    const int row = mtile * 64 + (wm * MB + mb) * 16 + rq + r;
                     erow[e] = row;
                     et[e] = t0 + wn * (16 * NB) + n * 16 + lcol;
                     ev[e] = acc[mb][n][r] + ((p.bias && row < p.M) ? p.bias[min(row, p.M - 1)] : 0.f);
@@ -767,12 +783,12 @@ int gemm_lds_bytes(int KC, int S) { return KC * S * 4; }
 int gemm_fast_chunk_rows(int taps, int nb) { (void)taps; (void)nb; return 64; }
 int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb, int resident) {
     (void)K;
-    return ((resident ? 4 : 2) * gemm_fast_chunk_rows(taps, nb) * S + (stage == ST_LN ? 2 * 32 * nb : 0)) * 4;
+    return ((resident ? 4 : 2) * gemm_fast_chunk_rows(taps, nb) * S + (stage == ST_LN ? 2 * 32 * (nb ? nb : 1) : 0)) * 4;
 }
 
-template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0>
+template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2>
 static hipError_t set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -785,27 +801,39 @@ void gemm_set_timing_events(hipEvent_t start, hipEvent_t stop) {
     g_ev_stop = stop;
 }
 
-template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0>
+template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2>
 static hipError_t launch_one(const GemmP& p, int batch, hipStream_t st) {
     const int lds = p.lds_bytes;
     dim3 grid(batch * p.tiles_per_b * p.mtiles, 1, 1);
     if (g_ev_start && g_ev_stop)
-        hipExtLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES>), grid, dim3(256), lds, st, g_ev_start,
+        hipExtLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN>), grid, dim3(256), lds, st, g_ev_start,
                               g_ev_stop, 0, p);
     else
-        hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES>), grid, dim3(256), lds, st, p);
+        hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN>), grid, dim3(256), lds, st, p);
     return hipGetLastError();
 }
 
 // fast instantiations exist for S = 48 / 80 (32-frame tiles) and 80 / 112 (64-frame tiles); 1x1 GEMMs have
 // no halo, so only the smaller stride of each tile width occurs for them
 bool gemm_has_fast(int taps, int nb, int S) {
+    if (nb == 0) return (taps == 1 && S == 16) || (taps == 3 && S == 48);     // narrow tiles (16 frames)
     if (nb == 1) return S == 48 || (taps == 3 && S == 80);
     return S == 80 || (taps == 3 && S == 112);
 }
 
 template <int STAGE, int TAPS, int EPI>
 static hipError_t dispatch(const GemmP& p, int nb, int fast, int batch, hipStream_t st) {
+    if constexpr (STAGE != ST_LN && EPI != EP_SWIGLU) {
+        if (nb == 0) {      // narrow tiles: fast path only (the host never asks for them otherwise)
+            if constexpr (TAPS == 1) {
+                if (fast == 2 && p.S == 16) return launch_one<STAGE, TAPS, EPI, 1, 16, 1, 1>(p, batch, st);
+                if (fast && p.S == 16) return launch_one<STAGE, TAPS, EPI, 1, 16, 0, 1>(p, batch, st);
+            } else {
+                if (fast && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48, 0, 1>(p, batch, st);
+            }
+            return hipErrorInvalidValue;
+        }
+    }
     if (nb == 1) {
         if constexpr (TAPS == 1)        // resident variant: 1x1 GEMMs only (measured: no gain for the k=3 conv)
             if (fast == 2 && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48, 1>(p, batch, st);
@@ -823,6 +851,14 @@ static hipError_t dispatch(const GemmP& p, int nb, int fast, int batch, hipStrea
 template <int STAGE, int TAPS, int EPI>
 static hipError_t attr_all() {
     hipError_t e;
+    if constexpr (STAGE != ST_LN && EPI != EP_SWIGLU) {
+        if constexpr (TAPS == 1) {
+            if ((e = set_attr<STAGE, TAPS, EPI, 1, 16, 1, 1>()) != hipSuccess) return e;
+            if ((e = set_attr<STAGE, TAPS, EPI, 1, 16, 0, 1>()) != hipSuccess) return e;
+        } else {
+            if ((e = set_attr<STAGE, TAPS, EPI, 1, 48, 0, 1>()) != hipSuccess) return e;
+        }
+    }
     if ((e = set_attr<STAGE, TAPS, EPI, 1, 0>()) != hipSuccess) return e;
     if ((e = set_attr<STAGE, TAPS, EPI, 2, 0>()) != hipSuccess) return e;
     if ((e = set_attr<STAGE, TAPS, EPI, 1, 48>()) != hipSuccess) return e;
