@@ -262,21 +262,27 @@ hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstrid
 // ---------------------------------------------------------------------------------------------
 constexpr int DW_TT = 256;
 constexpr int DW_MAXK = 63;
+// KS > 0: kernel size known at compile time - the lane's (KS + 3)-float input window is pulled from LDS with
+// aligned 16-byte reads into registers once and the taps run on registers (k = 31: 9 LDS reads per lane instead
+// of 124); KS == 0: any odd k <= 63, taps read from LDS one by one.
+template <int KS>
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                      long bstride, int rstride, int C, int T,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
-                                                     int ksz, int act, const float* __restrict__ prelu) {
-    __shared__ float row[4][DW_TT + 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                     int ksz_rt, int act, const float* __restrict__ prelu) {
+    __shared__ __attribute__((aligned(16))) float row[4][DW_TT + 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
-    const int c = blockIdx.y * 4 + wave;
+    const int c = blockIdx.y * 4 + wave;                 // wave-uniform: weights and bias are scalar loads
     const int t0 = blockIdx.x * DW_TT;
+    const int ksz = KS > 0 ? KS : ksz_rt;
     const int pad = ksz >> 1;
     if (c < C) {
         const float* s = src + (long)b * bstride + (long)c * rstride;
-        for (int i = lane; i < DW_TT + ksz - 1; i += 64) {
+        for (int i = lane; i < DW_TT + 64; i += 64) {
             const int t = t0 - pad + i;
-            row[wave][i] = (t >= 0 && t < T) ? s[t] : 0.f;
+            row[wave][i] = (t >= 0 && t < T && i < DW_TT + ksz - 1) ? s[t] : 0.f;
         }
     }
     __syncthreads();
@@ -287,10 +293,26 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ s
     for (int e = 0; e < 4; ++e) acc[e] = bv;
     const float* wc = w + (long)c * ksz;
     const float* r = &row[wave][lane * 4];
-    for (int j = 0; j < ksz; ++j) {
-        const float wj = wc[j];
+    if constexpr (KS > 0) {
+        constexpr int NW = (KS + 3 + 3) / 4 * 4;         // window, rounded up to whole float4s (stays inside the row)
+        float win[NW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += wj * r[j + e];
+        for (int i = 0; i < NW; i += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&r[i]);
+            win[i] = v[0]; win[i + 1] = v[1]; win[i + 2] = v[2]; win[i + 3] = v[3];
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const float wj = wc[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += wj * win[j + e];
+        }
+    } else {
+        for (int j = 0; j < ksz; ++j) {
+            const float wj = wc[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += wj * r[j + e];
+        }
     }
     float* d = dst + (long)b * bstride + (long)c * rstride + t0 + lane * 4;
     const float slope = (act == 0) ? prelu[c] : 0.f;
@@ -310,10 +332,17 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ s
 hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T,
                          const float* w, const float* bias, int ksz, int act, const float* prelu,
                          hipStream_t stream) {
-    if (ksz > DW_MAXK) return hipErrorInvalidValue;
+    if (ksz > DW_MAXK || ksz < 1 || ksz % 2 == 0) return hipErrorInvalidValue;
     dim3 grid((T + DW_TT - 1) / DW_TT, (C + 3) / 4, B);
-    hipLaunchKernelGGL(dwconv_kernel, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, w, bias, ksz, act,
-                       prelu);
+    if (ksz == 31)
+        hipLaunchKernelGGL(dwconv_kernel<31>, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, w, bias, ksz,
+                           act, prelu);
+    else if (ksz == 7)
+        hipLaunchKernelGGL(dwconv_kernel<7>, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, w, bias, ksz,
+                           act, prelu);
+    else
+        hipLaunchKernelGGL(dwconv_kernel<0>, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, w, bias, ksz,
+                           act, prelu);
     return hipGetLastError();
 }
 
