@@ -579,7 +579,8 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     // tile width: 64 frames when that still fills the chip twice over, else 32
     const int mtiles = g.pairC > 0 ? (g.pairC + 31) / 32 : (g.M + 63) / 64;
     const long wg64 = (long)batch * ((T + 63) / 64) * mtiles;
-    c.nb = wg64 >= 512 ? 2 : 1;
+    static const long nb2_min = getenv("DSD_NB2_MIN_WG") ? atol(getenv("DSD_NB2_MIN_WG")) : 512;     // diagnostic override
+    c.nb = wg64 >= nb2_min ? 2 : 1;
     // a k > 3 conv keeps all input channels resident (generic path): 64-frame tiles only while that fits in LDS
     if (g.taps > 3 && (size_t)g.K * (64 + 2 * round_up((g.taps / 2) * dil, 4) + 16) * 4 > 150 * 1024) c.nb = 1;
     // narrow tiles (64 rows x 16 frames, c.nb == 0): when 32-frame tiles would put at most ~1.5 workgroups on a CU,

@@ -37,6 +37,30 @@ __global__ __launch_bounds__(256) void stream_copy(const f32x4* __restrict__ src
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// Cost of a device-wide barrier among co-resident workgroups (one atomic counter, agent-scope release/acquire):
+// what a persistent multi-layer kernel would pay INSTEAD of a kernel boundary.  Every workgroup reaches every
+// barrier and the spin has a wall-clock deadline, so the grid always drains.
+__global__ __launch_bounds__(256) void grid_barrier_loop(unsigned* counter, float* data, int rounds, int nwg) {
+    const long long t0 = wall_clock64();
+    float v = data[blockIdx.x * 256 + threadIdx.x];
+    for (int r = 0; r < rounds; ++r) {
+        data[blockIdx.x * 256 + threadIdx.x] = v + 1.f;             // something to release
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            atomicAdd(counter, 1u);
+            const unsigned target = (unsigned)(r + 1) * (unsigned)nwg;
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
+                   wall_clock64() - t0 < 50000000LL /* 0.5 s of the 100 MHz clock */)
+                __builtin_amdgcn_s_sleep(1);
+            __threadfence();
+        }
+        __syncthreads();
+        v = data[((blockIdx.x + 1) % nwg) * 256 + threadIdx.x];     // something to acquire from a neighbour
+    }
+    data[blockIdx.x * 256 + threadIdx.x] = v;
+}
+
 int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -87,7 +111,32 @@ int main() {
         const double g2 = 2.0 * bytes / (ms * 1e-3) / 1e9;
         if (rep > 0 && g2 > best_memcpy) best_memcpy = g2;
     }
-    printf("{\"device\": \"%s\", \"compute_units\": %d, \"clock_mhz\": %d, \"mfma_f32_16x16x4_tflops\": %.1f, "
+    // ---- grid barrier ----
+    double barrier_us[2] = {0, 0};
+    {
+        unsigned* counter;
+        float* data;
+        CHECK(hipMalloc(&counter, 4));
+        CHECK(hipMalloc(&data, (size_t)cus * 2 * 256 * sizeof(float)));
+        CHECK(hipMemset(data, 0, (size_t)cus * 2 * 256 * sizeof(float)));
+        for (int k = 0; k < 2; ++k) {
+            const int nwg = cus * (k + 1), rounds = 200;
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CHECK(hipMemset(counter, 0, 4));
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(grid_barrier_loop, dim3(nwg), dim3(256), 0, 0, counter, data, rounds, nwg);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            barrier_us[k] = best * 1e3 / rounds;
+        }
+    }
+    printf("{\"grid_barrier_us_1wg_per_cu\": %.2f, \"grid_barrier_us_2wg_per_cu\": %.2f, ", barrier_us[0], barrier_us[1]);
+    printf("\"device\": \"%s\", \"compute_units\": %d, \"clock_mhz\": %d, \"mfma_f32_16x16x4_tflops\": %.1f, "
            "\"stream_copy_GBps\": %.0f, \"hipMemcpyDtoD_GBps\": %.0f, \"note\": \"read+write bytes counted; best of 5\"}\n",
            prop.name, cus, prop.clockRate / 1000, best_tf, best_gbs, best_memcpy);
     return 0;
