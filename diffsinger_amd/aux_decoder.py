@@ -68,6 +68,8 @@ class ConvNeXtDecoder(_NativeBackbone):
             x = x.contiguous()
             sb, st, sh = x.stride()
         out = torch.empty((b, t, self.out_dims), device=x.device, dtype=torch.float32)
+        if b == 0 or t == 0:                # empty batch / zero frames: nothing to launch
+            return out
         ptr = lambda v: C.c_void_p(0 if v is None else v.data_ptr())  # noqa: E731
         if out_scale is not None:
             out_scale = out_scale.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()

@@ -154,10 +154,13 @@ class _NativeBackbone(nn.Module):
                 "torch.no_grad(); training (p_losses, ddpm.py:212-219) stays on the reference modules.")
         if spec.dim() != 4 or spec.shape[1] != self.n_feats or spec.shape[2] != self.in_dims:
             raise ValueError(f"spec must be [B, {self.n_feats}, {self.in_dims}, T], got {tuple(spec.shape)}")
-        handle = self.prepare_cond(cond)
         b, _, _, t_len = spec.shape
         if cond.shape[0] != b or cond.shape[2] != t_len:
             raise ValueError(f"cond {tuple(cond.shape)} does not match spec {tuple(spec.shape)}")
+        if spec.numel() == 0:               # empty batch / zero frames: nothing to launch
+            self.native_handle(spec.device)
+            return torch.empty_like(spec, dtype=torch.float32)
+        handle = self.prepare_cond(cond)
         x = spec.detach().to(torch.float32).contiguous()
         step = diffusion_step.detach().reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
         if step.numel() not in (1, b):

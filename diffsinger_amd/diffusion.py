@@ -56,9 +56,18 @@ class _SamplerMixin:
     def _run_program(self, entry, cond, x_init, noise=None, out=None, transpose=True, scale=None, shift=None):
         prog, cprog, _keep = entry
         net = self._backbone()
-        handle = net.prepare_cond(cond)
         x_init = x_init.to(torch.float32).contiguous()
         b, f, m, t = x_init.shape
+        if b == 0 or t == 0:
+            # empty batch / zero frames: the reference's loop runs on empty tensors and returns an empty mel; there
+            # is nothing to launch (still a device tensor: a CPU input raises in prepare_cond as everywhere else)
+            if x_init.device.type != "cuda":
+                net.native_handle(x_init.device)
+            if out is not None:
+                return out
+            shape = ((b, t, m) if f == 1 else (b, f, t, m)) if transpose else (b, f, m, t)
+            return torch.empty(shape, device=x_init.device, dtype=torch.float32)
+        handle = net.prepare_cond(cond)
         if out is None:
             if transpose:
                 out = torch.empty((b, t, m) if f == 1 else (b, f, t, m), device=x_init.device, dtype=torch.float32)

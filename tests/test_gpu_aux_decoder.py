@@ -128,3 +128,26 @@ def test_acoustic_decoder_glue_vs_golden(tag):
     with pytest.raises(NotImplementedError):
         model(cond, dev(g["glue_mel2ph"]), infer=False)
     set_hp()
+
+
+def test_empty_inputs_return_empty_outputs():
+    """B == 0 or T == 0: like the reference's torch modules, an empty input gives an empty output (no launch)."""
+    from diffsinger_amd.diffusion import GaussianDiffusion, RectifiedFlow
+    from gpu_util import make_backbone
+    set_hp(diff_accelerator="ddim", diff_speedup=10, K_step_infer=1000)
+    args = dict(num_layers=2, num_channels=64, dilation_cycle_length=2)
+    d = GaussianDiffusion(32, 1, backbone_type="wavenet", backbone_args=args, spec_min=[-12.0], spec_max=[0.0]).cuda().eval()
+    r = RectifiedFlow(32, 1, backbone_type="wavenet", backbone_args=args, spec_min=[-12.0], spec_max=[0.0]).cuda().eval()
+    for shape in ((0, 17, 256), (2, 0, 256)):
+        cond = torch.zeros(shape, device="cuda")
+        with torch.no_grad():
+            assert tuple(d(cond, infer=True).shape) == (shape[0], shape[1], 32)
+            assert tuple(r(cond, infer=True).shape) == (shape[0], shape[1], 32)
+    net, _ = make_backbone("wavenet", 32, 1, args, 3)
+    with torch.no_grad():
+        y = net(torch.zeros(0, 1, 32, 9).cuda(), torch.zeros(0).cuda(), torch.zeros(0, 256, 9).cuda())
+    assert tuple(y.shape) == (0, 1, 32, 9)
+    a, _ = make_adaptor(256, 32, 64, 2, 7, 71, [-12.0], [0.0])
+    with torch.no_grad():
+        assert tuple(a(torch.zeros(0, 5, 256).cuda(), infer=True).shape) == (0, 5, 32)
+        assert tuple(a(torch.zeros(3, 0, 256).cuda(), infer=True).shape) == (3, 0, 32)
