@@ -102,6 +102,49 @@ def convnext_param_shapes(in_dims, out_dims, num_channels=512, num_layers=6, ker
     return shapes
 
 
+def fs2_acoustic_param_shapes(vocab_size, hidden_size=256, enc_layers=4, num_heads=2, ffn_kernel_size=3,
+                              num_spk=0, num_lang=0, variances=(), key_shift=False, speed=False):
+    """state_dict of modules/fastspeech/acoustic_encoder.py:14-63 (FastSpeech2Acoustic) in its rotary-embedding
+    configuration (`use_rope: true`): tts_modules.py:353-383, common_layers.py:120-234.  The rotary frequency
+    table is an (untrained) nn.Parameter of the shared RotaryEmbedding and shows up once per layer."""
+    h = hidden_size
+    shapes = OrderedDict()
+    shapes["txt_embed.weight"] = (vocab_size, h)
+    if num_lang:
+        shapes["lang_embed.weight"] = (num_lang + 1, h)
+    shapes["dur_embed.weight"] = (h, 1)
+    shapes["dur_embed.bias"] = (h,)
+    for l in range(enc_layers):
+        p = f"encoder.layers.{l}.op."
+        shapes[p + "layer_norm1.weight"] = (h,)
+        shapes[p + "layer_norm1.bias"] = (h,)
+        shapes[p + "self_attn.in_proj.weight"] = (3 * h, h)
+        shapes[p + "self_attn.out_proj.weight"] = (h, h)
+        shapes[p + "self_attn.rotary_embed.freqs"] = (h // num_heads // 2,)
+        shapes[p + "layer_norm2.weight"] = (h,)
+        shapes[p + "layer_norm2.bias"] = (h,)
+        shapes[p + "ffn.ffn_1.weight"] = (4 * h, h, ffn_kernel_size)
+        shapes[p + "ffn.ffn_1.bias"] = (4 * h,)
+        shapes[p + "ffn.ffn_2.weight"] = (h, 4 * h)
+        shapes[p + "ffn.ffn_2.bias"] = (h,)
+    shapes["encoder.layer_norm.weight"] = (h,)
+    shapes["encoder.layer_norm.bias"] = (h,)
+    shapes["pitch_embed.weight"] = (h, 1)
+    shapes["pitch_embed.bias"] = (h,)
+    for v in variances:
+        shapes[f"variance_embeds.{v}.weight"] = (h, 1)
+        shapes[f"variance_embeds.{v}.bias"] = (h,)
+    if key_shift:
+        shapes["key_shift_embed.weight"] = (h, 1)
+        shapes["key_shift_embed.bias"] = (h,)
+    if speed:
+        shapes["speed_embed.weight"] = (h, 1)
+        shapes["speed_embed.bias"] = (h,)
+    if num_spk:
+        shapes["spk_embed.weight"] = (num_spk, h)
+    return shapes
+
+
 def backbone_param_shapes(kind, in_dims, n_feats, hidden_size=256, **args):
     if kind == "wavenet":
         return wavenet_param_shapes(in_dims, n_feats, num_layers=args.get("num_layers", 20),
@@ -124,11 +167,19 @@ def synth_state_dict(shapes, seed=42):
     for name, shape in shapes.items():
         z = rng.standard_normal(shape, dtype=np.float32)
         leaf = name.rsplit(".", 1)[-1]
-        is_ln = name.startswith("norm.") or ".convmodule.net.0." in name or ".norm." in name
+        is_ln = (name.startswith("norm.") or ".convmodule.net.0." in name or ".norm." in name
+                 or ".layer_norm" in name)
         if is_ln and leaf == "weight":
             w = 1.0 + 0.1 * z
         elif ".convmodule.net.5." in name:
             w = 0.25 + 0.05 * z
+        elif leaf == "freqs":                      # rotary table: the reference's own values (rotary_embedding_torch.py:119)
+            d = 2 * shape[0]
+            w = (1.0 / (10000.0 ** (np.arange(0, d, 2, dtype=np.float32) / np.float32(d)))).astype(np.float32)
+        elif name.endswith("_embed.weight") and len(shape) == 2 and shape[1] > 1 and "variance" not in name:
+            w = z / np.sqrt(np.float32(shape[1]))      # embedding tables: N(0, H^-0.5) (common_layers.py:24)
+            if name.startswith(("txt_embed", "lang_embed")):
+                w[0] = 0.0                             # padding_idx row
         elif leaf == "gamma":                      # ConvNeXt layer scale (reference init 1e-6; O(1) here so it matters)
             w = 0.5 + 0.1 * z
         elif leaf == "bias":

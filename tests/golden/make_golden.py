@@ -489,8 +489,88 @@ def g7_aux_decoder():
     save("g7_aux_decoder", **out)
 
 
+# --------------------------------------------------------------------------- G8: FastSpeech2 acoustic encoder -> condition
+ENC_CASES = {
+    # tag: (vocab, extra hparams, synth kwargs, B, T_txt, T_mel, weight seed)
+    "default": (60, dict(), dict(), 1, 23, 180, 80),
+    "padded": (60, dict(), dict(), 3, 17, 96, 81),
+    "full": (45, dict(use_spk_id=True, num_spk=3, use_lang_id=True, num_lang=2, use_energy_embed=True,
+                      use_breathiness_embed=True, use_key_shift_embed=True, use_speed_embed=True),
+             dict(num_spk=3, num_lang=2, variances=("energy", "breathiness"), key_shift=True, speed=True), 2, 12, 70, 82),
+    "k9": (30, dict(enc_ffn_kernel_size=9, enc_layers=2, hidden_size=128), dict(ffn_kernel_size=9, enc_layers=2,
+                                                                               hidden_size=128), 2, 9, 40, 83),
+}
+
+
+def enc_inputs(tag, vocab, bsz, t_txt, t_mel, seed, n_lang=0, n_spk=0):
+    """Deterministic phoneme tokens / durations / f0 (shared with the tests through the fixture)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tokens = np.zeros((bsz, t_txt), dtype=np.int64)
+    mel2ph = np.zeros((bsz, t_mel), dtype=np.int64)
+    for b in range(bsz):
+        n_tok = t_txt if b == 0 else int(rng.integers(max(2, t_txt // 2), t_txt + 1))
+        tokens[b, :n_tok] = rng.integers(1, vocab, n_tok)
+        n_frames = t_mel if b == 0 else int(rng.integers(max(n_tok, t_mel // 2), t_mel + 1))
+        cuts = np.sort(rng.choice(np.arange(1, n_frames), n_tok - 1, replace=False))
+        durs = np.diff(np.concatenate([[0], cuts, [n_frames]]))
+        mel2ph[b, :n_frames] = np.repeat(np.arange(1, n_tok + 1), durs)
+    f0 = (220.0 * 2.0 ** rng.uniform(-1, 1, (bsz, t_mel))).astype(np.float32)
+    f0[mel2ph == 0] = 0.0
+    extra = dict(
+        key_shift=rng.uniform(-3, 3, (bsz, t_mel)).astype(np.float32),
+        speed=rng.uniform(0.5, 2, (bsz, t_mel)).astype(np.float32),
+        energy=rng.uniform(-60, -10, (bsz, t_mel)).astype(np.float32),
+        breathiness=rng.uniform(-80, -20, (bsz, t_mel)).astype(np.float32),
+        languages=(rng.integers(1, n_lang + 1, (bsz, t_txt)) * (tokens > 0)).astype(np.int64) if n_lang else None,
+        spk_embed_id=rng.integers(0, n_spk, (bsz,)).astype(np.int64) if n_spk else None,
+    )
+    return tokens, mel2ph, f0, extra
+
+
+def g8_encoder():
+    from modules.fastspeech.acoustic_encoder import FastSpeech2Acoustic  # (reference)
+    out = {}
+    for tag, (vocab, hp, skw, bsz, t_txt, t_mel, wseed) in ENC_CASES.items():
+        base = dict(hidden_size=256, enc_layers=4, enc_ffn_kernel_size=3, ffn_act="gelu", dropout=0.1, num_heads=2,
+                    use_pos_embed=True, rel_pos=True, use_rope=True, use_spk_id=False, num_spk=1, use_lang_id=False,
+                    num_lang=1)
+        base.update(hp)
+        set_hp(**base)
+        m = FastSpeech2Acoustic(vocab)
+        kw = dict(hidden_size=base["hidden_size"], enc_layers=base["enc_layers"], num_heads=base["num_heads"],
+                  ffn_kernel_size=base["enc_ffn_kernel_size"])
+        kw.update(skw)
+        sd = synth.synth_state_dict(synth.fs2_acoustic_param_shapes(vocab, **kw), seed=wseed)
+        m.load_state_dict({k: to_t(v) for k, v in sd.items()}, strict=True)
+        m.eval()
+        tokens, mel2ph, f0, ex = enc_inputs(tag, vocab, bsz, t_txt, t_mel, wseed + 1000,
+                                            n_lang=skw.get("num_lang", 0), n_spk=skw.get("num_spk", 0))
+        kwargs = {}
+        if skw.get("key_shift"):
+            kwargs["key_shift"] = to_t(ex["key_shift"])
+        if skw.get("speed"):
+            kwargs["speed"] = to_t(ex["speed"])
+        for v in skw.get("variances", ()):
+            kwargs[v] = to_t(ex[v])
+        if skw.get("num_lang"):
+            kwargs["languages"] = to_t(ex["languages"])
+        if skw.get("num_spk"):
+            kwargs["spk_embed_id"] = to_t(ex["spk_embed_id"])
+        with torch.no_grad():
+            cond = m(to_t(tokens), to_t(mel2ph), to_t(f0), **kwargs).numpy()
+        out[f"{tag}_meta"] = np.array([vocab, base["hidden_size"], base["enc_layers"], base["num_heads"],
+                                       base["enc_ffn_kernel_size"], bsz, t_txt, t_mel, wseed], dtype=np.int64)
+        out[f"{tag}_tokens"], out[f"{tag}_mel2ph"], out[f"{tag}_f0"] = tokens, mel2ph, f0
+        for k in ("key_shift", "speed", "energy", "breathiness", "languages", "spk_embed_id"):
+            if k in kwargs or (k in ("energy", "breathiness") and k in skw.get("variances", ())):
+                out[f"{tag}_{k}"] = ex[k]
+        out[f"{tag}_cond"] = cond[:, ::2] if tag in ("default", "padded") else cond      # every other frame: half the bytes
+        print(f"  enc {tag}: cond {cond.shape} absmax={np.abs(cond).max():.3f}")
+    save("g8_encoder", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -503,3 +583,5 @@ if __name__ == "__main__":
         g6_wrappers()
     if "g7" in which:
         g7_aux_decoder()
+    if "g8" in which:
+        g8_encoder()

@@ -342,3 +342,39 @@ def test_g7_acoustic_glue(tag):
     assert rel_err(aux, g[f"glue_{tag}_aux"]) < 2e-5
     assert rel_err(mel, g[f"glue_{tag}_mel"]) < 2e-4
     assert np.all(mel[0, 41:] == 0) and np.all(mel[1, 48:] == 0)
+
+
+# --------------------------------------------------------------------------- G8 (section 8(f) rank 2)
+from oracle import encoder as oe  # noqa: E402
+
+ENC_SYNTH = {
+    "default": dict(), "padded": dict(),
+    "full": dict(num_spk=3, num_lang=2, variances=("energy", "breathiness"), key_shift=True, speed=True),
+    "k9": dict(),
+}
+
+
+def enc_case(g, tag):
+    vocab, hidden, layers, heads, ks, bsz, t_txt, t_mel, wseed = (int(v) for v in g[f"{tag}_meta"])
+    kw = dict(hidden_size=hidden, enc_layers=layers, num_heads=heads, ffn_kernel_size=ks)
+    kw.update(ENC_SYNTH[tag])
+    params = synth.synth_state_dict(synth.fs2_acoustic_param_shapes(vocab, **kw), seed=wseed)
+    extra = {k: g[f"{tag}_{k}"] for k in ("key_shift", "speed", "energy", "breathiness", "languages", "spk_embed_id")
+             if f"{tag}_{k}" in g}
+    return params, heads, g[f"{tag}_tokens"], g[f"{tag}_mel2ph"], g[f"{tag}_f0"], extra
+
+
+@pytest.mark.parametrize("tag", sorted(ENC_SYNTH))
+def test_g8_fs2_acoustic_encoder(tag):
+    """FastSpeech2Acoustic (rotary configuration) restatement vs the reference; tolerance 2e-5 of the output range
+    (4 transformer layers: LayerNorm, RoPE attention, k-tap FFN; padded batches; every optional embedding)."""
+    g = load("g8_encoder")
+    params, heads, tokens, mel2ph, f0, extra = enc_case(g, tag)
+    cond = oe.fs2_acoustic_forward(params, tokens, mel2ph, f0, num_heads=heads, **extra)
+    want = g[f"{tag}_cond"]
+    if tag in ("default", "padded"):
+        cond = cond[:, ::2]
+    assert cond.shape == want.shape
+    assert rel_err(cond, want) < 2e-5
+    if tag == "padded":       # the case really has padded tokens and padded frames
+        assert (tokens == 0).any() and (mel2ph == 0).any()
