@@ -24,14 +24,28 @@ ACT_IDS = {"PReLU": 0, "SiLU": 1, "ReLU": 2}
 EXPORTS = [
     "dsd_api_version", "dsd_create", "dsd_destroy", "dsd_last_error", "dsd_load_weight",
     "dsd_finalize_weights", "dsd_prepare_cond", "dsd_denoise", "dsd_sample", "dsd_get_stats",
-    "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_aux_decode",
+    "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode",
 ]
+EMBED_FLAGS = {"energy": 1, "breathiness": 2, "voicing": 4, "tension": 8, "key_shift": 16, "speed": 32}
 
 
 class DsdConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "backbone", "in_dims", "n_feats", "num_layers", "num_channels", "hidden_size",
         "dilation_cycle_length", "expansion_factor", "kernel_size", "activation", "strong_cond", "device")]
+
+
+class DsdEncoderConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("vocab_size", C.c_int32), ("hidden_size", C.c_int32),
+                ("enc_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_kernel_size", C.c_int32),
+                ("num_spk", C.c_int32), ("num_lang", C.c_int32), ("embed_flags", C.c_uint32), ("device", C.c_int32)]
+
+
+class DsdEncodeExtras(C.Structure):
+    _fields_ = [("languages", C.c_void_p), ("spk_embed_id", C.c_void_p), ("spk_mix_embed", C.c_void_p),
+                ("spk_mix_bstride", C.c_int64), ("spk_mix_tstride", C.c_int64), ("key_shift", C.c_void_p),
+                ("speed", C.c_void_p), ("energy", C.c_void_p), ("breathiness", C.c_void_p), ("voicing", C.c_void_p),
+                ("tension", C.c_void_p)]
 
 
 class DsdTerm(C.Structure):
@@ -86,12 +100,14 @@ def _load():
     lib.dsd_denoise.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.dsd_sample.argtypes = [vp, C.POINTER(DsdProgram), vp, vp, vp, vp, vp, C.c_uint32, vp]
     lib.dsd_aux_decode.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, vp, vp, vp]
+    lib.dsd_encoder_create.argtypes = [C.POINTER(DsdEncoderConfig), C.POINTER(vp)]
+    lib.dsd_encode.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.POINTER(DsdEncodeExtras), vp, vp]
     lib.dsd_get_stats.argtypes = [vp, C.POINTER(DsdStats)]
     lib.dsd_kernel_timing.argtypes = [vp, i32]
     lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     for name in EXPORTS:
         getattr(lib, name)
-    if lib.dsd_api_version() != 2:
+    if lib.dsd_api_version() != 3:
         raise NativeLibraryError("libdsdenoise.so API version mismatch")
     return lib
 

@@ -59,6 +59,16 @@ struct dsd_handle {
     std::vector<PackedGemm> g_pw1, g_pw2;            // LYNXNet per layer
     std::vector<size_t> dw_w, dw_b, dw_prelu;        // LYNXNet / ConvNeXt depthwise params (float offsets)
     PackedGemm g_ain, g_aout;                        // ConvNeXt aux decoder: dense k-tap in/out convs
+    // FastSpeech2 acoustic encoder
+    dsd_encoder_config ecfg;
+    std::vector<PackedGemm> g_qkv, g_oproj, g_ffn1, g_ffn2;
+    std::vector<size_t> e_ln1g, e_ln1b, e_ln2g, e_ln2b;
+    size_t e_lng = 0, e_lnb = 0, e_txt = 0, e_lang = SIZE_MAX, e_durw = 0, e_durb = 0, e_freqs = 0, e_spk = SIZE_MAX;
+    size_t e_linw[7], e_linb[7];                     // pitch, energy, breathiness, voicing, tension, key shift, speed
+    int eL = 0, eLs = 0, eB = 0;
+    float *e_x = nullptr, *e_y = nullptr, *e_qkv = nullptr, *e_mid = nullptr, *e_nonpad = nullptr;
+    int* e_dur = nullptr;
+    float* e_arena = nullptr;
     size_t freqs_off = 0;
     int emb_act = ACT_MISH;
 
@@ -117,6 +127,50 @@ inline int L_of(const dsd_handle* h) { return h->cfg.num_layers; }
 inline int inner_of(const dsd_handle* h) { return h->cfg.num_channels * h->cfg.expansion_factor; }
 inline bool is_wavenet(const dsd_handle* h) { return h->cfg.backbone == DSD_BACKBONE_WAVENET; }
 inline bool is_aux(const dsd_handle* h) { return h->cfg.backbone == DSD_AUX_CONVNEXT; }
+inline bool is_enc(const dsd_handle* h) { return h->cfg.backbone == DSD_ENC_FS2_ACOUSTIC; }
+
+const char* const kLinNames[7] = {"pitch_embed", "variance_embeds.energy", "variance_embeds.breathiness",
+                                  "variance_embeds.voicing", "variance_embeds.tension", "key_shift_embed", "speed_embed"};
+inline bool lin_present(const dsd_encoder_config& e, int k) {
+    if (k == 0) return true;
+    const uint32_t bit[7] = {0, DSD_EMBED_ENERGY, DSD_EMBED_BREATHINESS, DSD_EMBED_VOICING, DSD_EMBED_TENSION,
+                             DSD_EMBED_KEY_SHIFT, DSD_EMBED_SPEED};
+    return (e.embed_flags & bit[k]) != 0;
+}
+
+// FastSpeech2Acoustic state_dict (acoustic_encoder.py:15-63; tts_modules.py:353-383; common_layers.py:120-234)
+std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_enc(const dsd_encoder_config& e) {
+    std::vector<std::pair<std::string, std::vector<int64_t>>> v;
+    const int64_t H = e.hidden_size, ks = e.ffn_kernel_size;
+    auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
+    add("txt_embed.weight", {e.vocab_size, H});
+    if (e.num_lang > 0) add("lang_embed.weight", {e.num_lang + 1, H});
+    add("dur_embed.weight", {H, 1});
+    add("dur_embed.bias", {H});
+    for (int l = 0; l < e.enc_layers; ++l) {
+        const std::string p = "encoder.layers." + std::to_string(l) + ".op.";
+        add(p + "layer_norm1.weight", {H});
+        add(p + "layer_norm1.bias", {H});
+        add(p + "self_attn.in_proj.weight", {3 * H, H});
+        add(p + "self_attn.out_proj.weight", {H, H});
+        add(p + "self_attn.rotary_embed.freqs", {H / e.num_heads / 2});
+        add(p + "layer_norm2.weight", {H});
+        add(p + "layer_norm2.bias", {H});
+        add(p + "ffn.ffn_1.weight", {4 * H, H, ks});
+        add(p + "ffn.ffn_1.bias", {4 * H});
+        add(p + "ffn.ffn_2.weight", {H, 4 * H});
+        add(p + "ffn.ffn_2.bias", {H});
+    }
+    add("encoder.layer_norm.weight", {H});
+    add("encoder.layer_norm.bias", {H});
+    for (int k = 0; k < 7; ++k)
+        if (lin_present(e, k)) {
+            add(std::string(kLinNames[k]) + ".weight", {H, 1});
+            add(std::string(kLinNames[k]) + ".bias", {H});
+        }
+    if (e.num_spk > 0) add("spk_embed.weight", {e.num_spk, H});
+    return v;
+}
 inline int cp_rows(const dsd_handle* h) { return is_wavenet(h) ? 2 * C_of(h) : C_of(h); }
 
 // ------------------------------------------------------------------------------------------
@@ -304,8 +358,65 @@ int build_packed_aux(dsd_handle* h) {
     return DSD_OK;
 }
 
+// FastSpeech2 acoustic encoder: 1x1 / k-tap GEMM operands in fragment order, everything else copied as is.
+// The FFN's `x * kernel_size ** -0.5` (common_layers.py:146) is folded into ffn_1's weights and bias.
+int build_packed_enc(dsd_handle* h) {
+    const dsd_encoder_config& e = h->ecfg;
+    const int H = e.hidden_size, L = e.enc_layers, ks = e.ffn_kernel_size;
+    h->blob_host.clear();
+    auto copy_vec = [&](const std::string& name) {
+        const auto& d = W(h, name).data;
+        const size_t off = blob_reserve(h, d.size());
+        memcpy(h->blob_host.data() + off, d.data(), sizeof(float) * d.size());
+        return off;
+    };
+    h->e_txt = copy_vec("txt_embed.weight");
+    h->e_lang = e.num_lang > 0 ? copy_vec("lang_embed.weight") : SIZE_MAX;
+    h->e_durw = copy_vec("dur_embed.weight");
+    h->e_durb = copy_vec("dur_embed.bias");
+    h->e_freqs = copy_vec("encoder.layers.0.op.self_attn.rotary_embed.freqs");     // one shared RotaryEmbedding
+    h->e_lng = copy_vec("encoder.layer_norm.weight");
+    h->e_lnb = copy_vec("encoder.layer_norm.bias");
+    h->e_spk = e.num_spk > 0 ? copy_vec("spk_embed.weight") : SIZE_MAX;
+    for (int k = 0; k < 7; ++k) {
+        h->e_linw[k] = h->e_linb[k] = SIZE_MAX;
+        if (lin_present(e, k)) {
+            h->e_linw[k] = copy_vec(std::string(kLinNames[k]) + ".weight");
+            h->e_linb[k] = copy_vec(std::string(kLinNames[k]) + ".bias");
+        }
+    }
+    h->g_qkv.resize(L); h->g_oproj.resize(L); h->g_ffn1.resize(L); h->g_ffn2.resize(L);
+    h->e_ln1g.resize(L); h->e_ln1b.resize(L); h->e_ln2g.resize(L); h->e_ln2b.resize(L);
+    const double fscale = 1.0 / sqrt((double)ks);
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "encoder.layers." + std::to_string(l) + ".op.";
+        h->e_ln1g[l] = copy_vec(p + "layer_norm1.weight");
+        h->e_ln1b[l] = copy_vec(p + "layer_norm1.bias");
+        h->e_ln2g[l] = copy_vec(p + "layer_norm2.weight");
+        h->e_ln2b[l] = copy_vec(p + "layer_norm2.bias");
+        auto lin = [&](const std::string& name, int cols) {
+            const HostTensor* t = &W(h, name);
+            return WGet([t, cols](int r, int k, int) { return (double)t->data[(size_t)r * cols + k]; });
+        };
+        h->g_qkv[l] = pack_gemm(h, 3 * H, H, 1, 0, lin(p + "self_attn.in_proj.weight", H), nullptr);
+        h->g_oproj[l] = pack_gemm(h, H, H, 1, 0, lin(p + "self_attn.out_proj.weight", H), nullptr);
+        const HostTensor* w1 = &W(h, p + "ffn.ffn_1.weight");
+        const HostTensor* b1 = &W(h, p + "ffn.ffn_1.bias");
+        // float multiply like the reference (x * k**-0.5 in fp32), then packed
+        const float fs = (float)fscale;
+        WGet w1f = [w1, H, ks, fs](int r, int k, int tap) { return (double)(w1->data[((size_t)r * H + k) * ks + tap] * fs); };
+        std::function<double(int)> b1f = [b1, fs](int i) { return (double)(b1->data[i] * fs); };
+        h->g_ffn1[l] = pack_gemm(h, 4 * H, H, ks, 0, w1f, &b1f);
+        const HostTensor* b2 = &W(h, p + "ffn.ffn_2.bias");
+        std::function<double(int)> b2f = [b2](int i) { return (double)b2->data[i]; };
+        h->g_ffn2[l] = pack_gemm(h, H, 4 * H, 1, 0, lin(p + "ffn.ffn_2.weight", 4 * H), &b2f);
+    }
+    return DSD_OK;
+}
+
 int build_packed(dsd_handle* h) {
     if (is_aux(h)) return build_packed_aux(h);
+    if (is_enc(h)) return build_packed_enc(h);
     const dsd_config& c = h->cfg;
     const int C = c.num_channels, M = FM_of(h), H = c.hidden_size, L = c.num_layers;
     h->blob_host.clear();
@@ -553,7 +664,7 @@ struct GemmCall {
 };
 
 GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b_bstride, int b_rstride, int batch,
-                   int T, int stage, int epi, int dil) {
+                   int T, int stage, int epi, int dil, bool generic_only = false) {
     GemmCall c;
     memset(&c.p, 0, sizeof(c.p));
     GemmP& p = c.p;
@@ -592,7 +703,7 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
         while (s16 % 32 != 16) s16 += 4;
         const bool ok = (g.taps == 1 || g.taps == 3) && g.K % 64 == 0 && g.Kreal == g.K && stage != ST_LN &&
                         epi != EP_SWIGLU && gemm_has_fast(g.taps, 0, s16);
-        if (ok && (force == 1 || (force != 0 && wg32 <= 192))) c.nb = 0;
+        if (ok && !generic_only && (force == 1 || (force != 0 && wg32 <= 192))) c.nb = 0;
     }
     const int BN = c.nb == 0 ? 16 : 32 * c.nb;
     p.tiles_per_b = (T + BN - 1) / BN;
@@ -608,8 +719,8 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     while ((1 << p.lpr_shift) < w4) ++p.lpr_shift;
     // a k=3 conv keeps all its input channels resident on the generic path (its walk does not mix taps and chunks)
     if (g.taps > 1) p.KC = g.K;
-    c.fast = (g.taps == 1 || g.taps == 3) && (g.K % gemm_fast_chunk_rows(g.taps, c.nb) == 0) && (g.Kreal == g.K) &&
-             gemm_has_fast(g.taps, c.nb, S);
+    c.fast = !generic_only && (g.taps == 1 || g.taps == 3) && (g.K % gemm_fast_chunk_rows(g.taps, c.nb) == 0) &&
+             (g.Kreal == g.K) && gemm_has_fast(g.taps, c.nb, S);
     // small grids (one workgroup per CU, one wave per SIMD): all <= 4 chunks resident, no barrier in the K walk
     if (c.fast && c.nb <= 1 && g.K <= 256 && g.taps == 1) c.fast = 2;
     p.lds_bytes = c.fast ? gemm_lds_bytes_fast(S, stage, g.taps, g.K, c.nb, c.fast == 2) : gemm_lds_bytes(p.KC, S);
@@ -824,6 +935,7 @@ void dsd_destroy(dsd_handle* h) {
     if (h->arena) (void)hipFree(h->arena);
     if (h->state) (void)hipFree(h->state);
     if (h->emb_arena) (void)hipFree(h->emb_arena);
+    if (h->e_arena) (void)hipFree(h->e_arena);
     delete h;
 }
 
@@ -833,12 +945,12 @@ int dsd_load_weight(dsd_handle* h, const char* name, const float* data, const in
     const std::string n(name);
     std::vector<int64_t> shp(shape, shape + ndim);
     bool found = false;
-    if (n == "diffusion_embedding.freqs") {
+    if (n == "diffusion_embedding.freqs" && !is_enc(h)) {
         if (ndim != 1 || shp[0] != h->cfg.num_channels / 2)
             return fail(h, DSD_EINVAL, "diffusion_embedding.freqs must have shape [%d]", h->cfg.num_channels / 2);
         found = true;
     } else {
-        for (auto& e : expected_params(h->cfg)) {
+        for (auto& e : (is_enc(h) ? expected_params_enc(h->ecfg) : expected_params(h->cfg))) {
             if (e.first != n) continue;
             if (e.second != shp) {
                 std::string want, got;
@@ -870,7 +982,7 @@ int dsd_load_weight(dsd_handle* h, const char* name, const float* data, const in
 int dsd_finalize_weights(dsd_handle* h) {
     if (!h) return DSD_EINVAL;
     std::string missing;
-    for (auto& e : expected_params(h->cfg))
+    for (auto& e : (is_enc(h) ? expected_params_enc(h->ecfg) : expected_params(h->cfg)))
         if (!h->raw.count(e.first)) missing += (missing.empty() ? "" : ", ") + e.first;
     if (!missing.empty()) return fail(h, DSD_ESTATE, "missing keys in state_dict: %s", missing.c_str());
     HIP_OK(h, hipSetDevice(h->cfg.device));
@@ -894,6 +1006,7 @@ int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int
                      int64_t stride_t, void* stream) {
     if (!h || !cond) return fail(h, DSD_EINVAL, "dsd_prepare_cond: null argument");
     if (is_aux(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is an aux decoder (use dsd_aux_decode)");
+    if (is_enc(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is an encoder (use dsd_encode)");
     if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_prepare_cond: weights are not finalized");
     if (B < 1 || T < 1) return fail(h, DSD_EINVAL, "dsd_prepare_cond: B and T must be positive (B=%d, T=%d)", B, T);
     if (stride_t != 1 && stride_h != 1)
@@ -911,6 +1024,147 @@ int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int
     rc = run_gemm(h, g, st);
     if (rc) return rc;
     h->cond_ready = true;
+    return DSD_OK;
+}
+
+int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out) {
+    if (!cfg || !out) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(dsd_encoder_config))
+        return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: struct_size %d != %zu", cfg->struct_size, sizeof(dsd_encoder_config));
+    if (cfg->vocab_size < 2 || cfg->enc_layers < 1 || cfg->num_heads < 1)
+        return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: non-positive dimension");
+    if (cfg->hidden_size < 32 || cfg->hidden_size % 32 != 0 || cfg->hidden_size % (2 * cfg->num_heads) != 0)
+        return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: hidden_size must be a multiple of 32 and of 2 * num_heads");
+    if (cfg->hidden_size / cfg->num_heads > 256)
+        return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: head dimension above 256 is not supported");
+    if (cfg->ffn_kernel_size < 1 || cfg->ffn_kernel_size % 2 == 0 || cfg->ffn_kernel_size > 15)
+        return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: enc_ffn_kernel_size must be odd and <= 15");
+    if (cfg->num_spk < 0 || cfg->num_lang < 0) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: negative table size");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, DSD_EHIP, "dsd_encoder_create: no HIP device is visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: device %d out of range [0, %d)", cfg->device, ndev);
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_encoder_create: hipSetDevice failed");
+    hipError_t ie = gemm_init_all();
+    if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_encoder_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
+    dsd_handle* h = new dsd_handle();
+    memset(&h->cfg, 0, sizeof(h->cfg));
+    h->cfg.struct_size = sizeof(dsd_config);
+    h->cfg.backbone = DSD_ENC_FS2_ACOUSTIC;
+    h->cfg.in_dims = cfg->vocab_size;
+    h->cfg.n_feats = 1;
+    h->cfg.num_layers = cfg->enc_layers;
+    h->cfg.num_channels = cfg->hidden_size;
+    h->cfg.hidden_size = cfg->hidden_size;
+    h->cfg.kernel_size = cfg->ffn_kernel_size;
+    h->cfg.device = cfg->device;
+    h->ecfg = *cfg;
+    *out = h;
+    return DSD_OK;
+}
+
+int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, const float* f0, int32_t B, int32_t L,
+               int32_t T, const dsd_encode_extras* ex, float* cond_out, void* stream) {
+    if (!h || !txt_tokens || !mel2ph || !f0 || !cond_out) return fail(h, DSD_EINVAL, "dsd_encode: null argument");
+    if (!is_enc(h)) return fail(h, DSD_ESTATE, "dsd_encode: this handle is not an encoder");
+    if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_encode: weights are not finalized");
+    if (B < 1 || L < 1 || T < 1) return fail(h, DSD_EINVAL, "dsd_encode: B, T_txt and T must be positive (%d, %d, %d)", B, L, T);
+    if (L > 2048) return fail(h, DSD_EINVAL, "dsd_encode: T_txt = %d tokens exceeds the supported 2048", L);
+    const dsd_encoder_config& e = h->ecfg;
+    dsd_encode_extras none;
+    memset(&none, 0, sizeof(none));
+    if (!ex) ex = &none;
+    if (e.num_lang > 0 && !ex->languages) return fail(h, DSD_EINVAL, "dsd_encode: use_lang_id model needs `languages`");
+    if (e.num_spk > 0 && !ex->spk_embed_id && !ex->spk_mix_embed)
+        return fail(h, DSD_EINVAL, "dsd_encode: use_spk_id model needs `spk_embed_id` or `spk_mix_embed`");
+    const float* feats[7] = {f0, ex->energy, ex->breathiness, ex->voicing, ex->tension, ex->key_shift, ex->speed};
+    for (int k = 1; k < 7; ++k)
+        if (lin_present(e, k) && !feats[k]) return fail(h, DSD_EINVAL, "dsd_encode: input for %s is missing", kLinNames[k]);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(h, hipSetDevice(e.device));
+    const int H = e.hidden_size, NL = e.enc_layers, Ls = padded_ts(L);
+    // workspace for (B, L)
+    if (!h->e_arena || h->eB != B || h->eL != L) {
+        if (h->e_arena) (void)hipFree(h->e_arena);
+        h->e_arena = nullptr;
+        const size_t per = (size_t)B * Ls;
+        size_t off = kGuard;
+        auto take = [&](size_t n) {
+            size_t o = off;
+            off += (n + 63) / 64 * 64 + 64;
+            return o;
+        };
+        const size_t o_x = take(per * H), o_y = take(per * H), o_qkv = take(per * 3 * H), o_mid = take(per * 4 * H);
+        const size_t o_np = take(per), o_dur = take((size_t)B * L);
+        off += kGuard;
+        float* a = nullptr;
+        if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
+            return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the encoder workspace failed", off * 4);
+        if (hipMemset(a, 0, off * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(encoder workspace) failed");
+        h->e_arena = a;
+        h->eB = B; h->eL = L; h->eLs = Ls;
+        h->e_x = a + o_x; h->e_y = a + o_y; h->e_qkv = a + o_qkv; h->e_mid = a + o_mid; h->e_nonpad = a + o_np;
+        h->e_dur = reinterpret_cast<int*>(a + o_dur);
+    }
+    const float* blob = h->blob;
+    const long xs = (long)H * Ls;
+    hipError_t er;
+    int rc;
+#define ENC_OK(expr, what)                                                                        \
+    if ((er = (expr)) != hipSuccess) return fail(h, DSD_EHIP, what " launch failed: %s", hipGetErrorString(er))
+    // mel2ph_to_dur + forward_embedding  (acoustic_encoder.py:89-96, tts_modules.py:385-398)
+    ENC_OK(launch_enc_dur((const long long*)mel2ph, B, T, L, h->e_dur, st), "dur");
+    ENC_OK(launch_enc_embed((const long long*)txt_tokens, (const long long*)ex->languages, h->e_dur, blob + h->e_txt,
+                            e.vocab_size, h->e_lang == SIZE_MAX ? nullptr : blob + h->e_lang, e.num_lang + 1,
+                            blob + h->e_durw, blob + h->e_durb, sqrtf((float)H), H, B, L, Ls, h->e_x, h->e_nonpad, st),
+           "embed");
+    for (int l = 0; l < NL; ++l) {      // EncSALayer.forward  (common_layers.py:236-268)
+        ENC_OK(launch_enc_layernorm(h->e_x, h->e_y, blob + h->e_ln1g[l], blob + h->e_ln1b[l], nullptr, H, B, L, Ls, 1e-5f, st),
+               "layer_norm1");
+        GemmCall q = make_gemm(h, h->g_qkv[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_ACT, 0);
+        q.p.act = ACT_NONE; q.p.out = h->e_qkv; q.p.o_bstride = 3 * xs; q.p.o_rstride = Ls;
+        if ((rc = run_gemm(h, q, st))) return rc;
+        ENC_OK(launch_enc_rope(h->e_qkv, blob + h->e_freqs, H, H / e.num_heads, B, L, Ls, st), "rope");
+        ENC_OK(launch_enc_attention(h->e_qkv, h->e_nonpad, h->e_y, H, e.num_heads, B, L, Ls, st), "attention");
+        GemmCall o = make_gemm(h, h->g_oproj[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_RES, 0);
+        o.p.aux = h->e_x; o.p.aux_bstride = xs; o.p.aux_rstride = Ls;
+        o.p.out = h->e_x; o.p.o_bstride = xs; o.p.o_rstride = Ls;
+        if ((rc = run_gemm(h, o, st))) return rc;
+        ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
+        ENC_OK(launch_enc_layernorm(h->e_x, h->e_y, blob + h->e_ln2g[l], blob + h->e_ln2b[l], nullptr, H, B, L, Ls, 1e-5f, st),
+               "layer_norm2");
+        // TransformerFFNLayer (common_layers.py:142-151): Conv1d(H, 4H, k) * k^-0.5 -> GELU -> Linear(4H, H)
+        GemmCall f1 = make_gemm(h, h->g_ffn1[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_ACT, 1, e.ffn_kernel_size > 1);
+        f1.p.act = ACT_GELU; f1.p.out = h->e_mid; f1.p.o_bstride = 4 * xs; f1.p.o_rstride = Ls;
+        if ((rc = run_gemm(h, f1, st))) return rc;
+        GemmCall f2 = make_gemm(h, h->g_ffn2[l], h->e_mid, 4 * xs, Ls, B, L, ST_PLAIN, EP_BIAS_RES, 0);
+        f2.p.aux = h->e_x; f2.p.aux_bstride = xs; f2.p.aux_rstride = Ls;
+        f2.p.out = h->e_x; f2.p.o_bstride = xs; f2.p.o_rstride = Ls;
+        if ((rc = run_gemm(h, f2, st))) return rc;
+        ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
+    }
+    // final LayerNorm * nonpadding  (tts_modules.py:424)
+    ENC_OK(launch_enc_layernorm(h->e_x, h->e_y, blob + h->e_lng, blob + h->e_lnb, h->e_nonpad, H, B, L, Ls, 1e-5f, st),
+           "final layer_norm");
+    EncExpandArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int k = 0; k < 7; ++k)
+        if (lin_present(e, k)) {
+            a.lin_w[k] = blob + h->e_linw[k];
+            a.lin_b[k] = blob + h->e_linb[k];
+            a.feat[k] = feats[k];
+        }
+    if (e.num_spk > 0) {
+        a.spk_table = blob + h->e_spk;
+        a.spk_id = (const long long*)ex->spk_embed_id;
+        a.spk_mix = ex->spk_mix_embed;
+        a.spk_mix_bstride = ex->spk_mix_bstride;
+        a.spk_mix_tstride = ex->spk_mix_tstride;
+        a.num_spk = e.num_spk;
+    }
+    ENC_OK(launch_enc_expand(h->e_y, (const long long*)mel2ph, a, H, B, L, Ls, T, cond_out, st), "expand");
+#undef ENC_OK
     return DSD_OK;
 }
 

@@ -103,6 +103,29 @@ hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const flo
 hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstride, const float* film,
                            int film_cstride, int film_col0, int film_colb, long bstride, int rstride, int C, int B,
                            int T, int strong, float* stats, int ts, float eps, hipStream_t stream);
+// encoder_kernels.hip (FastSpeech2 acoustic encoder glue)
+struct EncExpandArgs {
+    const float* lin_w[7];
+    const float* lin_b[7];
+    const float* feat[7];
+    const float* spk_table;
+    const long long* spk_id;
+    const float* spk_mix;
+    long spk_mix_bstride, spk_mix_tstride;
+    int num_spk;
+};
+hipError_t launch_enc_dur(const long long* mel2ph, int B, int T, int L, int* dur, hipStream_t st);
+hipError_t launch_enc_embed(const long long* tokens, const long long* langs, const int* dur, const float* txt_embed,
+                            int vocab, const float* lang_embed, int n_lang_rows, const float* dur_w, const float* dur_b,
+                            float embed_scale, int H, int B, int L, int Ls, float* x, float* nonpad, hipStream_t st);
+hipError_t launch_enc_layernorm(const float* x, float* y, const float* g, const float* beta, const float* mask, int C,
+                                int B, int L, int Ls, float eps, hipStream_t st);
+hipError_t launch_enc_mask(float* x, const float* mask, int C, int B, int L, int Ls, hipStream_t st);
+hipError_t launch_enc_rope(float* qkv, const float* freqs, int H, int head_dim, int B, int L, int Ls, hipStream_t st);
+hipError_t launch_enc_attention(const float* qkv, const float* nonpad, float* out, int H, int heads, int B, int L, int Ls,
+                                hipStream_t st);
+hipError_t launch_enc_expand(const float* enc, const long long* mel2ph, const EncExpandArgs& a, int H, int B, int L, int Ls,
+                             int T, float* cond, hipStream_t st);
 hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T,
                          const float* w, const float* bias, int ksz, int act, const float* prelu, hipStream_t stream);
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSD_API_VERSION 2
+#define DSD_API_VERSION 3
 
 /* error codes */
 #define DSD_OK 0
@@ -40,7 +40,10 @@ typedef struct dsd_handle dsd_handle;
 enum { DSD_BACKBONE_WAVENET = 0, DSD_BACKBONE_LYNXNET = 1,
        /* modules/aux_decoder/__init__.py:7-9  AUX_DECODERS = {'convnext': ConvNeXtDecoder}: not a denoiser - the
           shallow-diffusion aux decoder that produces the loop's start point (see dsd_aux_decode) */
-       DSD_AUX_CONVNEXT = 2 };
+       DSD_AUX_CONVNEXT = 2,
+       /* modules/fastspeech/acoustic_encoder.py:14  FastSpeech2Acoustic: the producer of `cond` (see dsd_encode);
+          created with dsd_encoder_create, not dsd_create */
+       DSD_ENC_FS2_ACOUSTIC = 3 };
 /* modules/backbones/lynxnet.py:38-42  activation_classes */
 enum { DSD_ACT_PRELU = 0, DSD_ACT_SILU = 1, DSD_ACT_RELU = 2 };
 
@@ -122,6 +125,59 @@ int dsd_denoise(dsd_handle* h, const float* x, const float* t, int32_t t_len, fl
  */
 int dsd_aux_decode(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64_t stride_b, int64_t stride_h,
                    int64_t stride_t, float* out, const float* out_scale, const float* out_shift, void* stream);
+
+/*
+ * FastSpeech2 acoustic encoder: phoneme tokens + durations + f0 -> `condition` [B, T, H], the tensor every entry
+ * point above consumes.  Constructor arguments = what FastSpeech2Acoustic.__init__ reads from hparams
+ * (modules/fastspeech/acoustic_encoder.py:15-63) in the reference fork's rotary-embedding configuration
+ * (`use_pos_embed: true, use_rope: true`, configs/acoustic.yaml:66; `ffn_act: gelu`, configs/base.yaml:32).
+ * Weights: the FastSpeech2Acoustic state_dict (`txt_embed.weight`, `dur_embed.*`, `encoder.layers.N.op.{layer_norm1,
+ * self_attn.{in_proj,out_proj}.weight, self_attn.rotary_embed.freqs, layer_norm2, ffn.ffn_1, ffn.ffn_2}.*`,
+ * `encoder.layer_norm.*`, `pitch_embed.*`, optional `lang_embed / spk_embed / variance_embeds.X / key_shift_embed /
+ * speed_embed`) through dsd_load_weight / dsd_finalize_weights.
+ */
+#define DSD_EMBED_ENERGY 1u
+#define DSD_EMBED_BREATHINESS 2u
+#define DSD_EMBED_VOICING 4u
+#define DSD_EMBED_TENSION 8u
+#define DSD_EMBED_KEY_SHIFT 16u
+#define DSD_EMBED_SPEED 32u
+
+typedef struct dsd_encoder_config {
+    int32_t struct_size;      /* sizeof(dsd_encoder_config)                                          */
+    int32_t vocab_size;       /* FastSpeech2Acoustic(vocab_size)                                     */
+    int32_t hidden_size;      /* hparams['hidden_size']                                              */
+    int32_t enc_layers;       /* hparams['enc_layers']                                               */
+    int32_t num_heads;        /* hparams['num_heads']                                                */
+    int32_t ffn_kernel_size;  /* hparams['enc_ffn_kernel_size'] (odd)                                */
+    int32_t num_spk;          /* hparams['num_spk'] if use_spk_id else 0                             */
+    int32_t num_lang;         /* hparams['num_lang'] if use_lang_id else 0 (table has num_lang + 1 rows) */
+    uint32_t embed_flags;     /* DSD_EMBED_*: use_energy_embed ... use_speed_embed                   */
+    int32_t device;
+} dsd_encoder_config;
+
+/* Optional inputs of FastSpeech2Acoustic.forward (acoustic_encoder.py:82-88); NULL = not given.  All device pointers. */
+typedef struct dsd_encode_extras {
+    const int64_t* languages;      /* [B, T_txt]   (use_lang_id)                                     */
+    const int64_t* spk_embed_id;   /* [B]          (use_spk_id, when spk_mix_embed is NULL)          */
+    const float* spk_mix_embed;    /* element (b,t,h) at [b*bstride + t*tstride + h] (use_spk_id)    */
+    int64_t spk_mix_bstride, spk_mix_tstride;
+    const float* key_shift;        /* [B, T] each                                                    */
+    const float* speed;
+    const float* energy;
+    const float* breathiness;
+    const float* voicing;
+    const float* tension;
+} dsd_encode_extras;
+
+int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out);
+/*
+ * Replaces: FastSpeech2Acoustic.forward(txt_tokens, mel2ph, f0, key_shift, speed, spk_embed_id, languages, **kwargs)
+ * (acoustic_encoder.py:82-118).  txt_tokens [B, T_txt] int64 (0 = padding), mel2ph [B, T] int64 (1-based token
+ * index per frame, 0 = padding frame), f0 [B, T] Hz; cond_out [B, T, H] contiguous.
+ */
+int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, const float* f0, int32_t B,
+               int32_t T_txt, int32_t T, const dsd_encode_extras* extras, float* cond_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sampling programs.  Every sampler of the reference (ddpm.py:149-204,221-351 p_sample /

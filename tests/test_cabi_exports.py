@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert _lib.lib().dsd_api_version() == 2
+    assert _lib.lib().dsd_api_version() == 3
 
 
 def test_struct_sizes_match_header():
@@ -119,3 +119,33 @@ def test_aux_decoder_state_dict_and_host_checks():
         a(torch.zeros(1, 4, 256), infer=True)
     with pytest.raises(ValueError):
         build_aux_decoder(256, 128, "convnext", dict(kernel_size=6))
+
+
+def test_encoder_state_dict_matches_reference_layout():
+    """FastSpeech2Acoustic shim: reference state_dict names/shapes (acoustic_encoder.py:15-63, tts_modules.py:353-383,
+    common_layers.py:154-234) incl. the per-layer alias of the shared rotary `freqs` parameter."""
+    import torch
+    from diffsinger_amd import synth
+    from diffsinger_amd.hparams import hparams
+    from diffsinger_amd.encoder import FastSpeech2Acoustic
+    hparams.clear()
+    hparams.update(hidden_size=128, enc_layers=2, enc_ffn_kernel_size=9, ffn_act="gelu", dropout=0.1, num_heads=2,
+                   use_pos_embed=True, rel_pos=True, use_rope=True, use_spk_id=True, num_spk=4, use_lang_id=True,
+                   num_lang=3, use_energy_embed=True, use_tension_embed=True, use_key_shift_embed=True,
+                   use_speed_embed=True)
+    m = FastSpeech2Acoustic(33)
+    shapes = synth.fs2_acoustic_param_shapes(33, hidden_size=128, enc_layers=2, num_heads=2, ffn_kernel_size=9,
+                                             num_spk=4, num_lang=3, variances=("energy", "tension"), key_shift=True,
+                                             speed=True)
+    sd = m.state_dict()
+    assert set(sd) == set(shapes)
+    for k, v in shapes.items():
+        assert tuple(sd[k].shape) == tuple(v), k
+    f = sd["encoder.layers.0.op.self_attn.rotary_embed.freqs"]
+    assert torch.allclose(f, 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64)))
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.ones(1, 3, dtype=torch.long), torch.ones(1, 5, dtype=torch.long), torch.ones(1, 5),
+          spk_embed_id=torch.zeros(1, dtype=torch.long), languages=torch.ones(1, 3, dtype=torch.long),
+          energy=torch.zeros(1, 5), tension=torch.zeros(1, 5), key_shift=torch.zeros(1, 5), speed=torch.ones(1, 5))
+    hparams.clear()
+    hparams.update(hidden_size=256)
