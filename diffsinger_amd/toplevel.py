@@ -1,8 +1,9 @@
-"""The decoder half of `DiffSingerAcoustic` (modules/toplevel.py:32-120): everything after the FastSpeech2
-encoder has produced `condition`.  Same attribute names as the reference (`aux_decoder`, `diffusion`), so the
-matching slices of an acoustic checkpoint load with strict=True; same hparams read at construction
-(toplevel.py:44-83) and the same infer-branch behaviour (:90-105).  The encoder itself is outside the hot path
-(SURVEY.md section 8 "out of scope") and stays on the reference.
+"""`DiffSingerAcoustic` (modules/toplevel.py:32-120) on libdsdenoise.
+
+`AcousticDecoder` is everything after the FastSpeech2 encoder has produced `condition` (aux decoder, padding
+masks, denoise loop); `DiffSingerAcoustic` adds the encoder (`fs2`) in front.  Same attribute names as the
+reference (`fs2`, `aux_decoder`, `diffusion`), so an acoustic checkpoint loads with strict=True; same hparams read
+at construction (toplevel.py:44-83) and the same infer-branch behaviour (:84-105).  Inference only.
 """
 from __future__ import annotations
 
@@ -12,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .aux_decoder import AuxDecoderAdaptor
+from .encoder import FastSpeech2Acoustic
 from .diffusion import GaussianDiffusion, RectifiedFlow
 from .hparams import hparams
 
@@ -45,6 +47,9 @@ class AcousticDecoder(nn.Module):
 
     def __init__(self, out_dims):
         super().__init__()
+        self._init_decoder(out_dims)
+
+    def _init_decoder(self, out_dims):
         self.use_shallow_diffusion = hparams.get('use_shallow_diffusion', False)
         self.shallow_args = hparams.get('shallow_diffusion_args', {})
         if self.use_shallow_diffusion:
@@ -87,3 +92,23 @@ class AcousticDecoder(nn.Module):
         mel_pred = self.diffusion(condition, src_spec=src_mel, infer=True, **diffusion_kwargs)
         mel_pred *= mask
         return ShallowDiffusionOutput(aux_out=aux_mel_pred, diff_out=mel_pred)
+
+
+class DiffSingerAcoustic(AcousticDecoder):
+    """toplevel.py:32-120: `fs2` encoder -> (aux decoder ->) denoise loop, tokens in, mel out."""
+
+    def __init__(self, vocab_size, out_dims):
+        nn.Module.__init__(self)
+        self.fs2 = FastSpeech2Acoustic(vocab_size=vocab_size)       # registered first, as in the reference
+        self._init_decoder(out_dims)
+
+    def forward(self, txt_tokens, mel2ph, f0, key_shift=None, speed=None, spk_embed_id=None, languages=None,
+                gt_mel=None, infer=True, noise=None, step_noise=None, **kwargs) -> ShallowDiffusionOutput:
+        condition = self.fs2(txt_tokens, mel2ph, f0, key_shift=key_shift, speed=speed, spk_embed_id=spk_embed_id,
+                             languages=languages, **kwargs)
+        extra = {}
+        if noise is not None:
+            extra["noise"] = noise
+        if step_noise is not None:
+            extra["step_noise"] = step_noise
+        return AcousticDecoder.forward(self, condition, mel2ph, gt_mel=gt_mel, infer=infer, **extra)

@@ -569,8 +569,57 @@ def g8_encoder():
     save("g8_encoder", **out)
 
 
+# --------------------------------------------------------------------------- G9: DiffSingerAcoustic, tokens -> mel
+def g9_acoustic_model():
+    """The reference's own top-level acoustic model (modules/toplevel.py:32-105), infer branch, small nets:
+    fs2 encoder -> ConvNeXt aux decoder -> mask -> shallow loop -> mask."""
+    from modules.toplevel import DiffSingerAcoustic  # (reference)
+    out = {}
+    vocab, m_bins, bsz, t_txt, t_mel = 40, 32, 2, 14, 60
+    enc_hp = dict(hidden_size=256, enc_layers=2, enc_ffn_kernel_size=3, ffn_act="gelu", dropout=0.1, num_heads=2,
+                  use_pos_embed=True, rel_pos=True, use_rope=True, use_spk_id=False, num_spk=1, use_lang_id=False,
+                  num_lang=1)
+    rng = np.random.Generator(np.random.PCG64(123))
+    smin = (-12.0 + rng.random(m_bins)).astype(np.float32)
+    smax = (0.0 + rng.random(m_bins)).astype(np.float32)
+    aux_args = dict(num_channels=64, num_layers=2, kernel_size=7, dropout_rate=0.1)
+    common = dict(use_shallow_diffusion=True, spec_min=smin.tolist(), spec_max=smax.tolist(),
+                  shallow_diffusion_args=dict(aux_decoder_arch="convnext", aux_decoder_args=aux_args,
+                                              val_gt_start=False, train_aux_decoder=True, train_diffusion=True,
+                                              aux_decoder_grad=0.1),
+                  backbone_type="wavenet", backbone_args=SAMPLER_NET["args"], timesteps=1000, K_step=400,
+                  T_start=0.4, time_scale_factor=1000)
+    tokens, mel2ph, f0, _ = enc_inputs("g9", vocab, bsz, t_txt, t_mel, 9001)
+    out["tokens"], out["mel2ph"], out["f0"] = tokens, mel2ph, f0
+    out["smin"], out["smax"] = smin, smax
+    out["meta"] = np.array([vocab, m_bins, bsz, t_txt, t_mel, 9100], dtype=np.int64)
+    for tag, hp in (("ddpm_dpm", dict(diffusion_type="ddpm", diff_accelerator="dpm-solver", diff_speedup=20,
+                                      K_step_infer=400)),
+                    ("reflow_euler", dict(diffusion_type="reflow", sampling_algorithm="euler", sampling_steps=20,
+                                          T_start_infer=0.4))):
+        set_hp(**enc_hp, **common, **hp)
+        model = DiffSingerAcoustic(vocab, m_bins)
+        sd = dict(model.state_dict())
+        fs2 = synth.synth_state_dict(synth.fs2_acoustic_param_shapes(vocab, enc_layers=2), seed=9200)
+        sd.update({"fs2." + k: to_t(v) for k, v in fs2.items()})
+        aux = synth.synth_state_dict(synth.convnext_param_shapes(256, m_bins, num_channels=64, num_layers=2,
+                                                                 prefix="aux_decoder.decoder."), seed=9201)
+        sd.update({k: to_t(v) for k, v in aux.items()})
+        fn = "denoise_fn" if hp["diffusion_type"] == "ddpm" else "velocity_fn"
+        net = synth.synth_state_dict(synth.backbone_param_shapes("wavenet", m_bins, 1, hidden_size=256,
+                                                                 **SAMPLER_NET["args"]), seed=9202)
+        sd.update({f"diffusion.{fn}.{k}": to_t(v) for k, v in net.items()})
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        with InjectRandn(9100) as inj, torch.no_grad():
+            res = model(to_t(tokens), to_t(mel2ph), to_t(f0), infer=True)
+        out[f"{tag}_aux"], out[f"{tag}_mel"] = res.aux_out.numpy(), res.diff_out.numpy()
+        print(f"  acoustic {tag}: randn calls={len(inj.seeds)} mel {res.diff_out.shape} absmax={res.diff_out.abs().max():.3f}")
+    save("g9_acoustic_model", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -585,3 +634,5 @@ if __name__ == "__main__":
         g7_aux_decoder()
     if "g8" in which:
         g8_encoder()
+    if "g9" in which:
+        g9_acoustic_model()

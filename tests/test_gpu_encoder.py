@@ -118,3 +118,39 @@ def test_encoder_spk_mix_and_errors():
     set_hp(**dict(ENC_HP, use_rope=False))
     with pytest.raises(NotImplementedError):
         FastSpeech2Acoustic(10)
+
+
+@pytest.mark.parametrize("tag", ("ddpm_dpm", "reflow_euler"))
+def test_diffsinger_acoustic_tokens_to_mel_vs_golden(tag):
+    """diffsinger_amd.toplevel.DiffSingerAcoustic against the reference's own top-level model (G9): phoneme tokens,
+    durations and f0 in, mel out - encoder, aux decoder, masks and the shallow loop all on the HIP library."""
+    from diffsinger_amd.toplevel import DiffSingerAcoustic
+    g = np.load(os.path.join(GOLDEN, "g9_acoustic_model.npz"))
+    vocab, m, bsz, t_txt, t_mel, nseed = (int(v) for v in g["meta"])
+    sn_args = dict(num_layers=4, num_channels=64, dilation_cycle_length=2)
+    hp = dict(ENC_HP, enc_layers=2, use_shallow_diffusion=True, spec_min=g["smin"].tolist(), spec_max=g["smax"].tolist(),
+              shallow_diffusion_args=dict(aux_decoder_arch="convnext", val_gt_start=False,
+                                          aux_decoder_args=dict(num_channels=64, num_layers=2, kernel_size=7)),
+              backbone_type="wavenet", backbone_args=sn_args, timesteps=1000, K_step=400, T_start=0.4,
+              time_scale_factor=1000)
+    if tag == "ddpm_dpm":
+        set_hp(diffusion_type="ddpm", diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=400, **hp)
+    else:
+        set_hp(diffusion_type="reflow", sampling_algorithm="euler", sampling_steps=20, T_start_infer=0.4, **hp)
+    model = DiffSingerAcoustic(vocab, m)
+    sd = dict(model.state_dict())
+    sd.update({"fs2." + k: torch.from_numpy(v) for k, v in
+               synth.synth_state_dict(synth.fs2_acoustic_param_shapes(vocab, enc_layers=2), seed=9200).items()})
+    sd.update({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(
+        synth.convnext_param_shapes(256, m, num_channels=64, num_layers=2, prefix="aux_decoder.decoder."), seed=9201).items()})
+    fn = "denoise_fn" if tag == "ddpm_dpm" else "velocity_fn"
+    sd.update({f"diffusion.{fn}.{k}": torch.from_numpy(v) for k, v in synth.synth_state_dict(
+        synth.backbone_param_shapes("wavenet", m, 1, hidden_size=256, **sn_args), seed=9202).items()})
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    noise = dev(synth.synth_normal((bsz, 1, m, t_mel), nseed))
+    with torch.no_grad():
+        out = model(dev(g["tokens"]), dev(g["mel2ph"]), dev(g["f0"]), infer=True, noise=noise)
+    assert rel_err(out.aux_out, g[f"{tag}_aux"]) < 2e-5
+    assert rel_err(out.diff_out, g[f"{tag}_mel"]) < 5e-4
+    set_hp()

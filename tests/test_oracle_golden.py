@@ -378,3 +378,35 @@ def test_g8_fs2_acoustic_encoder(tag):
     assert rel_err(cond, want) < 2e-5
     if tag == "padded":       # the case really has padded tokens and padded frames
         assert (tokens == 0).any() and (mel2ph == 0).any()
+
+
+# --------------------------------------------------------------------------- G9: tokens -> mel
+def g9_parts(g):
+    vocab, m, bsz, t_txt, t_mel, nseed = (int(v) for v in g["meta"])
+    fs2 = synth.synth_state_dict(synth.fs2_acoustic_param_shapes(vocab, enc_layers=2), seed=9200)
+    aux = synth.synth_state_dict(synth.convnext_param_shapes(256, m, num_channels=64, num_layers=2, prefix="decoder."),
+                                 seed=9201)
+    net = synth_params("wavenet", m, 1, SN_ARGS, 9202)
+    return (vocab, m, bsz, t_txt, t_mel, nseed), fs2, aux, net
+
+
+@pytest.mark.parametrize("tag", ("ddpm_dpm", "reflow_euler"))
+def test_g9_acoustic_model_tokens_to_mel(tag):
+    """The reference's top-level DiffSingerAcoustic (infer branch) restated as encoder -> aux decoder -> shallow loop."""
+    g = load("g9_acoustic_model")
+    (vocab, m, bsz, t_txt, t_mel, nseed), fs2, aux, netp = g9_parts(g)
+    cond = oe.fs2_acoustic_forward(fs2, g["tokens"], g["mel2ph"], g["f0"], num_heads=2)
+    net = lambda x, t, c: ob.wavenet_forward(netp, x, t, c, dilation_cycle_length=2)  # noqa: E731
+    smin, smax = g["smin"], g["smax"]
+    if tag == "ddpm_dpm":
+        d = od.GaussianDiffusion(net, m, 1, timesteps=1000, k_step=400, spec_min=smin.tolist(), spec_max=smax.tolist(),
+                                 use_shallow_diffusion=True)
+        kw = dict(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=400)
+    else:
+        d = od.RectifiedFlow(net, m, 1, t_start=0.4, time_scale_factor=1000, spec_min=smin.tolist(),
+                             spec_max=smax.tolist(), use_shallow_diffusion=True)
+        kw = dict(T_start_infer=0.4, sampling_algorithm="euler", sampling_steps=20)
+    noise = synth.synth_normal((bsz, 1, m, t_mel), nseed)
+    aux_mel, mel = oa.acoustic_infer(aux, d, cond, g["mel2ph"], noise, smin, smax, m, **kw)
+    assert rel_err(aux_mel, g[f"{tag}_aux"]) < 2e-5
+    assert rel_err(mel, g[f"{tag}_mel"]) < 2e-4
