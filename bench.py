@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1000, help="mel frames per utterance (T)")
-    ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100", "acoustic_default"])
+    ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100", "acoustic_default", "acoustic_e2e"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -121,19 +121,25 @@ def main():
     params = synth.synth_state_dict(shapes, seed=42)
     hparams.clear()
     acoustic = None
-    if args.workload == "acoustic_default":
+    if args.workload in ("acoustic_default", "acoustic_e2e"):
         # configs/acoustic.yaml:61-99 of the reference fork: shallow reflow (euler, 20 steps from t = 0.4) on the
         # LYNXNet above, started from the ConvNeXt aux decoder's mel - DiffSingerAcoustic.forward after the encoder
-        from diffsinger_amd.toplevel import AcousticDecoder
+        from diffsinger_amd.toplevel import AcousticDecoder, DiffSingerAcoustic
         aux_args = dict(num_channels=512, num_layers=6, kernel_size=7, dropout_rate=0.1)
+        e2e = args.workload == "acoustic_e2e"      # + the FastSpeech2 encoder: phoneme tokens in, mel out
+        hparams.update(enc_layers=4, enc_ffn_kernel_size=3, ffn_act="gelu", dropout=0.1, num_heads=2, use_pos_embed=True,
+                       rel_pos=True, use_rope=True, use_spk_id=False, num_spk=1, use_lang_id=False, num_lang=1)
         hparams.update(hidden_size=256, schedule_type="linear", infer=False, use_shallow_diffusion=True,
                        diffusion_type="reflow", T_start=0.4, T_start_infer=0.4, time_scale_factor=1000,
                        sampling_algorithm="euler", sampling_steps=20, timesteps=1000, K_step=400, K_step_infer=400,
                        backbone_type=kind, backbone_args=bargs, spec_min=[-12.0], spec_max=[0.0],
                        shallow_diffusion_args=dict(aux_decoder_arch="convnext", aux_decoder_args=aux_args,
                                                    val_gt_start=False))
-        acoustic = AcousticDecoder(128)
+        acoustic = DiffSingerAcoustic(60, 128) if e2e else AcousticDecoder(128)
         sd = dict(acoustic.state_dict())
+        if e2e:
+            fs2_sd = synth.synth_state_dict(synth.fs2_acoustic_param_shapes(60), seed=44)
+            sd.update({"fs2." + k: torch.from_numpy(v) for k, v in fs2_sd.items()})
         sd.update({"diffusion.velocity_fn." + k: torch.from_numpy(v) for k, v in params.items()})
         aux_sd = synth.synth_state_dict(synth.convnext_param_shapes(256, 128, prefix="aux_decoder.decoder."), seed=43)
         sd.update({k: torch.from_numpy(v) for k, v in aux_sd.items()})
@@ -141,7 +147,8 @@ def main():
         acoustic = acoustic.to(device).eval()
         d = acoustic.diffusion
         d.denoise_fn = d.velocity_fn          # one name for the backbone below
-        nfe, wname = 20, ("ConvNeXt aux decoder 6x512 -> shallow reflow euler 20 (t 0.4 -> 1) on LYNXNet 6x1024 "
+        nfe, wname = 20, (("FastSpeech2 encoder 4x256 (120 tokens) -> " if e2e else "") +
+                          "ConvNeXt aux decoder 6x512 -> shallow reflow euler 20 (t 0.4 -> 1) on LYNXNet 6x1024 "
                           "(configs/acoustic.yaml of the reference fork)")
     else:
         hparams.update(hidden_size=256, schedule_type="linear", use_shallow_diffusion=False, infer=False, **hp)
@@ -159,11 +166,16 @@ def main():
     noise = sharding.utterance_noise((1, 128, T), mine, seed=1, device=device)      # x_T, resident before timing
     cond_local = cond_all if not use_dist else None
 
-    mel2ph = torch.ones((len(mine), T), dtype=torch.long, device=device)
+    n_tok = 120
+    mel2ph = (torch.arange(T, device=device) * n_tok // T + 1).to(torch.long)[None].expand(len(mine), T).contiguous()
+    tokens = (torch.arange(n_tok, device=device) % 59 + 1).to(torch.long)[None].expand(len(mine), n_tok).contiguous()
+    f0 = torch.full((len(mine), T), 220.0, device=device)
 
     def run(c):
         if acoustic is not None:
             with torch.no_grad():       # as DiffSingerAcousticInfer.forward_model does (ds_acoustic.py:136)
+                if args.workload == "acoustic_e2e":     # the condition comes from the encoder on this GPU
+                    return acoustic(tokens, mel2ph, f0, infer=True, noise=noise).diff_out
                 return acoustic(c, mel2ph, infer=True, noise=noise).diff_out
         return d(c, infer=True, noise=noise)
 

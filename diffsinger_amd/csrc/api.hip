@@ -1366,7 +1366,12 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
     const int64_t C = C_of(h), M = FM_of(h), L = L_of(h);
     out->weight_bytes = (int64_t)h->blob_floats * 4;
     out->workspace_bytes = (int64_t)h->arena_floats * 4;
-    if (is_aux(h)) {        // one pass per utterance, not per NFE: the "_nfe" fields are per decoder pass here
+    if (is_enc(h)) {        // per TOKEN per encoder pass (attention excluded: it depends on the sequence length)
+        const int64_t H = h->ecfg.hidden_size, ks = h->ecfg.ffn_kernel_size, NL = h->ecfg.enc_layers;
+        out->flops_per_frame_nfe = 2 * NL * (3 * H * H + H * H + ks * H * 4 * H + 4 * H * H);
+        out->bytes_per_frame_nfe = 0;
+        out->kernels_per_nfe = 3 + 11 * (int)NL + 2;
+    } else if (is_aux(h)) {        // one pass per utterance, not per NFE: the "_nfe" fields are per decoder pass here
         const int64_t H = h->cfg.hidden_size, ks = h->cfg.kernel_size;
         out->flops_per_frame_nfe = 2 * (ks * H * C + L * (7 * C + C * 4 * C + 4 * C * C) + ks * C * M);
         out->bytes_per_frame_nfe = 4 * (H + M);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time the shallow-diffusion aux decoder pass (dsd_aux_decode) next to one denoiser NFE.  GPU box only."""
+"""Time the once-per-utterance neighbours of the loop: the aux decoder pass (dsd_aux_decode) and the FastSpeech2
+encoder (dsd_encode).  GPU box only."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -28,3 +29,26 @@ for bsz, t_len in ((1, 1000), (8, 1000), (16, 1000)):
     st = a.decoder.stats()
     fl = st["flops_per_frame_nfe"] * bsz * t_len
     print(f"B={bsz} T={t_len}: {dt*1e3:.3f} ms/pass  {bsz*t_len/dt/1e6:.2f} M frames/s  {fl/dt/1e12:.1f} TFLOP/s", flush=True)
+
+hparams.update(enc_layers=4, enc_ffn_kernel_size=3, ffn_act="gelu", dropout=0.1, num_heads=2, use_pos_embed=True,
+               rel_pos=True, use_rope=True, use_spk_id=False, num_spk=1, use_lang_id=False, num_lang=1)
+from diffsinger_amd.encoder import FastSpeech2Acoustic
+enc = FastSpeech2Acoustic(60)
+enc.load_state_dict({k: torch.from_numpy(v) for k, v in
+                     synth.synth_state_dict(synth.fs2_acoustic_param_shapes(60), seed=4).items()}, strict=True)
+enc = enc.cuda().eval()
+for bsz, n_tok, t_len in ((1, 120, 1000), (8, 120, 1000), (1, 300, 2500)):
+    tokens = (torch.arange(n_tok, device="cuda") % 59 + 1)[None].expand(bsz, n_tok).contiguous()
+    mel2ph = (torch.arange(t_len, device="cuda") * n_tok // t_len + 1)[None].expand(bsz, t_len).contiguous()
+    f0 = torch.full((bsz, t_len), 220.0, device="cuda")
+    with torch.no_grad():
+        for _ in range(5):
+            enc(tokens, mel2ph, f0)
+        torch.cuda.synchronize()
+        n = 50
+        t0 = time.perf_counter()
+        for _ in range(n):
+            enc(tokens, mel2ph, f0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+    print(f"encoder B={bsz} T_txt={n_tok} T={t_len}: {dt*1e3:.3f} ms/pass", flush=True)
