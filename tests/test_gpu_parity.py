@@ -386,3 +386,23 @@ def test_variance_wrappers_gpu_vs_oracle():
     for a, w in zip(outs, want):
         assert np.abs(a.cpu().numpy() - w).max() < 2e-2 * max(1.0, np.abs(w).max()) * 1e-1
     m.velocity_fn.release_native()
+
+
+def test_config3_lynxnet_full_width_ddim_vs_oracle():
+    """BASELINE config 3's network and sampler at full width (LYNXNet 6x1024, k=31, strong_cond, PReLU; DDIM) with a
+    batch of 8 utterances, against the numpy oracle.  The loop is shortened to 10 of the 100 DDIM steps (speed-up
+    100) and T to 200 frames so that the host-side oracle finishes in seconds; tolerance 5e-4 of the output range."""
+    largs = dict(num_layers=6, num_channels=1024, expansion_factor=2, kernel_size=31, activation="PReLU", strong_cond=True)
+    set_hp(diff_accelerator="ddim", diff_speedup=100, K_step_infer=1000)
+    d = _gd(1000, kind="lynxnet", in_dims=128, args=largs, wseed=77)
+    bsz, t_len = 8, 200
+    cond = synth.synth_normal((bsz, t_len, 256), 70)
+    noise = synth.synth_normal((bsz, 1, 128, t_len), 71)
+    out = d(dev(cond), infer=True, noise=dev(noise))
+    params = synth_params("lynxnet", 128, 1, largs, 77)
+    fn = lambda x, t, c: ob.lynxnet_forward(params, x, t, c, activation="PReLU", strong_cond=True)   # noqa: E731
+    o = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
+    want = o.forward(cond, noise, diff_accelerator="ddim", diff_speedup=100, K_step_infer=1000)
+    err = rel_err(out, want)
+    assert err < TOL_SAMPLER, err
+    d.denoise_fn.release_native()
