@@ -1035,8 +1035,8 @@ int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out) {
         return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: non-positive dimension");
     if (cfg->hidden_size < 32 || cfg->hidden_size % 32 != 0 || cfg->hidden_size % (2 * cfg->num_heads) != 0)
         return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: hidden_size must be a multiple of 32 and of 2 * num_heads");
-    if (cfg->hidden_size / cfg->num_heads > 256)
-        return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: head dimension above 256 is not supported");
+    if (cfg->hidden_size / cfg->num_heads > 256 || (cfg->hidden_size / cfg->num_heads) % 8 != 0)
+        return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: head dimension must be a multiple of 8, at most 256");
     if (cfg->ffn_kernel_size < 1 || cfg->ffn_kernel_size % 2 == 0 || cfg->ffn_kernel_size > 15)
         return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: enc_ffn_kernel_size must be odd and <= 15");
     if (cfg->num_spk < 0 || cfg->num_lang < 0) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: negative table size");

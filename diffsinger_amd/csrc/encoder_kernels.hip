@@ -8,6 +8,8 @@
 
 namespace dsd {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------------------------
 // mel2ph_to_dur (tts_modules.py:344-350): dur[b][k] = #{t : mel2ph[b][t] == k + 1}.  Integer atomics: exact.
 // ---------------------------------------------------------------------------------------------
@@ -50,27 +52,81 @@ __global__ void enc_embed_kernel(const long long* __restrict__ tokens, const lon
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over channels, materialised (nn.LayerNorm(H), eps 1e-5, biased variance, two-pass):
 //   y[b][c][l] = ((x - mean) * rstd * g[c] + beta[c]) * (mask ? mask[b][l] : 1)
-// One lane per token column, channels walked serially: C is 256 and L a few hundred.
+// One workgroup = 64 token columns (lanes) x 16 waves over the channels; a lane keeps its <= 32 channel values in
+// registers between the two passes (C <= 512; beyond that they are re-read).
 // ---------------------------------------------------------------------------------------------
-__global__ void enc_layernorm_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ g,
-                                     const float* __restrict__ beta, const float* __restrict__ mask, int C, int L,
-                                     int Ls, float eps) {
+constexpr int ELN_WAVES = 16;
+constexpr int ELN_REG = 32;
+__global__ __launch_bounds__(1024) void enc_layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ g, const float* __restrict__ beta,
+                                                             const float* __restrict__ mask, int C, int L, int Ls,
+                                                             float eps) {
+    __shared__ float red[ELN_WAVES][64];
+    __shared__ float stat[2][64];
     const int b = blockIdx.y;
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= L) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = min(blockIdx.x * 64 + lane, Ls - 1);          // columns >= L are computed on padding and never stored
     const float* xb = x + (long)b * C * Ls + l;
+    const int nper = (C + ELN_WAVES - 1) / ELN_WAVES;
+    float keep[ELN_REG];
     float sum = 0.f;
-    for (int c = 0; c < C; ++c) sum += xb[(long)c * Ls];
-    const float mean = sum / (float)C;
-    float sq = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float d = xb[(long)c * Ls] - mean;
-        sq += d * d;
+#pragma unroll
+    for (int i = 0; i < ELN_REG; ++i) {
+        const int c = wave + i * ELN_WAVES;
+        keep[i] = (i < nper && c < C) ? xb[(long)c * Ls] : 0.f;
+        sum += keep[i];
     }
-    const float rstd = 1.f / sqrtf(sq / (float)C + eps);
+    for (int i = ELN_REG; i < nper; ++i) {
+        const int c = wave + i * ELN_WAVES;
+        if (c < C) sum += xb[(long)c * Ls];
+    }
+    red[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < ELN_WAVES; ++w) s += red[w][lane];
+        stat[0][lane] = s / (float)C;
+    }
+    __syncthreads();
+    const float mean = stat[0][lane];
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < ELN_REG; ++i) {
+        const int c = wave + i * ELN_WAVES;
+        const float d = keep[i] - mean;
+        sq += (i < nper && c < C) ? d * d : 0.f;
+    }
+    for (int i = ELN_REG; i < nper; ++i) {
+        const int c = wave + i * ELN_WAVES;
+        if (c < C) {
+            const float d = xb[(long)c * Ls] - mean;
+            sq += d * d;
+        }
+    }
+    __syncthreads();
+    red[wave][lane] = sq;
+    __syncthreads();
+    if (wave == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < ELN_WAVES; ++w) s += red[w][lane];
+        stat[1][lane] = 1.f / sqrtf(s / (float)C + eps);
+    }
+    __syncthreads();
+    if (blockIdx.x * 64 + lane >= L) return;
+    const float rstd = stat[1][lane];
     const float m = mask ? mask[(long)b * Ls + l] : 1.f;
     float* yb = y + (long)b * C * Ls + l;
-    for (int c = 0; c < C; ++c) yb[(long)c * Ls] = ((xb[(long)c * Ls] - mean) * rstd * g[c] + beta[c]) * m;
+#pragma unroll
+    for (int i = 0; i < ELN_REG; ++i) {
+        const int c = wave + i * ELN_WAVES;
+        if (i < nper && c < C) yb[(long)c * Ls] = ((keep[i] - mean) * rstd * g[c] + beta[c]) * m;
+    }
+    for (int i = ELN_REG; i < nper; ++i) {
+        const int c = wave + i * ELN_WAVES;
+        if (c < C) yb[(long)c * Ls] = ((xb[(long)c * Ls] - mean) * rstd * g[c] + beta[c]) * m;
+    }
 }
 
 // x[b][c][l] *= mask[b][l]   (EncSALayer: `x * (1 - encoder_padding_mask)` after each residual, common_layers.py:259,266)
@@ -115,13 +171,13 @@ constexpr int ATT_MAXD = 256;
 constexpr int ATT_MAXCH = 32;          // key chunks of 64 per lane: L <= 2048
 __global__ __launch_bounds__(256) void enc_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ nonpad,
                                                             float* __restrict__ out, int H, int heads, int L, int Ls) {
-    __shared__ float qs[4][ATT_MAXD];
-    __shared__ float ps[4][ATT_MAXCH * 64];
+    __shared__ __attribute__((aligned(16))) float qs[4][ATT_MAXD];
+    __shared__ __attribute__((aligned(16))) float ps[4][ATT_MAXCH * 64];
     const int b = blockIdx.z, head = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = H / heads;
     const int q = blockIdx.x * 4 + wave;
-    if (q >= L) return;                             // whole wave leaves together (no barrier below)
+    if (q >= L) return;                             // whole wave leaves together (no workgroup barrier below)
     const float* Q = qkv + ((long)b * 3 * H + head * D) * Ls;
     const float* K = Q + (long)H * Ls;
     const float* V = K + (long)H * Ls;
@@ -129,15 +185,20 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float* __restr
     __builtin_amdgcn_wave_barrier();
     const float scale = sqrtf((float)D);
     const int nch = (L + 63) / 64;
+    // ---- scores: keys along the lanes, the query broadcast from LDS; 8 independent loads in flight ----
     float mx = -INFINITY;
     for (int ch = 0; ch < nch; ++ch) {
         const int j = ch * 64 + lane;
-        float s = -INFINITY;
-        if (j < L) {
-            float acc = 0.f;
-            for (int d = 0; d < D; ++d) acc += qs[wave][d] * K[(long)d * Ls + j];
-            s = (nonpad[(long)b * Ls + j] != 0.f) ? acc / scale : -INFINITY;
+        const int jc = min(j, L - 1);
+        float acc = 0.f;
+        for (int d0 = 0; d0 < D; d0 += 8) {
+            float kv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kv[i] = K[(long)(d0 + i) * Ls + jc];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += qs[wave][d0 + i] * kv[i];
         }
+        const float s = (j < L && nonpad[(long)b * Ls + jc] != 0.f) ? acc / scale : -INFINITY;
         ps[wave][ch * 64 + lane] = s;
         mx = fmaxf(mx, s);
     }
@@ -153,17 +214,28 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float* __restr
     for (int m = 1; m < 64; m <<= 1) sum += __shfl_xor(sum, m, 64);
     for (int ch = 0; ch < nch; ++ch) ps[wave][ch * 64 + lane] /= sum;
     __builtin_amdgcn_wave_barrier();
-    // o[d] = sum_j p_j v[d][j]: lanes along keys again, one wave reduction per output channel
-    float* O = out + ((long)b * H + head * D) * Ls + q;
-    for (int d = 0; d < D; ++d) {
+    // ---- o[d] = sum_j p_j v[d][j]: output channels along the lanes, each lane streams its own row of V in 16-byte
+    //      pieces (rows are contiguous in j), the probabilities are broadcast from LDS; no cross-lane reduction.
+    //      Keys in [L, nch*64) carry p = 0 and read finite padding of the row. ----
+    const int n4 = nch * 16;
+    for (int dd = lane; dd < D; dd += 64) {
+        const f32x4* vr = reinterpret_cast<const f32x4*>(V + (long)dd * Ls);
+        const f32x4* pr = reinterpret_cast<const f32x4*>(&ps[wave][0]);
         float acc = 0.f;
-        for (int ch = 0; ch < nch; ++ch) {
-            const int j = ch * 64 + lane;
-            if (j < L) acc += ps[wave][ch * 64 + lane] * V[(long)d * Ls + j];
-        }
+        for (int j4 = 0; j4 < n4; j4 += 4) {
+            f32x4 v[4];
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
-        if (lane == 0) O[(long)d * Ls] = acc;
+            for (int i = 0; i < 4; ++i) v[i] = vr[j4 + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 pv = pr[j4 + i];
+                acc += pv[0] * v[i][0];
+                acc += pv[1] * v[i][1];
+                acc += pv[2] * v[i][2];
+                acc += pv[3] * v[i][3];
+            }
+        }
+        out[((long)b * H + head * D + dd) * Ls + q] = acc;
     }
 }
 
@@ -226,7 +298,8 @@ hipError_t launch_enc_embed(const long long* tokens, const long long* langs, con
 
 hipError_t launch_enc_layernorm(const float* x, float* y, const float* g, const float* beta, const float* mask, int C,
                                 int B, int L, int Ls, float eps, hipStream_t st) {
-    hipLaunchKernelGGL(enc_layernorm_kernel, dim3((L + 63) / 64, B), dim3(64), 0, st, x, y, g, beta, mask, C, L, Ls, eps);
+    hipLaunchKernelGGL(enc_layernorm_kernel, dim3((L + 63) / 64, B), dim3(64 * ELN_WAVES), 0, st, x, y, g, beta, mask, C,
+                       L, Ls, eps);
     return hipGetLastError();
 }
 
