@@ -145,6 +145,56 @@ def fs2_acoustic_param_shapes(vocab_size, hidden_size=256, enc_layers=4, num_hea
     return shapes
 
 
+NSF_HIFIGAN_DEFAULT = dict(       # the openvpi 44.1 kHz / hop 512 NSF-HiFiGAN layout (config.json ships with the checkpoint)
+    sampling_rate=44100, num_mels=128, hop_size=512, upsample_rates=[8, 8, 2, 2, 2],
+    upsample_kernel_sizes=[16, 16, 4, 4, 4], upsample_initial_channel=512, resblock="1",
+    resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], mini_nsf=False,
+    noise_sigma=0.0)
+
+
+def nsf_hifigan_param_shapes(h):
+    """state_dict of modules/nsf_hifigan/models.py:207-260 (Generator, mini_nsf = False) in its inference form,
+    i.e. after `remove_weight_norm()`: plain `weight` / `bias` everywhere."""
+    shapes = OrderedDict()
+    shapes["m_source.l_linear.weight"] = (1, 9)
+    shapes["m_source.l_linear.bias"] = (1,)
+    ch = h["upsample_initial_channel"]
+    rates = list(h["upsample_rates"])
+    noise = OrderedDict()
+    ups = OrderedDict()
+    res = OrderedDict()
+    nk = len(h["resblock_kernel_sizes"])
+    for i, (u, k) in enumerate(zip(rates, h["upsample_kernel_sizes"])):
+        ch //= 2
+        ups[f"ups.{i}.weight"] = (2 * ch, ch, k)
+        ups[f"ups.{i}.bias"] = (ch,)
+        for j, (rk, rd) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
+            pre = f"resblocks.{i * nk + j}."
+            if str(h.get("resblock", "1")) == "1":
+                for grp in ("convs1", "convs2"):
+                    for d in range(len(rd)):
+                        res[f"{pre}{grp}.{d}.weight"] = (ch, ch, rk)
+                        res[f"{pre}{grp}.{d}.bias"] = (ch,)
+            else:
+                for d in range(len(rd)):
+                    res[f"{pre}convs.{d}.weight"] = (ch, ch, rk)
+                    res[f"{pre}convs.{d}.bias"] = (ch,)
+        if i + 1 < len(rates):
+            sf = int(np.prod(rates[i + 1:]))
+            noise[f"noise_convs.{i}.weight"] = (ch, 1, sf * 2)
+        else:
+            noise[f"noise_convs.{i}.weight"] = (ch, 1, 1)
+        noise[f"noise_convs.{i}.bias"] = (ch,)
+    shapes.update(noise)
+    shapes["conv_pre.weight"] = (h["upsample_initial_channel"], h["num_mels"], 7)
+    shapes["conv_pre.bias"] = (h["upsample_initial_channel"],)
+    shapes.update(ups)
+    shapes.update(res)
+    shapes["conv_post.weight"] = (1, ch, 7)
+    shapes["conv_post.bias"] = (1,)
+    return shapes
+
+
 def backbone_param_shapes(kind, in_dims, n_feats, hidden_size=256, **args):
     if kind == "wavenet":
         return wavenet_param_shapes(in_dims, n_feats, num_layers=args.get("num_layers", 20),
@@ -159,9 +209,9 @@ def backbone_param_shapes(kind, in_dims, n_feats, hidden_size=256, **args):
     raise KeyError(kind)
 
 
-def synth_state_dict(shapes, seed=42):
-    """name -> float32 ndarray.  Fan-in scaled normals for matrices, N(0, 0.1) biases,
-    LayerNorm gains around 1, PReLU slopes around 0.25."""
+def synth_state_dict(shapes, seed=42, gain=1.0):
+    """name -> float32 ndarray.  Fan-in scaled normals for matrices (times `gain`: < 1 keeps deep residual stacks
+    such as the vocoder's in the O(1) range), N(0, 0.1) biases, LayerNorm gains around 1, PReLU slopes around 0.25."""
     rng = np.random.Generator(np.random.PCG64(seed))
     out = OrderedDict()
     for name, shape in shapes.items():
@@ -186,7 +236,7 @@ def synth_state_dict(shapes, seed=42):
             w = 0.1 * z
         else:
             fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
-            w = z / np.sqrt(np.float32(fan_in))
+            w = np.float32(gain) * z / np.sqrt(np.float32(fan_in))
         out[name] = np.ascontiguousarray(w, dtype=np.float32)
     return out
 

@@ -618,8 +618,54 @@ def g9_acoustic_model():
     save("g9_acoustic_model", **out)
 
 
+# --------------------------------------------------------------------------- G10: NSF-HiFiGAN generator, mel + f0 -> wav
+VOC_CASES = {
+    # tag: (config overrides, B, T, weight seed)
+    "default": (dict(), 2, 10, 300),
+    "small_rb2": (dict(num_mels=32, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4],
+                       upsample_initial_channel=64, resblock="2", resblock_kernel_sizes=[3, 5],
+                       resblock_dilation_sizes=[[1, 2], [2, 6]], hop_size=16), 2, 37, 301),
+}
+VOC_GAIN = 0.7
+
+
+def g10_vocoder():
+    from modules.nsf_hifigan.models import Generator  # (reference)
+    from modules.nsf_hifigan.env import AttrDict  # (reference)
+    out = {}
+    for tag, (over, bsz, t_len, wseed) in VOC_CASES.items():
+        h = dict(synth.NSF_HIFIGAN_DEFAULT)
+        h.update(over)
+        gen = Generator(AttrDict(h))
+        gen.remove_weight_norm()
+        sd = synth.synth_state_dict(synth.nsf_hifigan_param_shapes(h), seed=wseed, gain=VOC_GAIN)
+        gen.load_state_dict({k: to_t(v) for k, v in sd.items()}, strict=True)
+        gen.eval()
+        upp = int(np.prod(h["upsample_rates"]))
+        mel = (synth.synth_normal((bsz, t_len, h["num_mels"]), wseed + 1) * 1.5 - 5.0).astype(np.float32)   # log10 mel
+        rng = np.random.Generator(np.random.PCG64(wseed + 2))
+        f0 = (220.0 * 2.0 ** rng.uniform(-1, 1, (bsz, t_len))).astype(np.float32)
+        f0[:, : t_len // 4] = 0.0                                         # an unvoiced stretch
+        rand_ini = rng.random(9).astype(np.float32)
+        noise = synth.synth_normal((bsz, t_len * upp, 9), wseed + 3)
+        orig_rand, orig_randn_like = torch.rand, torch.randn_like
+        torch.rand = lambda *a, **k: to_t(rand_ini).reshape(1, 1, 9).clone()
+        torch.randn_like = lambda x, **k: to_t(noise).clone()
+        try:
+            with torch.no_grad():
+                c = 2.30259 * to_t(mel).transpose(2, 1)                   # vocoders/nsf_hifigan.py:59-64
+                wav = gen(c, to_t(f0)).numpy()
+        finally:
+            torch.rand, torch.randn_like = orig_rand, orig_randn_like
+        out[f"{tag}_meta"] = np.array([bsz, t_len, wseed, upp], dtype=np.int64)
+        out[f"{tag}_f0"], out[f"{tag}_rand_ini"] = f0, rand_ini
+        out[f"{tag}_wav"] = wav
+        print(f"  vocoder {tag}: wav {wav.shape} absmax={np.abs(wav).max():.3f} std={wav.std():.4f}")
+    save("g10_vocoder", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -636,3 +682,5 @@ if __name__ == "__main__":
         g8_encoder()
     if "g9" in which:
         g9_acoustic_model()
+    if "g10" in which:
+        g10_vocoder()

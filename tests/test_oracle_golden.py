@@ -410,3 +410,36 @@ def test_g9_acoustic_model_tokens_to_mel(tag):
     aux_mel, mel = oa.acoustic_infer(aux, d, cond, g["mel2ph"], noise, smin, smax, m, **kw)
     assert rel_err(aux_mel, g[f"{tag}_aux"]) < 2e-5
     assert rel_err(mel, g[f"{tag}_mel"]) < 2e-4
+
+
+# --------------------------------------------------------------------------- G10 (section 8(f) rank 3)
+from oracle import vocoder as ov  # noqa: E402
+
+VOC_OVER = {
+    "default": dict(),
+    "small_rb2": dict(num_mels=32, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4], upsample_initial_channel=64,
+                      resblock="2", resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2], [2, 6]], hop_size=16),
+}
+VOC_GAIN = 0.7
+
+
+def voc_case(g, tag):
+    bsz, t_len, wseed, upp = (int(v) for v in g[f"{tag}_meta"])
+    h = dict(synth.NSF_HIFIGAN_DEFAULT)
+    h.update(VOC_OVER[tag])
+    params = synth.synth_state_dict(synth.nsf_hifigan_param_shapes(h), seed=wseed, gain=VOC_GAIN)
+    mel = (synth.synth_normal((bsz, t_len, h["num_mels"]), wseed + 1) * 1.5 - 5.0).astype(np.float32)
+    noise = synth.synth_normal((bsz, t_len * upp, 9), wseed + 3)
+    return h, params, mel, g[f"{tag}_f0"], g[f"{tag}_rand_ini"], noise
+
+
+@pytest.mark.parametrize("tag", sorted(VOC_OVER))
+def test_g10_nsf_hifigan_generator(tag):
+    """NSF-HiFiGAN generator restatement (sine source with injected phases/noise, transposed-conv upsampling, noise
+    convs, ResBlock1/2, tanh) vs the reference; tolerance 5e-5 of the waveform range."""
+    g = load("g10_vocoder")
+    h, params, mel, f0, rand_ini, noise = voc_case(g, tag)
+    wav = ov.spec2wav(params, h, mel, f0, rand_ini, noise)
+    want = g[f"{tag}_wav"].reshape(-1)
+    assert wav.shape == want.shape
+    assert rel_err(wav, want) < 5e-5
