@@ -24,7 +24,7 @@ ACT_IDS = {"PReLU": 0, "SiLU": 1, "ReLU": 2}
 EXPORTS = [
     "dsd_api_version", "dsd_create", "dsd_destroy", "dsd_last_error", "dsd_load_weight",
     "dsd_finalize_weights", "dsd_prepare_cond", "dsd_denoise", "dsd_sample", "dsd_get_stats",
-    "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode",
+    "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode", "dsd_vocoder_create", "dsd_vocode",
 ]
 EMBED_FLAGS = {"energy": 1, "breathiness": 2, "voicing": 4, "tension": 8, "key_shift": 16, "speed": 32}
 
@@ -39,6 +39,14 @@ class DsdEncoderConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("vocab_size", C.c_int32), ("hidden_size", C.c_int32),
                 ("enc_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_kernel_size", C.c_int32),
                 ("num_spk", C.c_int32), ("num_lang", C.c_int32), ("embed_flags", C.c_uint32), ("device", C.c_int32)]
+
+
+class DsdVocoderConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("num_mels", C.c_int32), ("sampling_rate", C.c_int32),
+                ("upsample_initial_channel", C.c_int32), ("n_ups", C.c_int32), ("upsample_rates", C.c_int32 * 8),
+                ("upsample_kernel_sizes", C.c_int32 * 8), ("resblock", C.c_int32), ("n_kernels", C.c_int32),
+                ("resblock_kernel_sizes", C.c_int32 * 8), ("n_dilations", C.c_int32 * 8),
+                ("resblock_dilation_sizes", (C.c_int32 * 4) * 8), ("harmonic_num", C.c_int32), ("device", C.c_int32)]
 
 
 class DsdEncodeExtras(C.Structure):
@@ -100,6 +108,8 @@ def _load():
     lib.dsd_denoise.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.dsd_sample.argtypes = [vp, C.POINTER(DsdProgram), vp, vp, vp, vp, vp, C.c_uint32, vp]
     lib.dsd_aux_decode.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, vp, vp, vp]
+    lib.dsd_vocoder_create.argtypes = [C.POINTER(DsdVocoderConfig), C.POINTER(vp)]
+    lib.dsd_vocode.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp]
     lib.dsd_encoder_create.argtypes = [C.POINTER(DsdEncoderConfig), C.POINTER(vp)]
     lib.dsd_encode.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.POINTER(DsdEncodeExtras), vp, vp]
     lib.dsd_get_stats.argtypes = [vp, C.POINTER(DsdStats)]
@@ -107,7 +117,7 @@ def _load():
     lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     for name in EXPORTS:
         getattr(lib, name)
-    if lib.dsd_api_version() != 3:
+    if lib.dsd_api_version() != 4:
         raise NativeLibraryError("libdsdenoise.so API version mismatch")
     return lib
 

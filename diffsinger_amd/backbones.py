@@ -82,7 +82,8 @@ class _NativeBackbone(nn.Module):
         if self._handle is None:
             cfg = self._config(idx)
             hp = C.c_void_p()
-            create = lib.dsd_encoder_create if isinstance(cfg, _lib.DsdEncoderConfig) else lib.dsd_create
+            create = (lib.dsd_encoder_create if isinstance(cfg, _lib.DsdEncoderConfig) else
+                      lib.dsd_vocoder_create if isinstance(cfg, _lib.DsdVocoderConfig) else lib.dsd_create)
             rc = create(C.byref(cfg), C.byref(hp))
             if rc != 0:
                 raise _lib.NativeLibraryError(f"dsd_create failed ({rc}): {lib.dsd_last_error(None).decode()}")

@@ -59,6 +59,18 @@ struct dsd_handle {
     std::vector<PackedGemm> g_pw1, g_pw2;            // LYNXNet per layer
     std::vector<size_t> dw_w, dw_b, dw_prelu;        // LYNXNet / ConvNeXt depthwise params (float offsets)
     PackedGemm g_ain, g_aout;                        // ConvNeXt aux decoder: dense k-tap in/out convs
+    // NSF-HiFiGAN generator
+    dsd_vocoder_config vcfg;
+    PackedGemm v_pre, v_post;
+    std::vector<PackedGemm> v_ups;                   // transposed convs as phase-row GEMMs
+    std::vector<std::vector<PackedGemm>> v_res;      // [stage * n_kernels + j][2 * n_dil (ResBlock1) or n_dil]
+    std::vector<size_t> v_nw, v_nb;                  // noise conv weights / biases
+    std::vector<int> v_uptaps;
+    size_t v_linw = 0, v_linb = 0;
+    int vB = 0, vT = 0;
+    float* v_arena = nullptr;
+    std::vector<float*> v_buf;                       // per stage: x, t1, r, acc
+    float *v_mel = nullptr, *v_pre_out = nullptr, *v_har = nullptr, *v_phase = nullptr, *v_wav = nullptr;
     // FastSpeech2 acoustic encoder
     dsd_encoder_config ecfg;
     std::vector<PackedGemm> g_qkv, g_oproj, g_ffn1, g_ffn2;
@@ -128,6 +140,50 @@ inline int inner_of(const dsd_handle* h) { return h->cfg.num_channels * h->cfg.e
 inline bool is_wavenet(const dsd_handle* h) { return h->cfg.backbone == DSD_BACKBONE_WAVENET; }
 inline bool is_aux(const dsd_handle* h) { return h->cfg.backbone == DSD_AUX_CONVNEXT; }
 inline bool is_enc(const dsd_handle* h) { return h->cfg.backbone == DSD_ENC_FS2_ACOUSTIC; }
+inline bool is_voc(const dsd_handle* h) { return h->cfg.backbone == DSD_VOC_NSF_HIFIGAN; }
+
+inline int voc_stage_channels(const dsd_vocoder_config& v, int i) { return v.upsample_initial_channel >> (i + 1); }
+inline long voc_upp(const dsd_vocoder_config& v, int from) {     // product of upsample_rates[from:]
+    long p = 1;
+    for (int i = from; i < v.n_ups; ++i) p *= v.upsample_rates[i];
+    return p;
+}
+
+// Generator state_dict after remove_weight_norm()  (nsf_hifigan/models.py:207-260)
+std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_voc(const dsd_vocoder_config& v) {
+    std::vector<std::pair<std::string, std::vector<int64_t>>> out;
+    auto add = [&](const std::string& n, std::vector<int64_t> s) { out.emplace_back(n, std::move(s)); };
+    add("m_source.l_linear.weight", {1, v.harmonic_num + 1});
+    add("m_source.l_linear.bias", {1});
+    add("conv_pre.weight", {v.upsample_initial_channel, v.num_mels, 7});
+    add("conv_pre.bias", {v.upsample_initial_channel});
+    for (int i = 0; i < v.n_ups; ++i) {
+        const int64_t ch = voc_stage_channels(v, i);
+        add("ups." + std::to_string(i) + ".weight", {2 * ch, ch, v.upsample_kernel_sizes[i]});
+        add("ups." + std::to_string(i) + ".bias", {ch});
+        const int64_t nk = i + 1 < v.n_ups ? 2 * voc_upp(v, i + 1) : 1;
+        add("noise_convs." + std::to_string(i) + ".weight", {ch, 1, nk});
+        add("noise_convs." + std::to_string(i) + ".bias", {ch});
+        for (int j = 0; j < v.n_kernels; ++j) {
+            const std::string p = "resblocks." + std::to_string(i * v.n_kernels + j) + ".";
+            for (int d = 0; d < v.n_dilations[j]; ++d) {
+                const int64_t k = v.resblock_kernel_sizes[j];
+                if (v.resblock == 1) {
+                    add(p + "convs1." + std::to_string(d) + ".weight", {ch, ch, k});
+                    add(p + "convs1." + std::to_string(d) + ".bias", {ch});
+                    add(p + "convs2." + std::to_string(d) + ".weight", {ch, ch, k});
+                    add(p + "convs2." + std::to_string(d) + ".bias", {ch});
+                } else {
+                    add(p + "convs." + std::to_string(d) + ".weight", {ch, ch, k});
+                    add(p + "convs." + std::to_string(d) + ".bias", {ch});
+                }
+            }
+        }
+    }
+    add("conv_post.weight", {1, voc_stage_channels(v, v.n_ups - 1), 7});
+    add("conv_post.bias", {1});
+    return out;
+}
 
 const char* const kLinNames[7] = {"pitch_embed", "variance_embeds.energy", "variance_embeds.breathiness",
                                   "variance_embeds.voicing", "variance_embeds.tension", "key_shift_embed", "speed_embed"};
@@ -414,9 +470,80 @@ int build_packed_enc(dsd_handle* h) {
     return DSD_OK;
 }
 
+// NSF-HiFiGAN generator.  A ConvTranspose1d(C_in, C_out, K, stride u, padding (K-u)/2) becomes an ordinary odd-tap
+// convolution at the INPUT resolution with u * C_out output rows - row r*C_out + o is output phase r of channel o:
+//   y[o][u q + r] = sum_i sum_n W[i][o][k0 + u n] x[i][q + e - n],   k0 = (r + pad) mod u,  e = (r + pad) div u
+// so tap a (input offset d = a - D) of phase row (r, o) holds W[i][o][k0 + u (e - d)] when that index is a valid
+// kernel position and zero otherwise; the GEMM's scatter epilogue writes column q of row (r, o) to out[o][u q + r].
+int build_packed_voc(dsd_handle* h) {
+    const dsd_vocoder_config& v = h->vcfg;
+    h->blob_host.clear();
+    auto copy_vec = [&](const std::string& name) {
+        const auto& d = W(h, name).data;
+        const size_t off = blob_reserve(h, d.size());
+        memcpy(h->blob_host.data() + off, d.data(), sizeof(float) * d.size());
+        return off;
+    };
+    auto dense = [&](const std::string& name, int rows, int cin, int ks) {
+        const HostTensor* t = &W(h, name + ".weight");
+        const HostTensor* b = &W(h, name + ".bias");
+        WGet w = [t, cin, ks](int r, int k, int tap) { return (double)t->data[((size_t)r * cin + k) * ks + tap]; };
+        std::function<double(int)> bf = [b](int i) { return (double)b->data[i]; };
+        return pack_gemm(h, rows, cin, ks, 0, w, &bf);
+    };
+    h->v_linw = copy_vec("m_source.l_linear.weight");
+    h->v_linb = copy_vec("m_source.l_linear.bias");
+    h->v_pre = dense("conv_pre", v.upsample_initial_channel, v.num_mels, 7);
+    h->v_ups.resize(v.n_ups);
+    h->v_uptaps.resize(v.n_ups);
+    h->v_nw.resize(v.n_ups);
+    h->v_nb.resize(v.n_ups);
+    h->v_res.assign((size_t)v.n_ups * v.n_kernels, {});
+    for (int i = 0; i < v.n_ups; ++i) {
+        const int ch = voc_stage_channels(v, i), u = v.upsample_rates[i], K = v.upsample_kernel_sizes[i], pad = (K - u) / 2;
+        int D = 0;
+        for (int r = 0; r < u; ++r) {
+            const int k0 = (r + pad) % u, e = (r + pad) / u, nmax = (K - 1 - k0) / u;
+            D = std::max(D, std::max(e, nmax - e));
+        }
+        const int taps = 2 * D + 1;
+        h->v_uptaps[i] = taps;
+        const HostTensor* t = &W(h, "ups." + std::to_string(i) + ".weight");      // [2ch, ch, K]
+        const HostTensor* b = &W(h, "ups." + std::to_string(i) + ".bias");
+        WGet w = [t, ch, u, K, pad, D](int row, int ci, int a) {
+            const int r = row / ch, o = row % ch;
+            const int k0 = (r + pad) % u, e = (r + pad) / u;
+            const int n = e - (a - D);
+            const int k = k0 + u * n;
+            if (n < 0 || k >= K) return 0.0;
+            return (double)t->data[((size_t)ci * ch + o) * K + k];
+        };
+        h->v_ups[i] = pack_gemm(h, u * ch, 2 * ch, taps, 0, w, nullptr);
+        h->v_ups[i].bias_off = blob_reserve(h, (size_t)ch);
+        memcpy(h->blob_host.data() + h->v_ups[i].bias_off, b->data.data(), sizeof(float) * ch);
+        h->v_nw[i] = copy_vec("noise_convs." + std::to_string(i) + ".weight");
+        h->v_nb[i] = copy_vec("noise_convs." + std::to_string(i) + ".bias");
+        for (int j = 0; j < v.n_kernels; ++j) {
+            const std::string p = "resblocks." + std::to_string(i * v.n_kernels + j) + ".";
+            auto& list = h->v_res[(size_t)i * v.n_kernels + j];
+            for (int d = 0; d < v.n_dilations[j]; ++d) {
+                if (v.resblock == 1) {
+                    list.push_back(dense(p + "convs1." + std::to_string(d), ch, ch, v.resblock_kernel_sizes[j]));
+                    list.push_back(dense(p + "convs2." + std::to_string(d), ch, ch, v.resblock_kernel_sizes[j]));
+                } else {
+                    list.push_back(dense(p + "convs." + std::to_string(d), ch, ch, v.resblock_kernel_sizes[j]));
+                }
+            }
+        }
+    }
+    h->v_post = dense("conv_post", 1, voc_stage_channels(v, v.n_ups - 1), 7);
+    return DSD_OK;
+}
+
 int build_packed(dsd_handle* h) {
     if (is_aux(h)) return build_packed_aux(h);
     if (is_enc(h)) return build_packed_enc(h);
+    if (is_voc(h)) return build_packed_voc(h);
     const dsd_config& c = h->cfg;
     const int C = c.num_channels, M = FM_of(h), H = c.hidden_size, L = c.num_layers;
     h->blob_host.clear();
@@ -692,8 +819,9 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     const long wg64 = (long)batch * ((T + 63) / 64) * mtiles;
     static const long nb2_min = getenv("DSD_NB2_MIN_WG") ? atol(getenv("DSD_NB2_MIN_WG")) : 512;     // diagnostic override
     c.nb = wg64 >= nb2_min ? 2 : 1;
-    // a k > 3 conv keeps all input channels resident (generic path): 64-frame tiles only while that fits in LDS
-    if (g.taps > 3 && (size_t)g.K * (64 + 2 * round_up((g.taps / 2) * dil, 4) + 16) * 4 > 150 * 1024) c.nb = 1;
+    // a conv on the generic path keeps all input channels resident: 64-frame tiles only while that fits in LDS
+    if ((g.taps > 3 || (generic_only && g.taps > 1)) &&
+        (size_t)g.K * (64 + 2 * round_up((g.taps / 2) * dil, 4) + 16) * 4 > 150 * 1024) c.nb = 1;
     // narrow tiles (64 rows x 16 frames, c.nb == 0): when 32-frame tiles would put at most ~1.5 workgroups on a CU,
     // twice as many half-size workgroups share each SIMD between two waves and halve the latency of a lone one
     if (c.nb == 1) {
@@ -733,6 +861,9 @@ int run_gemm(dsd_handle* h, const GemmCall& c, hipStream_t st) {
     if (c.p.lds_bytes > 160 * 1024)
         return fail(h, DSD_EINVAL, "GEMM tile needs %d bytes of LDS (> 160 KiB): %d input channels x k=%d at dilation %d "
                     "is outside the supported shapes", c.p.lds_bytes, c.p.K, c.taps, c.p.dil);
+    if ((long)c.batch * c.p.tiles_per_b * c.p.mtiles >= (1L << 22))
+        return fail(h, DSD_EINVAL, "GEMM grid of %ld workgroups exceeds 2^22 (batch %d x %d frame tiles x %d row tiles): "
+                    "split the batch", (long)c.batch * c.p.tiles_per_b * c.p.mtiles, c.batch, c.p.tiles_per_b, c.p.mtiles);
     hipError_t e = launch_gemm(c.p, c.stage, c.taps, c.epi, c.nb, c.fast, c.batch, st);
     if (e != hipSuccess) return fail(h, DSD_EHIP, "GEMM launch failed: %s", hipGetErrorString(e));
     return DSD_OK;
@@ -936,6 +1067,7 @@ void dsd_destroy(dsd_handle* h) {
     if (h->state) (void)hipFree(h->state);
     if (h->emb_arena) (void)hipFree(h->emb_arena);
     if (h->e_arena) (void)hipFree(h->e_arena);
+    if (h->v_arena) (void)hipFree(h->v_arena);
     delete h;
 }
 
@@ -945,12 +1077,12 @@ int dsd_load_weight(dsd_handle* h, const char* name, const float* data, const in
     const std::string n(name);
     std::vector<int64_t> shp(shape, shape + ndim);
     bool found = false;
-    if (n == "diffusion_embedding.freqs" && !is_enc(h)) {
+    if (n == "diffusion_embedding.freqs" && !is_enc(h) && !is_voc(h)) {
         if (ndim != 1 || shp[0] != h->cfg.num_channels / 2)
             return fail(h, DSD_EINVAL, "diffusion_embedding.freqs must have shape [%d]", h->cfg.num_channels / 2);
         found = true;
     } else {
-        for (auto& e : (is_enc(h) ? expected_params_enc(h->ecfg) : expected_params(h->cfg))) {
+        for (auto& e : (is_enc(h) ? expected_params_enc(h->ecfg) : is_voc(h) ? expected_params_voc(h->vcfg) : expected_params(h->cfg))) {
             if (e.first != n) continue;
             if (e.second != shp) {
                 std::string want, got;
@@ -982,7 +1114,7 @@ int dsd_load_weight(dsd_handle* h, const char* name, const float* data, const in
 int dsd_finalize_weights(dsd_handle* h) {
     if (!h) return DSD_EINVAL;
     std::string missing;
-    for (auto& e : (is_enc(h) ? expected_params_enc(h->ecfg) : expected_params(h->cfg)))
+    for (auto& e : (is_enc(h) ? expected_params_enc(h->ecfg) : is_voc(h) ? expected_params_voc(h->vcfg) : expected_params(h->cfg)))
         if (!h->raw.count(e.first)) missing += (missing.empty() ? "" : ", ") + e.first;
     if (!missing.empty()) return fail(h, DSD_ESTATE, "missing keys in state_dict: %s", missing.c_str());
     HIP_OK(h, hipSetDevice(h->cfg.device));
@@ -1007,6 +1139,7 @@ int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int
     if (!h || !cond) return fail(h, DSD_EINVAL, "dsd_prepare_cond: null argument");
     if (is_aux(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is an aux decoder (use dsd_aux_decode)");
     if (is_enc(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is an encoder (use dsd_encode)");
+    if (is_voc(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is a vocoder (use dsd_vocode)");
     if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_prepare_cond: weights are not finalized");
     if (B < 1 || T < 1) return fail(h, DSD_EINVAL, "dsd_prepare_cond: B and T must be positive (B=%d, T=%d)", B, T);
     if (stride_t != 1 && stride_h != 1)
@@ -1165,6 +1298,181 @@ int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, 
     }
     ENC_OK(launch_enc_expand(h->e_y, (const long long*)mel2ph, a, H, B, L, Ls, T, cond_out, st), "expand");
 #undef ENC_OK
+    return DSD_OK;
+}
+
+int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out) {
+    if (!cfg || !out) return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(dsd_vocoder_config))
+        return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: struct_size %d != %zu", cfg->struct_size, sizeof(dsd_vocoder_config));
+    if (cfg->num_mels < 1 || cfg->sampling_rate < 1 || cfg->n_ups < 1 || cfg->n_ups > DSD_VOC_MAX_UPS || cfg->n_kernels < 1 ||
+        cfg->n_kernels > DSD_VOC_MAX_KERNELS || (cfg->resblock != 1 && cfg->resblock != 2))
+        return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: bad layer counts");
+    if (cfg->harmonic_num < 0 || cfg->harmonic_num > 15) return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: harmonic_num must be in [0, 15]");
+    if (cfg->upsample_initial_channel % (1 << cfg->n_ups) != 0 || (cfg->upsample_initial_channel >> cfg->n_ups) < 1)
+        return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: upsample_initial_channel must be divisible by 2^n_ups");
+    for (int i = 0; i < cfg->n_ups; ++i) {
+        const int u = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
+        if (u < 1 || k < u || (k - u) % 2 != 0 || k > 8 * u)
+            return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: upsample stage %d (rate %d, kernel %d) is not supported", i, u, k);
+    }
+    for (int j = 0; j < cfg->n_kernels; ++j) {
+        if (cfg->resblock_kernel_sizes[j] < 1 || cfg->resblock_kernel_sizes[j] % 2 == 0 || cfg->resblock_kernel_sizes[j] > 15 ||
+            cfg->n_dilations[j] < 1 || cfg->n_dilations[j] > DSD_VOC_MAX_DILS)
+            return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: residual block %d: odd kernel <= 15 and 1..%d dilations", j, DSD_VOC_MAX_DILS);
+        for (int d = 0; d < cfg->n_dilations[j]; ++d)
+            if (cfg->resblock_dilation_sizes[j][d] < 1 || cfg->resblock_dilation_sizes[j][d] * (cfg->resblock_kernel_sizes[j] / 2) > 48)
+                return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: residual block %d dilation %d reaches beyond 48 frames", j, d);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, DSD_EHIP, "dsd_vocoder_create: no HIP device is visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: device %d out of range [0, %d)", cfg->device, ndev);
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_vocoder_create: hipSetDevice failed");
+    hipError_t ie = gemm_init_all();
+    if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_vocoder_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
+    dsd_handle* h = new dsd_handle();
+    memset(&h->cfg, 0, sizeof(h->cfg));
+    h->cfg.struct_size = sizeof(dsd_config);
+    h->cfg.backbone = DSD_VOC_NSF_HIFIGAN;
+    h->cfg.in_dims = cfg->num_mels;
+    h->cfg.n_feats = 1;
+    h->cfg.num_layers = cfg->n_ups;
+    h->cfg.num_channels = cfg->upsample_initial_channel;
+    h->cfg.hidden_size = cfg->num_mels;
+    h->cfg.device = cfg->device;
+    h->vcfg = *cfg;
+    *out = h;
+    return DSD_OK;
+}
+
+int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_m, int64_t stride_t,
+               const float* f0, const float* rand_ini, const float* noise, float* wav_out, void* stream) {
+    if (!h || !mel || !f0 || !rand_ini || !noise || !wav_out) return fail(h, DSD_EINVAL, "dsd_vocode: null argument");
+    if (!is_voc(h)) return fail(h, DSD_ESTATE, "dsd_vocode: this handle is not a vocoder");
+    if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_vocode: weights are not finalized");
+    if (B < 1 || T < 1) return fail(h, DSD_EINVAL, "dsd_vocode: B and T must be positive (B=%d, T=%d)", B, T);
+    if (stride_t != 1 && stride_m != 1)
+        return fail(h, DSD_EINVAL, "dsd_vocode: mel must be contiguous along T ([B,M,T]) or along M ([B,T,M])");
+    const dsd_vocoder_config& v = h->vcfg;
+    const long upp = voc_upp(v, 0);
+    if ((long)T * upp > (1L << 28)) return fail(h, DSD_EINVAL, "dsd_vocode: %ld output samples per utterance is too long", (long)T * upp);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(h, hipSetDevice(v.device));
+    const int NU = v.n_ups, C0 = v.upsample_initial_channel, Ts0 = padded_ts(T);
+    // stage lengths
+    std::vector<long> len(NU + 1);
+    std::vector<int> lts(NU + 1);
+    len[0] = T;
+    for (int i = 0; i < NU; ++i) len[i + 1] = len[i] * v.upsample_rates[i];
+    for (int i = 0; i <= NU; ++i) lts[i] = padded_ts((int)len[i]);
+    if (!h->v_arena || h->vB != B || h->vT != T) {
+        if (h->v_arena) (void)hipFree(h->v_arena);
+        h->v_arena = nullptr;
+        size_t off = kGuard;
+        auto take = [&](size_t n) {
+            size_t o = off;
+            off += (n + 63) / 64 * 64 + 64;
+            return o;
+        };
+        const size_t o_mel = take((size_t)B * v.num_mels * Ts0), o_pre = take((size_t)B * C0 * Ts0);
+        const size_t o_har = take((size_t)B * lts[NU]), o_ph = take((size_t)B * T), o_wav = take((size_t)B * lts[NU]);
+        std::vector<size_t> ob;
+        for (int i = 0; i < NU; ++i) {
+            const size_t n = (size_t)B * voc_stage_channels(v, i) * lts[i + 1];
+            for (int k = 0; k < 4; ++k) ob.push_back(take(n));
+        }
+        off += kGuard;
+        float* a = nullptr;
+        if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
+            return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the vocoder workspace failed", off * 4);
+        if (hipMemset(a, 0, off * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(vocoder workspace) failed");
+        h->v_arena = a;
+        h->vB = B; h->vT = T;
+        h->v_mel = a + o_mel; h->v_pre_out = a + o_pre; h->v_har = a + o_har; h->v_phase = a + o_ph; h->v_wav = a + o_wav;
+        h->v_buf.clear();
+        for (size_t o : ob) h->v_buf.push_back(a + o);
+    }
+    const float* blob = h->blob;
+    hipError_t er;
+    int rc;
+#define VOC_OK(expr, what)                                                                        \
+    if ((er = (expr)) != hipSuccess) return fail(h, DSD_EHIP, what " launch failed: %s", hipGetErrorString(er))
+    // harmonic-plus-noise source at the output rate  (models.py:120-168, 200-203, 266)
+    VOC_OK(launch_voc_source(f0, rand_ini, noise, blob + h->v_linw, blob + h->v_linb, B, T, (int)upp, v.harmonic_num + 1,
+                             (float)v.sampling_rate, 0.1f, 0.003f, h->v_phase, lts[NU], h->v_har, st), "source");
+    // conv_pre  (models.py:227, 267)
+    VOC_OK(launch_pack(mel, stride_b, stride_m, stride_t, h->v_mel, B, v.num_mels, T, Ts0, st), "pack(mel)");
+    {
+        GemmCall g = make_gemm(h, h->v_pre, h->v_mel, (long)v.num_mels * Ts0, Ts0, B, T, ST_PLAIN, EP_BIAS_ACT, 1, true);
+        g.p.act = ACT_NONE; g.p.out = h->v_pre_out; g.p.o_bstride = (long)C0 * Ts0; g.p.o_rstride = Ts0;
+        if ((rc = run_gemm(h, g, st))) return rc;
+    }
+    const float* cur = h->v_pre_out;
+    int cur_c = C0;
+    for (int i = 0; i < NU; ++i) {
+        const int ch = voc_stage_channels(v, i), u = v.upsample_rates[i];
+        const int Tin = (int)len[i], Tsi = lts[i], Tq = (int)len[i + 1], Tsq = lts[i + 1];
+        float* x = h->v_buf[4 * i + 0];
+        float* t1 = h->v_buf[4 * i + 1];
+        float* r = h->v_buf[4 * i + 2];
+        float* acc = h->v_buf[4 * i + 3];
+        const long xs = (long)ch * Tsq;
+        {   // leaky_relu -> ConvTranspose1d  (models.py:271-272)
+            GemmCall g = make_gemm(h, h->v_ups[i], cur, (long)cur_c * Tsi, Tsi, B, Tin, ST_LRELU, EP_SCATTER, 1, true);
+            g.p.in_scale = 0.1f; g.p.C = ch; g.p.up = u;
+            g.p.out = x; g.p.o_bstride = xs; g.p.o_rstride = Tsq;
+            if ((rc = run_gemm(h, g, st))) return rc;
+        }
+        {   // + noise_convs[i](har_source)  (models.py:274-276)
+            const int sf = (int)voc_upp(v, i + 1);
+            const int ksz = i + 1 < NU ? 2 * sf : 1;
+            VOC_OK(launch_voc_noise_conv(x, h->v_har, blob + h->v_nw[i], blob + h->v_nb[i], B, ch, Tq, Tsq, sf, ksz,
+                                         len[NU], lts[NU], st), "noise conv");
+        }
+        for (int j = 0; j < v.n_kernels; ++j) {     // residual blocks  (models.py:280-286; ResBlock1 :62-69, ResBlock2 :92-97)
+            const auto& cv = h->v_res[(size_t)i * v.n_kernels + j];
+            for (int d = 0; d < v.n_dilations[j]; ++d) {
+                const float* src = d == 0 ? x : r;
+                const int dil = v.resblock_dilation_sizes[j][d];
+                if (v.resblock == 1) {
+                    GemmCall c1 = make_gemm(h, cv[2 * d], src, xs, Tsq, B, Tq, ST_LRELU, EP_BIAS_ACT, dil, true);
+                    c1.p.in_scale = 0.1f; c1.p.act = ACT_LRELU;
+                    c1.p.out = t1; c1.p.o_bstride = xs; c1.p.o_rstride = Tsq;
+                    if ((rc = run_gemm(h, c1, st))) return rc;
+                    GemmCall c2 = make_gemm(h, cv[2 * d + 1], t1, xs, Tsq, B, Tq, ST_PLAIN, EP_BIAS_RES, 1, true);
+                    c2.p.aux = src; c2.p.aux_bstride = xs; c2.p.aux_rstride = Tsq;
+                    c2.p.out = r; c2.p.o_bstride = xs; c2.p.o_rstride = Tsq;
+                    if ((rc = run_gemm(h, c2, st))) return rc;
+                } else {
+                    // xt + x with x read both as the (leaky-ReLU'd) conv input and as the residual: the output goes to
+                    // the other buffer, the conv's halo reads must not see this launch's own stores
+                    float* dst = (src == x || src == t1) ? r : t1;
+                    GemmCall c1 = make_gemm(h, cv[d], src, xs, Tsq, B, Tq, ST_LRELU, EP_BIAS_RES, dil, true);
+                    c1.p.in_scale = 0.1f;
+                    c1.p.aux = src; c1.p.aux_bstride = xs; c1.p.aux_rstride = Tsq;
+                    c1.p.out = dst; c1.p.o_bstride = xs; c1.p.o_rstride = Tsq;
+                    if ((rc = run_gemm(h, c1, st))) return rc;
+                    if (dst == t1) {        // keep the running state in r for the next iteration / the accumulation
+                        float* tmp = r; r = t1; t1 = tmp;
+                    }
+                }
+            }
+            VOC_OK(launch_voc_accum(acc, r, (long)B * xs, j == 0, j + 1 == v.n_kernels ? (float)v.n_kernels : 1.f, st), "accumulate");
+        }
+        cur = acc;
+        cur_c = ch;
+    }
+    {   // leaky_relu (default slope 0.01) -> conv_post -> tanh  (models.py:287-289)
+        const int ch = voc_stage_channels(v, NU - 1), Tq = (int)len[NU], Tsq = lts[NU];
+        GemmCall g = make_gemm(h, h->v_post, cur, (long)ch * Tsq, Tsq, B, Tq, ST_LRELU, EP_BIAS_ACT, 1, true);
+        g.p.in_scale = 0.01f; g.p.act = ACT_TANH;
+        g.p.out = h->v_wav; g.p.o_bstride = Tsq; g.p.o_rstride = Tsq;
+        if ((rc = run_gemm(h, g, st))) return rc;
+        VOC_OK(launch_unpack(h->v_wav, Tsq, wav_out, B, 1, 1, Tq, 0, nullptr, nullptr, st), "unpack(wav)");
+    }
+#undef VOC_OK
     return DSD_OK;
 }
 

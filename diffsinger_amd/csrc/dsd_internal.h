@@ -16,9 +16,9 @@ namespace dsd {
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int padded_ts(int T) { return round_up(T, 64) + 32; }
 
-enum Stage { ST_PLAIN = 0, ST_FILM = 1, ST_LN = 2, ST_SCALE = 3 };
-enum Epi { EP_BIAS_ACT = 0, EP_GATE = 1, EP_RESSKIP = 2, EP_LINCOMB = 3, EP_SWIGLU = 4, EP_BIAS_RES = 5 };
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3 };
+enum Stage { ST_PLAIN = 0, ST_FILM = 1, ST_LN = 2, ST_SCALE = 3, ST_LRELU = 4 };
+enum Epi { EP_BIAS_ACT = 0, EP_GATE = 1, EP_RESSKIP = 2, EP_LINCOMB = 3, EP_SWIGLU = 4, EP_BIAS_RES = 5, EP_SCATTER = 6 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3, ACT_LRELU = 4, ACT_TANH = 5 };
 
 constexpr int kMaxTerms = 8;
 constexpr int kMaxOut = 3;
@@ -62,7 +62,7 @@ struct GemmP {
     int taps;               // kernel size along time (1, 3, or any odd k on the generic path)
     int HL;                 // halo columns staged on each side (multiple of 4, >= (taps / 2) * dil)
     int S;                  // LDS row stride in floats, S % 32 == 16
-    float in_scale;         // ST_SCALE: staged value DIVIDED by this
+    float in_scale;         // ST_SCALE: staged value DIVIDED by this;  ST_LRELU: negative slope of the leaky ReLU
     // ST_FILM: y = x + film[c * film_cstride + film_col0 + b * film_colb]
     const float* film;
     int film_cstride, film_col0, film_colb;
@@ -80,6 +80,7 @@ struct GemmP {
     float* x;               // EP_RESSKIP: residual stream, updated in place
     float* skip;            // EP_RESSKIP: running skip sum
     int first_layer;        // EP_RESSKIP: 1 = skip is written, not accumulated
+    int up;                 // EP_SCATTER: upsampling factor u; row r*C + o, column t -> out[o][u*t + r] (C = p.C)
     int nout;               // EP_LINCOMB
     LinOut lo[kMaxOut];
 };
@@ -103,6 +104,14 @@ hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const flo
 hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstride, const float* film,
                            int film_cstride, int film_col0, int film_colb, long bstride, int rstride, int C, int B,
                            int T, int strong, float* stats, int ts, float eps, hipStream_t stream);
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// vocoder_kernels.hip (NSF-HiFiGAN source, noise convs, residual-block average)
+hipError_t launch_voc_source(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
+                             const float* lin_b, int B, int T, int upp, int dim, float sr, float sine_amp, float noise_std,
+                             float* acc_tmp, int Tsu, float* har, hipStream_t st);
+hipError_t launch_voc_noise_conv(float* x, const float* har, const float* w, const float* bias, int B, int C, int Tq,
+                                 int Tsq, int sf, int ksz, long Tup, int Tsu, hipStream_t st);
+hipError_t launch_voc_accum(float* acc, const float* r, long n, int first, float div, hipStream_t st);
 // encoder_kernels.hip (FastSpeech2 acoustic encoder glue)
 struct EncExpandArgs {
     const float* lin_w[7];

@@ -40,6 +40,8 @@ __device__ __forceinline__ float act_apply(float v, int act) {
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_MISH: return v * tanhf(log1pf(expf(v)));           // nn.Mish (wavenet.py:60)
         case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // exact GELU (lynxnet.py:106)
+        case ACT_LRELU: return v >= 0.f ? v : v * 0.1f;                 // LRELU_SLOPE (nsf_hifigan/models.py:15)
+        case ACT_TANH: return tanhf(v);
         default: return v;
     }
 }
@@ -124,6 +126,7 @@ template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2>
 __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(WN == 2 || (WN == 1 && SW > 0 && EPI != EP_SWIGLU && STAGE != ST_LN), "4x1 wave layout: fast path only");
+    static_assert(SW == 0 || (STAGE != ST_LRELU && EPI != EP_SCATTER), "leaky-ReLU staging / scatter epilogue: generic path");
     constexpr int WM = 4 / WN;                  // waves along rows
     constexpr int MB = 4 / WM;                  // 16-row blocks per wave
     constexpr int BN = 16 * NB * WN;
@@ -551,6 +554,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
                             if (STAGE == ST_FILM) y = y + add[u];
                             else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
                             else if (STAGE == ST_SCALE) y = y / p.in_scale;   // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
+                            else if (STAGE == ST_LRELU) y = y >= 0.f ? y : y * p.in_scale;   // F.leaky_relu on the input
                             const bool ok = (t >= 0) && (t < p.T) && row_ok;
                             o[e] = ok ? y : 0.f;       // zero padding applies AFTER the FiLM add (wavenet.py:36-38)
                         }
@@ -708,6 +712,14 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
                 for (int r = 0; r < 4; ++r) {
                     const int row = rowb + r;
                     if (row >= p.M) continue;
+                    if (EPI == EP_SCATTER) {
+                        // transposed-conv phase rows: row = r_phase * C + o  ->  out[o][up * t + r_phase]
+                        const int ph = row / p.C, o = row - ph * p.C;
+                        if (t < p.T)
+                            p.out[(long)b * p.o_bstride + (long)o * p.o_rstride + (long)t * p.up + ph] =
+                                acc[mb][n][r] + (p.bias ? p.bias[o] : 0.f);
+                        continue;
+                    }
                     const float v = acc[mb][n][r] + (p.bias ? p.bias[row] : 0.f);
                     if (EPI == EP_BIAS_ACT) {
                         p.out[(long)b * p.o_bstride + (long)row * p.o_rstride + t] = act_apply(v, p.act);
@@ -886,6 +898,15 @@ hipError_t gemm_init_all() {
     if ((e = attr_all<ST_LN, 1, EP_BIAS_ACT>()) != hipSuccess) return e;
     if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0>()) != hipSuccess) return e;
     if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0>()) != hipSuccess) return e;
+    // NSF-HiFiGAN: leaky-ReLU staged k-tap convs, residual epilogue, transposed-conv scatter (generic path only)
+    if ((e = set_attr<ST_LRELU, 0, EP_BIAS_ACT, 1, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_LRELU, 0, EP_BIAS_ACT, 2, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_RES, 1, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_RES, 2, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_LRELU, 0, EP_BIAS_RES, 1, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_LRELU, 0, EP_BIAS_RES, 2, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_LRELU, 0, EP_SCATTER, 1, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_LRELU, 0, EP_SCATTER, 2, 0>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -902,9 +923,16 @@ hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int
     DSD_CASE(ST_PLAIN, 1, EP_BIAS_RES)
     DSD_CASE(ST_LN, 1, EP_LINCOMB)
     DSD_CASE(ST_LN, 1, EP_BIAS_ACT)
-    if (stage == ST_PLAIN && epi == EP_BIAS_ACT && taps > 1 && taps == p.taps && !fast)     // dense k-tap conv
-        return nb == 1 ? launch_one<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0>(p, batch, st)
-                       : launch_one<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0>(p, batch, st);
+#define DSD_DENSE(ST, EP)                                                                   \
+    if (stage == ST && epi == EP && taps == p.taps && !fast && nb >= 1)                      \
+        return nb == 1 ? launch_one<ST, 0, EP, 1, 0>(p, batch, st) : launch_one<ST, 0, EP, 2, 0>(p, batch, st);
+    // dense k-tap convs with the kernel size taken from the argument block (generic path)
+    DSD_DENSE(ST_PLAIN, EP_BIAS_ACT)
+    DSD_DENSE(ST_LRELU, EP_BIAS_ACT)
+    DSD_DENSE(ST_PLAIN, EP_BIAS_RES)
+    DSD_DENSE(ST_LRELU, EP_BIAS_RES)
+    DSD_DENSE(ST_LRELU, EP_SCATTER)
+#undef DSD_DENSE
     return hipErrorInvalidValue;
 }
 

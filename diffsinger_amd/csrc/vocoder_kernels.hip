@@ -1,0 +1,127 @@
+// Non-GEMM kernels of the NSF-HiFiGAN generator (mel + f0 -> waveform).  Every convolution
+// with more than one input channel runs on the GEMM family of gemm.hip (transposed convolutions as phase-row GEMMs
+// with a scatter epilogue); what is here is the harmonic-plus-noise source (SineGen / SourceModuleHnNSF), the
+// single-input-channel strided "noise convs" that inject it at every resolution, and the residual-block average.
+// Internal layout [batch][channel][Ts], lanes along time.
+#include "dsd_internal.h"
+
+namespace dsd {
+
+// ---------------------------------------------------------------------------------------------
+// SineGen._f02sine, frame level (models.py:139-142): the phase each frame starts from is the running fp32 sum of
+// the per-frame phase advances wrapped into [-0.5, 0.5) - torch.cumsum's sequential order, one lane per utterance.
+//   rad_last = f0 / sr * upp;  rad2 = fmod(rad_last + 0.5, 1) - 0.5;  acc[t] = fmod(sum_{t' <= t} rad2[t'], 1)
+// ---------------------------------------------------------------------------------------------
+__global__ void voc_phase_kernel(const float* __restrict__ f0, int T, float sr, int upp, float* __restrict__ acc) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    float run = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float rad_last = f0[(long)b * T + t] / sr * (float)upp;
+        const float rad2 = fmodf(rad_last + 0.5f, 1.0f) - 0.5f;
+        run += rad2;
+        acc[(long)b * T + t] = fmodf(run, 1.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SineGen.forward + SourceModuleHnNSF.forward, sample level (models.py:139-168, 200-203):
+//   rad = f0/sr * (n+1) + acc[t-1];  per harmonic d: sin(2 pi (rad (d+1) + rand_ini[d])) * amp
+//   sine * uv + (uv * noise_std + (1 - uv) * amp / 3) * noise  ->  tanh(Linear(dim -> 1))
+// rand_ini [dim] (element 0 is forced to 0, models.py:146) and noise [B, T*upp, dim] are inputs: the reference
+// draws them with torch.rand / torch.randn_like.
+// ---------------------------------------------------------------------------------------------
+constexpr int VOC_MAXDIM = 16;
+__global__ void voc_source_kernel(const float* __restrict__ f0, const float* __restrict__ acc,
+                                  const float* __restrict__ rand_ini, const float* __restrict__ noise,
+                                  const float* __restrict__ lin_w, const float* __restrict__ lin_b, int T, int upp,
+                                  int dim, float sr, float sine_amp, float noise_std, int Tsu, float* __restrict__ har) {
+    const int b = blockIdx.y;
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;       // sample index within the utterance
+    if (s >= (long)T * upp) return;
+    const int t = (int)(s / upp), n = (int)(s - (long)t * upp);
+    const float f = f0[(long)b * T + t];
+    float rad = f / sr * (float)(n + 1);
+    if (t > 0) rad += acc[(long)b * T + t - 1];
+    const float uv = f > 0.f ? 1.f : 0.f;
+    const float namp = uv * noise_std + (1.f - uv) * sine_amp / 3.f;
+    const float* nz = noise + ((long)b * T * upp + s) * dim;
+    float m = 0.f;
+    for (int d = 0; d < dim; ++d) {
+        float r = rad * (float)(d + 1);
+        r += (d == 0) ? 0.f : rand_ini[d];
+        const float sine = sinf(6.283185307179586f * r) * sine_amp;
+        m += (sine * uv + namp * nz[d]) * lin_w[d];
+    }
+    har[(long)b * Tsu + s] = tanhf(m + lin_b[0]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// noise_convs[i] (models.py:239-245, 275-276): Conv1d(1, C, 2*sf, stride sf, padding sf/2) (or k = 1 at the last
+// stage) on the source, ADDED to the upsampled activations:
+//   x[b][o][q] += bias[o] + sum_k w[o][k] * har[b][q*sf - sf/2 + k]        (zero outside [0, Tup))
+// One workgroup = 64 output frames x 4 channels; the source window of the 64 frames is staged in LDS once.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void voc_noise_conv_kernel(float* __restrict__ x, const float* __restrict__ har,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             int C, int Tq, int Tsq, int sf, int ksz, long Tup, int Tsu) {
+    extern __shared__ float win[];                  // (64 - 1) * sf + ksz source samples
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pad = ksz > 1 ? sf / 2 : 0;
+    const int nwin = 63 * sf + ksz;
+    const long s0 = (long)q0 * sf - pad;
+    for (int i = threadIdx.x; i < nwin; i += 256) {
+        const long s = s0 + i;
+        win[i] = (s >= 0 && s < Tup) ? har[(long)b * Tsu + s] : 0.f;
+    }
+    __syncthreads();
+    const int q = q0 + lane;
+    for (int o = blockIdx.y * 4 + wave; o < C; o += gridDim.y * 4) {
+        float acc = 0.f;
+        const float* wo = w + (long)o * ksz;
+        for (int k = 0; k < ksz; ++k) acc += wo[k] * win[lane * sf + k];
+        if (q < Tq) x[((long)b * C + o) * Tsq + q] += acc + bias[o];
+    }
+}
+
+// acc = first ? r : acc + r;  if scale != 1: acc /= scale      (xs accumulation and `xs / num_kernels`, models.py:280-286)
+__global__ void voc_accum_kernel(float* __restrict__ acc, const float* __restrict__ r, long n, int first, float div) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4_t a = *reinterpret_cast<const f32x4_t*>(r + i);
+    if (!first) {
+        const f32x4_t c = *reinterpret_cast<const f32x4_t*>(acc + i);
+        a = c + a;
+    }
+    if (div != 1.f) a = a / div;
+    *reinterpret_cast<f32x4_t*>(acc + i) = a;
+}
+
+hipError_t launch_voc_source(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
+                             const float* lin_b, int B, int T, int upp, int dim, float sr, float sine_amp, float noise_std,
+                             float* acc_tmp, int Tsu, float* har, hipStream_t st) {
+    if (dim > VOC_MAXDIM) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(voc_phase_kernel, dim3(B), dim3(64), 0, st, f0, T, sr, upp, acc_tmp);
+    const long n = (long)T * upp;
+    hipLaunchKernelGGL(voc_source_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, f0, acc_tmp, rand_ini, noise,
+                       lin_w, lin_b, T, upp, dim, sr, sine_amp, noise_std, Tsu, har);
+    return hipGetLastError();
+}
+
+hipError_t launch_voc_noise_conv(float* x, const float* har, const float* w, const float* bias, int B, int C, int Tq,
+                                 int Tsq, int sf, int ksz, long Tup, int Tsu, hipStream_t st) {
+    const int nwin = 63 * sf + ksz;
+    const int ygrid = (C + 3) / 4 < 16 ? (C + 3) / 4 : 16;
+    hipLaunchKernelGGL(voc_noise_conv_kernel, dim3((Tq + 63) / 64, ygrid, B), dim3(256), nwin * sizeof(float), st, x, har, w,
+                       bias, C, Tq, Tsq, sf, ksz, Tup, Tsu);
+    return hipGetLastError();
+}
+
+hipError_t launch_voc_accum(float* acc, const float* r, long n, int first, float div, hipStream_t st) {
+    hipLaunchKernelGGL(voc_accum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, acc, r, n, first, div);
+    return hipGetLastError();
+}
+
+}  // namespace dsd

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSD_API_VERSION 3
+#define DSD_API_VERSION 4
 
 /* error codes */
 #define DSD_OK 0
@@ -43,7 +43,10 @@ enum { DSD_BACKBONE_WAVENET = 0, DSD_BACKBONE_LYNXNET = 1,
        DSD_AUX_CONVNEXT = 2,
        /* modules/fastspeech/acoustic_encoder.py:14  FastSpeech2Acoustic: the producer of `cond` (see dsd_encode);
           created with dsd_encoder_create, not dsd_create */
-       DSD_ENC_FS2_ACOUSTIC = 3 };
+       DSD_ENC_FS2_ACOUSTIC = 3,
+       /* modules/nsf_hifigan/models.py:207  Generator (NSF-HiFiGAN vocoder: mel + f0 -> waveform; see dsd_vocode);
+          created with dsd_vocoder_create */
+       DSD_VOC_NSF_HIFIGAN = 4 };
 /* modules/backbones/lynxnet.py:38-42  activation_classes */
 enum { DSD_ACT_PRELU = 0, DSD_ACT_SILU = 1, DSD_ACT_RELU = 2 };
 
@@ -178,6 +181,47 @@ int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out);
  */
 int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, const float* f0, int32_t B,
                int32_t T_txt, int32_t T, const dsd_encode_extras* extras, float* cond_out, void* stream);
+
+/*
+ * NSF-HiFiGAN generator (the step after the loop: mel -> waveform).  The constructor arguments are the fields of the
+ * checkpoint's config.json that Generator.__init__ reads (modules/nsf_hifigan/models.py:207-260), `mini_nsf: false`.
+ * Weights: the Generator state_dict in its inference form, i.e. after remove_weight_norm() (models.py:292-302):
+ * `m_source.l_linear.*`, `noise_convs.N.*`, `conv_pre.*`, `ups.N.*` ([C_in, C_out, K] as ConvTranspose1d stores it),
+ * `resblocks.N.convs1.M.* / convs2.M.*` (ResBlock1) or `resblocks.N.convs.M.*` (ResBlock2), `conv_post.*`.
+ */
+#define DSD_VOC_MAX_UPS 8
+#define DSD_VOC_MAX_KERNELS 8
+#define DSD_VOC_MAX_DILS 4
+typedef struct dsd_vocoder_config {
+    int32_t struct_size;
+    int32_t num_mels;
+    int32_t sampling_rate;
+    int32_t upsample_initial_channel;
+    int32_t n_ups;
+    int32_t upsample_rates[DSD_VOC_MAX_UPS];
+    int32_t upsample_kernel_sizes[DSD_VOC_MAX_UPS];
+    int32_t resblock;                                  /* 1 = ResBlock1, 2 = ResBlock2 */
+    int32_t n_kernels;
+    int32_t resblock_kernel_sizes[DSD_VOC_MAX_KERNELS];
+    int32_t n_dilations[DSD_VOC_MAX_KERNELS];
+    int32_t resblock_dilation_sizes[DSD_VOC_MAX_KERNELS][DSD_VOC_MAX_DILS];
+    int32_t harmonic_num;                              /* SourceModuleHnNSF(harmonic_num=8), models.py:221-224 */
+    int32_t device;
+} dsd_vocoder_config;
+
+int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out);
+/*
+ * Replaces: Generator.forward(x, f0)  (models.py:262-290) with the two random draws of SineGen made explicit:
+ *   mel      element (b, m, t) at mel[b*stride_b + m*stride_m + t*stride_t]: natural-log mel, [B, num_mels, T] view
+ *            (the wrapper's 2.30259 * log10-mel, vocoders/nsf_hifigan.py:59-64, is the caller's)
+ *   f0       [B, T] Hz, 0 = unvoiced
+ *   rand_ini [harmonic_num + 1] uniform [0,1) initial phases (torch.rand, models.py:145; element 0 is ignored)
+ *   noise    [B, T * prod(upsample_rates), harmonic_num + 1] standard normals (torch.randn_like, models.py:165)
+ *   wav_out  [B, T * prod(upsample_rates)]
+ */
+int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_m,
+               int64_t stride_t, const float* f0, const float* rand_ini, const float* noise, float* wav_out,
+               void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sampling programs.  Every sampler of the reference (ddpm.py:149-204,221-351 p_sample /
