@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1000, help="mel frames per utterance (T)")
-    ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100", "acoustic_default", "acoustic_e2e"])
+    ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100", "acoustic_default", "acoustic_e2e", "acoustic_wav"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -121,12 +121,12 @@ def main():
     params = synth.synth_state_dict(shapes, seed=42)
     hparams.clear()
     acoustic = None
-    if args.workload in ("acoustic_default", "acoustic_e2e"):
+    if args.workload in ("acoustic_default", "acoustic_e2e", "acoustic_wav"):
         # configs/acoustic.yaml:61-99 of the reference fork: shallow reflow (euler, 20 steps from t = 0.4) on the
         # LYNXNet above, started from the ConvNeXt aux decoder's mel - DiffSingerAcoustic.forward after the encoder
         from diffsinger_amd.toplevel import AcousticDecoder, DiffSingerAcoustic
         aux_args = dict(num_channels=512, num_layers=6, kernel_size=7, dropout_rate=0.1)
-        e2e = args.workload == "acoustic_e2e"      # + the FastSpeech2 encoder: phoneme tokens in, mel out
+        e2e = args.workload in ("acoustic_e2e", "acoustic_wav")   # + the FastSpeech2 encoder: phoneme tokens in, mel out
         hparams.update(enc_layers=4, enc_ffn_kernel_size=3, ffn_act="gelu", dropout=0.1, num_heads=2, use_pos_embed=True,
                        rel_pos=True, use_rope=True, use_spk_id=False, num_spk=1, use_lang_id=False, num_lang=1)
         hparams.update(hidden_size=256, schedule_type="linear", infer=False, use_shallow_diffusion=True,
@@ -149,7 +149,16 @@ def main():
         d.denoise_fn = d.velocity_fn          # one name for the backbone below
         nfe, wname = 20, (("FastSpeech2 encoder 4x256 (120 tokens) -> " if e2e else "") +
                           "ConvNeXt aux decoder 6x512 -> shallow reflow euler 20 (t 0.4 -> 1) on LYNXNet 6x1024 "
-                          "(configs/acoustic.yaml of the reference fork)")
+                          "(configs/acoustic.yaml of the reference fork)" +
+                          (" -> NSF-HiFiGAN 44.1 kHz waveform" if args.workload == "acoustic_wav" else ""))
+        vocoder = None
+        if args.workload == "acoustic_wav":      # tokens in, waveform out: the whole of scripts/infer.py's model side
+            from diffsinger_amd.vocoder import Generator, NsfHifiGAN
+            vh = dict(synth.NSF_HIFIGAN_DEFAULT)
+            vgen = Generator(vh)
+            vgen.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(
+                synth.nsf_hifigan_param_shapes(vh), seed=45, gain=0.7).items()}, strict=True)
+            vocoder = NsfHifiGAN(vgen.to(device).eval())
     else:
         hparams.update(hidden_size=256, schedule_type="linear", use_shallow_diffusion=False, infer=False, **hp)
         d = GaussianDiffusion(128, 1, timesteps=1000, k_step=1000, backbone_type=kind, backbone_args=bargs,
@@ -170,10 +179,18 @@ def main():
     mel2ph = (torch.arange(T, device=device) * n_tok // T + 1).to(torch.long)[None].expand(len(mine), T).contiguous()
     tokens = (torch.arange(n_tok, device=device) % 59 + 1).to(torch.long)[None].expand(len(mine), n_tok).contiguous()
     f0 = torch.full((len(mine), T), 220.0, device=device)
+    voc_ri = voc_noise = None
+    if args.workload == "acoustic_wav":          # SineGen's draws, resident like x_T
+        voc_ri = torch.rand(9, device=device)
+        voc_noise = torch.randn((len(mine), T * 512, 9), device=device)
 
     def run(c):
         if acoustic is not None:
             with torch.no_grad():       # as DiffSingerAcousticInfer.forward_model does (ds_acoustic.py:136)
+                if args.workload == "acoustic_wav":
+                    mel = acoustic(tokens, mel2ph, f0, infer=True, noise=noise).diff_out
+                    wav = vocoder.spec2wav_torch(mel, f0=f0, rand_ini=voc_ri, noise=voc_noise)
+                    return wav.view(len(mine), -1)[:, :T].unsqueeze(-1).expand(-1, -1, 128)   # gather-shaped view
                 if args.workload == "acoustic_e2e":     # the condition comes from the encoder on this GPU
                     return acoustic(tokens, mel2ph, f0, infer=True, noise=noise).diff_out
                 return acoustic(c, mel2ph, infer=True, noise=noise).diff_out

@@ -52,3 +52,37 @@ for bsz, n_tok, t_len in ((1, 120, 1000), (8, 120, 1000), (1, 300, 2500)):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
     print(f"encoder B={bsz} T_txt={n_tok} T={t_len}: {dt*1e3:.3f} ms/pass", flush=True)
+
+from diffsinger_amd.vocoder import Generator
+h = dict(synth.NSF_HIFIGAN_DEFAULT)
+gen = Generator(h)
+gen.load_state_dict({k: torch.from_numpy(v) for k, v in
+                     synth.synth_state_dict(synth.nsf_hifigan_param_shapes(h), seed=6, gain=0.7).items()}, strict=True)
+gen = gen.cuda().eval()
+st = None
+for bsz, t_len in ((1, 1000), (4, 1000)):
+    mel = torch.from_numpy(synth.synth_normal((bsz, 128, t_len), 7) * 3 - 11).cuda()
+    f0 = torch.full((bsz, t_len), 220.0, device="cuda")
+    noise = torch.randn((bsz, t_len * 512, 9), device="cuda")
+    ri = torch.rand(9, device="cuda")
+    with torch.no_grad():
+        for _ in range(2):
+            gen(mel, f0, rand_ini=ri, noise=noise)
+        torch.cuda.synchronize()
+        n = 5
+        t0 = time.perf_counter()
+        for _ in range(n):
+            gen(mel, f0, rand_ini=ri, noise=noise)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+    flops = 0
+    ch = 512
+    rate = 1
+    for u, k in zip(h["upsample_rates"], h["upsample_kernel_sizes"]):
+        ch //= 2
+        flops += 2 * (2 * ch) * ch * k * rate          # transposed conv, per input frame of that stage
+        rate *= u
+        flops += rate * sum(2 * ch * ch * rk * 2 * 3 for rk in h["resblock_kernel_sizes"])
+    flops += 2 * 128 * 512 * 7 + rate * 2 * ch * 7
+    print(f"vocoder B={bsz} T={t_len}: {dt*1e3:.2f} ms/pass  RTF {dt / (bsz * t_len * 512 / 44100):.5f}  "
+          f"{flops * bsz * t_len / dt / 1e12:.1f} TFLOP/s", flush=True)
