@@ -37,6 +37,13 @@ struct PackedGemm {
     int pairC = 0;        // > 0: paired packing with this many pairs
 };
 
+// weights of a few-channel convolution in tconv.hip's B-fragment order
+struct PackedTConv {
+    size_t w_off = SIZE_MAX, b_off = 0;
+    int ci = 0, co = 0, co_real = 0, taps = 0;
+    bool valid() const { return w_off != SIZE_MAX; }
+};
+
 struct GraphEntry {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -64,6 +71,8 @@ struct dsd_handle {
     PackedGemm v_pre, v_post;
     std::vector<PackedGemm> v_ups;                   // transposed convs as phase-row GEMMs
     std::vector<std::vector<PackedGemm>> v_res;      // [stage * n_kernels + j][2 * n_dil (ResBlock1) or n_dil]
+    std::vector<std::vector<PackedTConv>> v_rest;    // same indexing: the 16- / 32-channel stages (tconv.hip)
+    PackedTConv v_postt;
     std::vector<size_t> v_nw, v_nb;                  // noise conv weights / biases
     std::vector<int> v_uptaps;
     size_t v_linw = 0, v_linb = 0;
@@ -478,6 +487,28 @@ int build_packed_enc(dsd_handle* h) {
 int build_packed_voc(dsd_handle* h) {
     const dsd_vocoder_config& v = h->vcfg;
     h->blob_host.clear();
+    // few-channel convolutions: B fragments [tap][ci/4][co/16][lane] (tconv.hip)
+    auto tconv_pack = [&](const std::string& name, int co_real, int ci, int ks) {
+        const HostTensor* t = &W(h, name + ".weight");     // [co_real, ci, ks]
+        const HostTensor* b = &W(h, name + ".bias");
+        PackedTConv pt;
+        pt.ci = ci; pt.co = round_up(co_real, 16); pt.co_real = co_real; pt.taps = ks;
+        const int kc4 = ci / 4, nbn = pt.co / 16;
+        pt.w_off = blob_reserve(h, (size_t)ks * kc4 * nbn * 64);
+        float* dst = h->blob_host.data() + pt.w_off;
+        for (int tap = 0; tap < ks; ++tap)
+            for (int c4 = 0; c4 < kc4; ++c4)
+                for (int nb = 0; nb < nbn; ++nb)
+                    for (int l = 0; l < 64; ++l) {
+                        const int o = nb * 16 + (l & 15), c = c4 * 4 + (l >> 4);
+                        dst[((size_t)(tap * kc4 + c4) * nbn + nb) * 64 + l] =
+                            o < co_real ? t->data[((size_t)o * ci + c) * ks + tap] : 0.f;
+                    }
+        pt.b_off = blob_reserve(h, (size_t)co_real);
+        memcpy(h->blob_host.data() + pt.b_off, b->data.data(), sizeof(float) * co_real);
+        return pt;
+    };
+    auto few = [](int ch) { return ch == 16 || ch == 32; };
     auto copy_vec = [&](const std::string& name) {
         const auto& d = W(h, name).data;
         const size_t off = blob_reserve(h, d.size());
@@ -499,6 +530,7 @@ int build_packed_voc(dsd_handle* h) {
     h->v_nw.resize(v.n_ups);
     h->v_nb.resize(v.n_ups);
     h->v_res.assign((size_t)v.n_ups * v.n_kernels, {});
+    h->v_rest.assign((size_t)v.n_ups * v.n_kernels, {});
     for (int i = 0; i < v.n_ups; ++i) {
         const int ch = voc_stage_channels(v, i), u = v.upsample_rates[i], K = v.upsample_kernel_sizes[i], pad = (K - u) / 2;
         int D = 0;
@@ -526,7 +558,18 @@ int build_packed_voc(dsd_handle* h) {
         for (int j = 0; j < v.n_kernels; ++j) {
             const std::string p = "resblocks." + std::to_string(i * v.n_kernels + j) + ".";
             auto& list = h->v_res[(size_t)i * v.n_kernels + j];
+            auto& tlist = h->v_rest[(size_t)i * v.n_kernels + j];
             for (int d = 0; d < v.n_dilations[j]; ++d) {
+                if (few(ch)) {
+                    const int ks = v.resblock_kernel_sizes[j];
+                    if (v.resblock == 1) {
+                        tlist.push_back(tconv_pack(p + "convs1." + std::to_string(d), ch, ch, ks));
+                        tlist.push_back(tconv_pack(p + "convs2." + std::to_string(d), ch, ch, ks));
+                    } else {
+                        tlist.push_back(tconv_pack(p + "convs." + std::to_string(d), ch, ch, ks));
+                    }
+                    continue;
+                }
                 if (v.resblock == 1) {
                     list.push_back(dense(p + "convs1." + std::to_string(d), ch, ch, v.resblock_kernel_sizes[j]));
                     list.push_back(dense(p + "convs2." + std::to_string(d), ch, ch, v.resblock_kernel_sizes[j]));
@@ -537,6 +580,7 @@ int build_packed_voc(dsd_handle* h) {
         }
     }
     h->v_post = dense("conv_post", 1, voc_stage_channels(v, v.n_ups - 1), 7);
+    if (voc_stage_channels(v, v.n_ups - 1) == 16) h->v_postt = tconv_pack("conv_post", 1, 16, 7);
     return DSD_OK;
 }
 
@@ -1301,6 +1345,28 @@ int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, 
     return DSD_OK;
 }
 
+static int run_tconv(dsd_handle* h, const PackedTConv& pt, const float* x, float* out, const float* res, int B, int C,
+                     int T, int Ts, int dil, float slope_in, int act, hipStream_t st) {
+    TConvP p;
+    memset(&p, 0, sizeof(p));
+    p.W = h->blob + pt.w_off;
+    p.bias = h->blob + pt.b_off;
+    p.x = x; p.x_bstride = (long)C * Ts; p.x_rstride = Ts;
+    p.out = out; p.res = res; p.o_bstride = (long)pt.co_real * Ts; p.o_rstride = Ts;
+    p.T = T; p.Ts_out = Ts;
+    p.taps = pt.taps; p.dil = dil;
+    p.HP = round_up((pt.taps / 2) * dil, 4);
+    int SP = 256 + 2 * p.HP;
+    while (SP % 32 != 16) SP += 4;
+    p.SP = SP;
+    p.slope_in = slope_in; p.act = act; p.co_real = pt.co_real;
+    p.lds_bytes = tconv_lds_bytes(pt.ci, pt.co, pt.taps, SP);
+    if (p.lds_bytes > 160 * 1024) return fail(h, DSD_EINVAL, "few-channel conv needs %d bytes of LDS", p.lds_bytes);
+    hipError_t e = launch_tconv(p, pt.ci, pt.co, B, st);
+    if (e != hipSuccess) return fail(h, DSD_EHIP, "tconv launch failed: %s", hipGetErrorString(e));
+    return DSD_OK;
+}
+
 int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out) {
     if (!cfg || !out) return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: null argument");
     if (cfg->struct_size != (int32_t)sizeof(dsd_vocoder_config))
@@ -1331,6 +1397,7 @@ int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out) {
         return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: device %d out of range [0, %d)", cfg->device, ndev);
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_vocoder_create: hipSetDevice failed");
     hipError_t ie = gemm_init_all();
+    if (ie == hipSuccess) ie = tconv_init_all();
     if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_vocoder_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
     dsd_handle* h = new dsd_handle();
     memset(&h->cfg, 0, sizeof(h->cfg));
@@ -1433,9 +1500,23 @@ int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t st
         }
         for (int j = 0; j < v.n_kernels; ++j) {     // residual blocks  (models.py:280-286; ResBlock1 :62-69, ResBlock2 :92-97)
             const auto& cv = h->v_res[(size_t)i * v.n_kernels + j];
+            const auto& tv = h->v_rest[(size_t)i * v.n_kernels + j];
             for (int d = 0; d < v.n_dilations[j]; ++d) {
                 const float* src = d == 0 ? x : r;
                 const int dil = v.resblock_dilation_sizes[j][d];
+                if (!tv.empty()) {          // 16 / 32 channels: time-major convolutions (tconv.hip)
+                    if (v.resblock == 1) {
+                        if ((rc = run_tconv(h, tv[2 * d], src, t1, nullptr, B, ch, Tq, Tsq, dil, 0.1f, ACT_LRELU, st))) return rc;
+                        if ((rc = run_tconv(h, tv[2 * d + 1], t1, r, src, B, ch, Tq, Tsq, 1, 1.f, ACT_NONE, st))) return rc;
+                    } else {
+                        float* dst = src == x ? r : t1;
+                        if ((rc = run_tconv(h, tv[d], src, dst, src, B, ch, Tq, Tsq, dil, 0.1f, ACT_NONE, st))) return rc;
+                        if (dst == t1) {
+                            float* tmp = r; r = t1; t1 = tmp;
+                        }
+                    }
+                    continue;
+                }
                 if (v.resblock == 1) {
                     GemmCall c1 = make_gemm(h, cv[2 * d], src, xs, Tsq, B, Tq, ST_LRELU, EP_BIAS_ACT, dil, true);
                     c1.p.in_scale = 0.1f; c1.p.act = ACT_LRELU;
@@ -1466,10 +1547,14 @@ int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t st
     }
     {   // leaky_relu (default slope 0.01) -> conv_post -> tanh  (models.py:287-289)
         const int ch = voc_stage_channels(v, NU - 1), Tq = (int)len[NU], Tsq = lts[NU];
-        GemmCall g = make_gemm(h, h->v_post, cur, (long)ch * Tsq, Tsq, B, Tq, ST_LRELU, EP_BIAS_ACT, 1, true);
-        g.p.in_scale = 0.01f; g.p.act = ACT_TANH;
-        g.p.out = h->v_wav; g.p.o_bstride = Tsq; g.p.o_rstride = Tsq;
-        if ((rc = run_gemm(h, g, st))) return rc;
+        if (h->v_postt.valid()) {
+            if ((rc = run_tconv(h, h->v_postt, cur, h->v_wav, nullptr, B, ch, Tq, Tsq, 1, 0.01f, ACT_TANH, st))) return rc;
+        } else {
+            GemmCall g = make_gemm(h, h->v_post, cur, (long)ch * Tsq, Tsq, B, Tq, ST_LRELU, EP_BIAS_ACT, 1, true);
+            g.p.in_scale = 0.01f; g.p.act = ACT_TANH;
+            g.p.out = h->v_wav; g.p.o_bstride = Tsq; g.p.o_rstride = Tsq;
+            if ((rc = run_gemm(h, g, st))) return rc;
+        }
         VOC_OK(launch_unpack(h->v_wav, Tsq, wav_out, B, 1, 1, Tq, 0, nullptr, nullptr, st), "unpack(wav)");
     }
 #undef VOC_OK

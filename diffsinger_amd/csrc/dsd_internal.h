@@ -104,6 +104,28 @@ hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const flo
 hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstride, const float* film,
                            int film_cstride, int film_col0, int film_colb, long bstride, int rstride, int C, int B,
                            int T, int strong, float* stats, int ts, float eps, hipStream_t stream);
+// tconv.hip: time-major MFMA convolution for 16 / 32 channels
+struct TConvP {
+    const float* W;         // B fragments [tap][CI/4][CO/16][64]: lane l = W[o = nb*16 + (l&15)][c = c4*4 + (l>>4)][tap]
+    const float* bias;      // [co_real]
+    const float* x;         // input, internal layout
+    long x_bstride;
+    int x_rstride;
+    float* out;
+    const float* res;       // residual added after the activation, same layout as out (may alias it), or nullptr
+    long o_bstride;
+    int o_rstride;
+    int T, Ts_out;
+    int taps, dil;
+    int HP, SP;             // staged halo (multiple of 4) and LDS row stride (16 mod 32)
+    float slope_in;         // leaky ReLU on the input (1 = none)
+    int act;                // ACT_NONE / ACT_LRELU / ACT_TANH on the output (before the residual)
+    int co_real;            // output channels actually stored
+    int lds_bytes;
+};
+int tconv_lds_bytes(int ci, int co, int taps, int SP);
+hipError_t tconv_init_all();
+hipError_t launch_tconv(const TConvP& p, int ci, int co, int batch, hipStream_t st);
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // vocoder_kernels.hip (NSF-HiFiGAN source, noise convs, residual-block average)
 hipError_t launch_voc_source(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,

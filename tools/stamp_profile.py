@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "diffsinger_amd", "csrc")
 OUT = os.path.join(ROOT, "diffsinger_amd", "libdsdenoise_stamps.so")
-srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "aux_kernels.hip", "encoder_kernels.hip", "vocoder_kernels.hip", "api.hip")]
+srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "aux_kernels.hip", "encoder_kernels.hip", "vocoder_kernels.hip", "tconv.hip", "api.hip")]
 if not os.path.exists(OUT) or any(os.path.getmtime(s) > os.path.getmtime(OUT) for s in srcs):
     extra = [a for a in sys.argv[1:] if a.startswith("-D")]
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DDSD_STAMPS",
