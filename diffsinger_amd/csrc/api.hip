@@ -553,7 +553,13 @@ int build_packed_voc(dsd_handle* h) {
         h->v_ups[i] = pack_gemm(h, u * ch, 2 * ch, taps, 0, w, nullptr);
         h->v_ups[i].bias_off = blob_reserve(h, (size_t)ch);
         memcpy(h->blob_host.data() + h->v_ups[i].bias_off, b->data.data(), sizeof(float) * ch);
-        h->v_nw[i] = copy_vec("noise_convs." + std::to_string(i) + ".weight");
+        {   // noise conv weights transposed to [k][C]: the kernel's threads run along the channels
+            const auto& wn = W(h, "noise_convs." + std::to_string(i) + ".weight");     // [ch, 1, k]
+            const int nk = (int)wn.shape[2];
+            h->v_nw[i] = blob_reserve(h, (size_t)nk * ch);
+            for (int k = 0; k < nk; ++k)
+                for (int o = 0; o < ch; ++o) h->blob_host[h->v_nw[i] + (size_t)k * ch + o] = wn.data[(size_t)o * nk + k];
+        }
         h->v_nb[i] = copy_vec("noise_convs." + std::to_string(i) + ".bias");
         for (int j = 0; j < v.n_kernels; ++j) {
             const std::string p = "resblocks." + std::to_string(i * v.n_kernels + j) + ".";

@@ -12,15 +12,26 @@ namespace dsd {
 // the per-frame phase advances wrapped into [-0.5, 0.5) - torch.cumsum's sequential order, one lane per utterance.
 //   rad_last = f0 / sr * upp;  rad2 = fmod(rad_last + 0.5, 1) - 0.5;  acc[t] = fmod(sum_{t' <= t} rad2[t'], 1)
 // ---------------------------------------------------------------------------------------------
-__global__ void voc_phase_kernel(const float* __restrict__ f0, int T, float sr, int upp, float* __restrict__ acc) {
+__global__ __launch_bounds__(256) void voc_phase_kernel(const float* __restrict__ f0, int T, float sr, int upp,
+                                                        float* __restrict__ acc) {
+    __shared__ float buf[2048];
     const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    float run = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const float rad_last = f0[(long)b * T + t] / sr * (float)upp;
-        const float rad2 = fmodf(rad_last + 0.5f, 1.0f) - 0.5f;
-        run += rad2;
-        acc[(long)b * T + t] = fmodf(run, 1.0f);
+    float run = 0.f;                               // carried by thread 0 across the 2048-frame pieces
+    for (int base = 0; base < T; base += 2048) {
+        const int n = min(2048, T - base);
+        for (int i = threadIdx.x; i < n; i += 256) {       // per-frame advance, in parallel
+            const float rad_last = f0[(long)b * T + base + i] / sr * (float)upp;
+            buf[i] = fmodf(rad_last + 0.5f, 1.0f) - 0.5f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)                              // the running sum itself is sequential: same order as torch.cumsum
+            for (int i = 0; i < n; ++i) {
+                run += buf[i];
+                buf[i] = fmodf(run, 1.0f);
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) acc[(long)b * T + base + i] = buf[i];
+        __syncthreads();
     }
 }
 
@@ -60,30 +71,44 @@ __global__ void voc_source_kernel(const float* __restrict__ f0, const float* __r
 // noise_convs[i] (models.py:239-245, 275-276): Conv1d(1, C, 2*sf, stride sf, padding sf/2) (or k = 1 at the last
 // stage) on the source, ADDED to the upsampled activations:
 //   x[b][o][q] += bias[o] + sum_k w[o][k] * har[b][q*sf - sf/2 + k]        (zero outside [0, Tup))
-// One workgroup = 64 output frames x 4 channels; the source window of the 64 frames is staged in LDS once.
+// Threads run along the output CHANNELS (weights are stored transposed, [k][C]: coalesced), every thread produces
+// NQ consecutive frames of its channel, and the source window of the workgroup's frames sits in LDS, read as a
+// broadcast.  One workgroup = min(C, 256) channels x (256 / C) groups of NQ frames.
 // ---------------------------------------------------------------------------------------------
+constexpr int VOC_NQ = 16;
 __global__ __launch_bounds__(256) void voc_noise_conv_kernel(float* __restrict__ x, const float* __restrict__ har,
-                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             const float* __restrict__ wt, const float* __restrict__ bias,
                                                              int C, int Tq, int Tsq, int sf, int ksz, long Tup, int Tsu) {
-    extern __shared__ float win[];                  // (64 - 1) * sf + ksz source samples
+    extern __shared__ float win[];                  // (frames per workgroup - 1) * sf + ksz source samples
     const int b = blockIdx.z;
-    const int q0 = blockIdx.x * 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cpb = C < 256 ? C : 256;              // channels per workgroup
+    const int groups = 256 / cpb;                   // frame groups per workgroup
+    const int fpb = groups * VOC_NQ;                // frames per workgroup
+    const int q0 = blockIdx.x * fpb;
+    const int o = blockIdx.y * cpb + threadIdx.x % cpb, grp = threadIdx.x / cpb;
     const int pad = ksz > 1 ? sf / 2 : 0;
-    const int nwin = 63 * sf + ksz;
+    const int nwin = (fpb - 1) * sf + ksz;
     const long s0 = (long)q0 * sf - pad;
     for (int i = threadIdx.x; i < nwin; i += 256) {
-        const long s = s0 + i;
-        win[i] = (s >= 0 && s < Tup) ? har[(long)b * Tsu + s] : 0.f;
+        const long sidx = s0 + i;
+        win[i] = (sidx >= 0 && sidx < Tup) ? har[(long)b * Tsu + sidx] : 0.f;
     }
     __syncthreads();
-    const int q = q0 + lane;
-    for (int o = blockIdx.y * 4 + wave; o < C; o += gridDim.y * 4) {
-        float acc = 0.f;
-        const float* wo = w + (long)o * ksz;
-        for (int k = 0; k < ksz; ++k) acc += wo[k] * win[lane * sf + k];
-        if (q < Tq) x[((long)b * C + o) * Tsq + q] += acc + bias[o];
+    if (grp >= groups || o >= C) return;
+    float acc[VOC_NQ];
+#pragma unroll
+    for (int j = 0; j < VOC_NQ; ++j) acc[j] = 0.f;
+    const float* wbase = win + (grp * VOC_NQ) * sf;
+    for (int k = 0; k < ksz; ++k) {
+        const float w = wt[(long)k * C + o];
+#pragma unroll
+        for (int j = 0; j < VOC_NQ; ++j) acc[j] += w * wbase[j * sf + k];
     }
+    const float bo = bias[o];
+    float* xo = x + ((long)b * C + o) * Tsq + q0 + grp * VOC_NQ;
+#pragma unroll
+    for (int j = 0; j < VOC_NQ; ++j)
+        if (q0 + grp * VOC_NQ + j < Tq) xo[j] += acc[j] + bo;
 }
 
 // acc = first ? r : acc + r;  if scale != 1: acc /= scale      (xs accumulation and `xs / num_kernels`, models.py:280-286)
@@ -103,7 +128,7 @@ hipError_t launch_voc_source(const float* f0, const float* rand_ini, const float
                              const float* lin_b, int B, int T, int upp, int dim, float sr, float sine_amp, float noise_std,
                              float* acc_tmp, int Tsu, float* har, hipStream_t st) {
     if (dim > VOC_MAXDIM) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(voc_phase_kernel, dim3(B), dim3(64), 0, st, f0, T, sr, upp, acc_tmp);
+    hipLaunchKernelGGL(voc_phase_kernel, dim3(B), dim3(256), 0, st, f0, T, sr, upp, acc_tmp);
     const long n = (long)T * upp;
     hipLaunchKernelGGL(voc_source_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, f0, acc_tmp, rand_ini, noise,
                        lin_w, lin_b, T, upp, dim, sr, sine_amp, noise_std, Tsu, har);
@@ -112,10 +137,10 @@ hipError_t launch_voc_source(const float* f0, const float* rand_ini, const float
 
 hipError_t launch_voc_noise_conv(float* x, const float* har, const float* w, const float* bias, int B, int C, int Tq,
                                  int Tsq, int sf, int ksz, long Tup, int Tsu, hipStream_t st) {
-    const int nwin = 63 * sf + ksz;
-    const int ygrid = (C + 3) / 4 < 16 ? (C + 3) / 4 : 16;
-    hipLaunchKernelGGL(voc_noise_conv_kernel, dim3((Tq + 63) / 64, ygrid, B), dim3(256), nwin * sizeof(float), st, x, har, w,
-                       bias, C, Tq, Tsq, sf, ksz, Tup, Tsu);
+    const int cpb = C < 256 ? C : 256, fpb = (256 / cpb) * VOC_NQ;
+    const int nwin = (fpb - 1) * sf + ksz;
+    hipLaunchKernelGGL(voc_noise_conv_kernel, dim3((Tq + fpb - 1) / fpb, (C + cpb - 1) / cpb, B), dim3(256),
+                       nwin * sizeof(float), st, x, har, w, bias, C, Tq, Tsq, sf, ksz, Tup, Tsu);
     return hipGetLastError();
 }
 
