@@ -1,0 +1,312 @@
+"""`.ds` segments in, waveform out: the acoustic inference harness around the HIP modules
+(SURVEY.md section 8(f) rank 4).  Behavioural twin of the reference's `inference/ds_acoustic.py`,
+`basics/base_svs_infer.py:38-131` (speaker mix), `utils/infer_utils.py:41-56,99-118` (curve resampling, cross-fade,
+wav writing), `modules/fastspeech/tts_modules.py:278-311` (length regulator) and the `--depth/--steps` handling of
+`scripts/infer.py:168-198` (= the `depth` / `steps` runtime inputs of the ONNX export,
+`deployment/modules/diffusion.py:105-131`).
+
+Host-side glue only: wire format, resampling, length regulation, speaker mixing, per-segment seeding, cross-fade
+and wav writing, so that a caller does not need the reference checkout at run time.  The phoneme dictionary is
+data handling outside this package: any object with `encode(ph_seq, lang=None) -> list[int]`, `__len__()` and
+`is_cross_lingual(phone) -> bool` works (the reference's `utils.phoneme_utils.PhonemeDictionary` is one;
+`SimplePhonemeTable` covers single-dictionary models).  Segments are run one by one, as the reference does:
+utterance-level parallelism is across GPUs (sharding.py).
+"""
+from __future__ import annotations
+
+import json
+import pathlib
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .hparams import hparams
+
+VARIANCE_NAMES = ('energy', 'breathiness', 'voicing', 'tension')     # param_adaptor.py: VARIANCE_CHECKLIST order
+
+
+# --------------------------------------------------------------------------------------------------- depth / steps
+def apply_depth_steps(hp: dict, depth: Optional[float] = None, steps: Optional[int] = None) -> dict:
+    """Fill the reflow-era keys from the DDPM-era ones (and back), then apply the two runtime knobs:
+    `depth` in (0, 1] = how much of the diffusion is run from the aux mel, `steps` = sampling steps."""
+    shallow = bool(hp['use_shallow_diffusion'])
+    if 'diff_speedup' not in hp and 'pndm_speedup' in hp:
+        hp['diff_speedup'] = hp['pndm_speedup']
+    for new_key, old_key in (('T_start', 'K_step'), ('T_start_infer', 'K_step_infer')):
+        if new_key not in hp:
+            hp[new_key] = 1 - hp[old_key] / hp['timesteps']
+    if 'sampling_steps' not in hp:
+        hp['sampling_steps'] = (hp['K_step_infer'] if shallow else hp['timesteps']) // hp['diff_speedup']
+    if 'time_scale_factor' not in hp:
+        hp['time_scale_factor'] = hp['timesteps']
+    if depth is not None:
+        limit = 1 - hp['T_start']
+        assert depth <= limit, f"Depth should not be larger than 1 - T_start ({limit})"
+        hp['K_step_infer'], hp['T_start_infer'] = round(hp['timesteps'] * depth), 1 - depth
+    if steps is not None:
+        if shallow and 'K_step_infer' in hp:
+            hp['diff_speedup'] = round((1 - hp['T_start_infer']) / steps * hp['K_step_infer'])
+        elif not shallow and 'timesteps' in hp:
+            hp['diff_speedup'] = round(hp['timesteps'] / steps)
+        hp['sampling_steps'] = steps
+    return hp
+
+
+# ------------------------------------------------------------------------------------------------ signal helpers
+def resample_align_curve(points: np.ndarray, original_timestep: float, target_timestep: float, align_length: int):
+    """Linear resampling of a control curve to the model's frame rate, then cut / hold-last to `align_length`."""
+    src_t = original_timestep * np.arange(len(points))
+    dst_t = np.arange(0, (len(points) - 1) * original_timestep, target_timestep)
+    curve = np.interp(dst_t, src_t, points).astype(points.dtype)
+    if len(curve) >= align_length:
+        return curve[:align_length]
+    return np.concatenate((curve, np.full(align_length - len(curve), fill_value=curve[-1])), axis=0)
+
+
+def cross_fade(a: np.ndarray, b: np.ndarray, idx: int):
+    """`b` starts at sample `idx` of `a`; the overlap is blended with a linear ramp (end points included)."""
+    overlap = a.shape[0] - idx
+    ramp = np.linspace(0, 1.0, num=overlap, endpoint=True)
+    out = np.zeros(idx + b.shape[0])
+    out[:idx] = a[:idx]
+    out[idx:a.shape[0]] = (1 - ramp) * a[idx:] + ramp * b[:overlap]
+    out[a.shape[0]:] = b[overlap:]
+    return out
+
+
+def save_wav(wav, path, sr, norm=False):
+    from scipy.io import wavfile
+    scaled = (wav / np.abs(wav).max() if norm else wav) * 32767
+    wavfile.write(path, sr, scaled.astype(np.int16))
+
+
+def length_regulator(dur: torch.Tensor, dur_padding: Optional[torch.Tensor] = None, alpha: Optional[float] = None):
+    """durations [B, T_txt] -> mel2ph [B, T]: frame t carries the 1-based index of the token whose cumulative
+    duration first exceeds t, 0 past the end of its utterance."""
+    assert alpha is None or alpha > 0
+    if alpha is not None:
+        dur = torch.round(dur.float() * alpha).long()
+    if dur_padding is not None:
+        dur = dur * (1 - dur_padding.long())
+    ends = torch.cumsum(dur, 1).contiguous()
+    frames = torch.arange(int(ends[:, -1].max()), device=dur.device)[None, :].expand(dur.shape[0], -1).contiguous()
+    owner = torch.searchsorted(ends, frames, right=True) + 1
+    return torch.where(frames < ends[:, -1:], owner, torch.zeros_like(owner))
+
+
+class SimplePhonemeTable:
+    """Single-dictionary phoneme table: ids 1..N over the sorted phoneme set (AP and SP always present), 0 = padding."""
+
+    def __init__(self, phonemes: Sequence[str]):
+        names = sorted(set(phonemes) | {'AP', 'SP'})
+        self._ids = {name: i + 1 for i, name in enumerate(names)}
+
+    def __len__(self):
+        return len(self._ids) + 1
+
+    def is_cross_lingual(self, phone):
+        return False
+
+    def encode(self, sentence, lang=None):
+        return [self._ids[p.split('/', maxsplit=1)[-1]] for p in sentence.strip().split()]
+
+
+# ------------------------------------------------------------------------------------------------- speaker mix
+def _mix_track(values, name, param, timestep, length, mode, device):
+    """One speaker's proportion over the `length` tokens / frames: a constant, or a curve given as a string."""
+    if not isinstance(values, str):
+        assert values >= 0., f'Speaker mix checks failed.\nProportion of speaker \'{name}\' is negative.'
+        return torch.full((1, length), fill_value=values, dtype=torch.float32, device=device)
+    if mode == 'token':
+        items = values.split()
+        assert len(items) == length, ('Speaker mix checks failed. In dynamic token-level mix, '
+                                      'number of proportion values must equal number of tokens.')
+        track = np.array(items, 'float32')
+    else:
+        track = resample_align_curve(np.array(values.split(), 'float32'), original_timestep=float(param['spk_mix_timestep']),
+                                     target_timestep=timestep, align_length=length)
+    track = torch.from_numpy(track).to(device)[None]
+    assert torch.all(track >= 0.), (f'Speaker mix checks failed.\nProportions of speaker \'{name}\' on some {mode}s '
+                                    f'are negative.')
+    return track
+
+
+def load_speaker_mix(param_src: dict, summary_dst: dict, spk_map: Dict[str, int], timestep: float, device,
+                     mix_mode: str = 'frame', mix_length: int = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> spk_mix_id [1, 1, N], spk_mix_value [1, T or 1, N] (normalised to sum 1 over the N speakers)."""
+    assert mix_mode in ('token', 'frame')
+    key = 'spk_mix' if mix_mode == 'frame' else 'ph_spk_mix'
+    mix = param_src.get(key)
+    if mix is None:
+        assert len(spk_map) == 1, "This is a multi-speaker model. Please specify a speaker or speaker mix by --spk option."
+        mix = {next(iter(spk_map)): 1.0}
+    for name in mix:
+        assert name in spk_map, f'Speaker \'{name}\' not found.'
+    dynamic = len(mix) > 1 and any(isinstance(v, str) for v in mix.values())
+    if len(mix) == 1:
+        summary_dst['spk' if mix_mode == 'frame' else 'ph_spk'] = next(iter(mix))
+    elif dynamic:
+        summary_dst[key] = f"dynamic({'|'.join(mix)})"
+    else:
+        summary_dst[key] = 'static(' + '|'.join(f'{n}:{mix[n]:.3f}' for n in mix) + ')'
+    ids = torch.LongTensor([spk_map[n] for n in mix]).to(device)[None, None]
+    if dynamic:
+        weights = torch.stack([_mix_track(v, n, param_src, timestep, mix_length, mix_mode, device) for n, v in mix.items()],
+                              dim=2)
+        total = weights.sum(dim=2, keepdim=True)
+        assert torch.all(total > 0.), 'Speaker mix checks failed.\nProportions of speaker mix on some frames sum to zero.'
+    else:
+        for n, v in mix.items():
+            assert v >= 0., f'Speaker mix checks failed.\nProportion of speaker \'{n}\' is negative.'
+        weights = torch.FloatTensor(list(mix.values())).to(device)[None, None]
+        total = weights.sum()
+        assert total > 0., 'Speaker mix checks failed.\nProportions of speaker mix sum to zero.'
+    return ids, weights / total
+
+
+def load_ds(path) -> List[dict]:
+    """A `.ds` project: a JSON list of segments (or one segment object)."""
+    with open(path, 'r', encoding='utf8') as f:
+        params = json.load(f)
+    return params if isinstance(params, list) else [params]
+
+
+# ----------------------------------------------------------------------------------------------------- harness
+class AcousticHarness:
+    """`model` = diffsinger_amd.toplevel.DiffSingerAcoustic (or any module with the reference's forward signature),
+    `vocoder` = diffsinger_amd.vocoder.NsfHifiGAN or None (mel output only)."""
+
+    def __init__(self, model, vocoder, phoneme_dictionary, spk_map: Optional[Dict[str, int]] = None,
+                 lang_map: Optional[Dict[str, int]] = None, device=None):
+        self.model, self.vocoder, self.phoneme_dictionary = model, vocoder, phoneme_dictionary
+        self.spk_map, self.lang_map = spk_map or {}, lang_map or {}
+        self.device = device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu')
+        self.timestep = hparams['hop_size'] / hparams['audio_sample_rate']
+        self.variances_to_embed = {v for v in VARIANCE_NAMES if hparams.get(f'use_{v}_embed', False)}
+        if hparams['use_spk_id']:
+            assert isinstance(self.spk_map, dict) and len(self.spk_map) > 0, 'Invalid or empty speaker map!'
+            assert len(self.spk_map) == len(set(self.spk_map.values())), 'Duplicate speaker id in speaker map!'
+
+    # -- one segment -> model inputs --------------------------------------------------------------------------
+    def _curve(self, param, key, step_key, length):
+        return resample_align_curve(np.array(param[key].split(), np.float32), original_timestep=float(param[step_key]),
+                                    target_timestep=self.timestep, align_length=length)
+
+    def _tokens(self, param, batch):
+        lang = param.get('lang')
+        if lang is None:
+            assert len(self.lang_map) <= 1, "This is a multilingual model. Please specify a language by --lang option."
+        else:
+            assert lang in self.lang_map, f'Unrecognized language name: \'{lang}\'.'
+        phones = param['ph_seq'].split()
+        if hparams.get('use_lang_id', False):
+            def lang_id(p):
+                if not self.phoneme_dictionary.is_cross_lingual(p):
+                    return 0
+                return self.lang_map[p.split('/', maxsplit=1)[0] if '/' in p else lang]
+            batch['languages'] = torch.LongTensor([lang_id(p) for p in phones]).to(self.device)
+        batch['tokens'] = torch.LongTensor([self.phoneme_dictionary.encode(param['ph_seq'], lang=lang)]).to(self.device)
+
+    def _frames(self, param, batch):
+        """Phoneme durations in seconds -> integer frame counts by rounding the cumulative boundaries, -> mel2ph."""
+        seconds = torch.from_numpy(np.array(param['ph_dur'].split(), np.float32)).to(self.device)
+        bounds = torch.round(torch.cumsum(seconds, dim=0) / self.timestep + 0.5).long()
+        frames = torch.diff(bounds, dim=0, prepend=torch.zeros(1, dtype=torch.long, device=self.device))[None]
+        batch['mel2ph'] = length_regulator(frames, batch['tokens'] == 0)
+        return batch['mel2ph'].size(1)
+
+    def _key_shift(self, param, length):
+        lo, hi = hparams['augmentation_args']['random_pitch_shifting']['range']
+        gender = param.get('gender', None)
+        gender = 0. if gender is None else gender
+        if isinstance(gender, (int, float, bool)):
+            value = gender * hi if gender >= 0 else gender * abs(lo)
+            return torch.FloatTensor([value]).to(self.device)[:, None], f'static({gender:.3f})'
+        curve = self._curve(param, 'gender', 'gender_timestep', length)
+        up = curve >= 0
+        shift = curve * (up * hi + (1 - up) * abs(lo))
+        return torch.clip(torch.from_numpy(shift.astype(np.float32)).to(self.device)[None], min=lo, max=hi), 'dynamic'
+
+    def _speed(self, param, length):
+        if param.get('velocity') is None:
+            return torch.FloatTensor([1.]).to(self.device)[:, None], 'default'
+        lo, hi = hparams['augmentation_args']['random_time_stretching']['range']
+        curve = self._curve(param, 'velocity', 'velocity_timestep', length)
+        return torch.clip(torch.from_numpy(curve.astype(np.float32)).to(self.device)[None], min=lo, max=hi), 'manual'
+
+    def preprocess_input(self, param: dict, idx: int = 0, verbose: bool = False) -> Dict[str, torch.Tensor]:
+        batch, summary = {}, {}
+        self._tokens(param, batch)
+        length = self._frames(param, batch)
+        summary.update(tokens=batch['tokens'].size(1), frames=length, seconds='%.2f' % (length * self.timestep))
+        if hparams['use_spk_id']:
+            batch['spk_mix_id'], batch['spk_mix_value'] = load_speaker_mix(
+                param, summary, self.spk_map, self.timestep, self.device, mix_mode='frame', mix_length=length)
+        batch['f0'] = torch.from_numpy(self._curve(param, 'f0_seq', 'f0_timestep', length)).to(self.device)[None]
+        for name in VARIANCE_NAMES:
+            if name in self.variances_to_embed:
+                batch[name] = torch.from_numpy(self._curve(param, name, f'{name}_timestep', length)).to(self.device)[None]
+                summary[name] = 'manual'
+        if hparams['use_key_shift_embed']:
+            batch['key_shift'], summary['gender'] = self._key_shift(param, length)
+        if hparams['use_speed_embed']:
+            batch['speed'], summary['velocity'] = self._speed(param, length)
+        if verbose:
+            print(f'[{idx}]\t' + ', '.join(f'{k}: {v}' for k, v in summary.items()))
+        return batch
+
+    # -- model, vocoder ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_model(self, sample):
+        kwargs = {v: sample.get(v) for v in self.variances_to_embed}
+        if hparams['use_spk_id']:
+            table = self.model.fs2.spk_embed(sample['spk_mix_id'])                       # [1, 1, N, H]
+            kwargs['spk_mix_embed'] = torch.sum(table * sample['spk_mix_value'].unsqueeze(3), dim=2, keepdim=False)
+        else:
+            kwargs['spk_mix_embed'] = None
+        out = self.model(sample['tokens'], languages=sample.get('languages'), mel2ph=sample['mel2ph'], f0=sample['f0'],
+                         key_shift=sample.get('key_shift'), speed=sample.get('speed'), infer=True, **kwargs)
+        return out.diff_out
+
+    @torch.no_grad()
+    def run_vocoder(self, spec, **kwargs):
+        return self.vocoder.spec2wav_torch(spec, **kwargs)[None]
+
+    # -- a whole project --------------------------------------------------------------------------------------
+    @staticmethod
+    def _seed(value):
+        torch.manual_seed(value & 0xffff_ffff)
+        torch.cuda.manual_seed_all(value & 0xffff_ffff)
+
+    def run_inference(self, params: List[dict], out_path=None, seed: int = -1, save_mel: bool = False):
+        """One pass over the segments of a project: returns the assembled waveform (or the list of mels) and, when
+        `out_path` is given, writes it.  Each segment is placed at its `offset`; where it overlaps what is already
+        there the two are cross-faded."""
+        batches = [self.preprocess_input(param, idx=i) for i, param in enumerate(params)]
+        mels, track, cursor = [], np.zeros(0), 0
+        for param, batch in zip(params, batches):
+            if 'seed' in param:
+                self._seed(param['seed'])
+            elif seed >= 0:
+                self._seed(seed)
+            mel = self.forward_model(batch)
+            if save_mel:
+                mels.append({'offset': param.get('offset', 0.), 'mel': mel.cpu(), 'f0': batch['f0'].cpu()})
+                continue
+            wav = self.run_vocoder(mel, f0=batch['f0'])[0].cpu().numpy()
+            gap = round(param.get('offset', 0) * hparams['audio_sample_rate']) - cursor
+            if gap >= 0:
+                track = np.concatenate((track, np.zeros(gap), wav))
+            else:
+                track = cross_fade(track, wav, cursor + gap)
+            cursor += gap + wav.shape[0]
+        result = mels if save_mel else track
+        if out_path is not None:
+            out_path = pathlib.Path(out_path)
+            out_path.parent.mkdir(parents=True, exist_ok=True)
+            if save_mel:
+                torch.save(result, out_path)
+            else:
+                save_wav(result, out_path, hparams['audio_sample_rate'])
+        return result

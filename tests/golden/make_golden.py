@@ -664,8 +664,89 @@ def g10_vocoder():
     save("g10_vocoder", **out)
 
 
+# --------------------------------------------------------------------------- G11: .ds harness (host-side wire format)
+def make_ds_segments():
+    """A synthetic three-segment project in the .ds wire format (written next to the fixtures as g11_segments.ds)."""
+    rng = np.random.Generator(np.random.PCG64(1100))
+    phones = ["a", "b", "c", "d", "e", "SP", "AP"]
+    segs = []
+    offset = 0.0
+    for i, n_ph in enumerate((6, 9, 5)):
+        ph = [phones[int(k)] for k in rng.integers(0, len(phones), n_ph)]
+        dur = rng.uniform(0.05, 0.4, n_ph).round(4)
+        total = float(dur.sum())
+        n_f0 = int(total / 0.005) + 1
+        f0 = (220.0 * 2.0 ** rng.uniform(-0.5, 0.5, n_f0)).round(1)
+        seg = {"offset": round(offset, 3), "ph_seq": " ".join(ph), "ph_dur": " ".join(str(v) for v in dur),
+               "f0_seq": " ".join(str(v) for v in f0), "f0_timestep": "0.005",
+               "energy": " ".join(str(v) for v in rng.uniform(-60, -10, n_f0 // 2).round(2)), "energy_timestep": "0.01",
+               "seed": 100 + i}
+        if i == 0:
+            seg["gender"] = -0.5
+            seg["spk_mix"] = {"alice": 0.25, "bob": 0.75}
+        elif i == 1:
+            seg["gender"] = " ".join(str(v) for v in rng.uniform(-1, 1, 40).round(3))
+            seg["gender_timestep"] = str(round(total / 39, 5))
+            seg["velocity"] = " ".join(str(v) for v in rng.uniform(0.3, 2.5, 30).round(3))
+            seg["velocity_timestep"] = str(round(total / 29, 5))
+            seg["spk_mix"] = {"alice": " ".join(str(v) for v in rng.uniform(0, 1, 25).round(3)), "bob": 0.5}
+            seg["spk_mix_timestep"] = str(round(total / 24, 5))
+        else:
+            seg["spk_mix"] = {"bob": 1.0}
+        segs.append(seg)
+        offset += total * 0.9                       # the next segment overlaps the tail of this one: cross-fade
+    return segs
+
+
+def g11_harness():
+    import json
+    import types
+    lib = types.ModuleType("librosa")
+    lib.__path__ = []
+    filt = types.ModuleType("librosa.filters")
+    filt.mel = lambda *a, **k: None
+    sys.modules.setdefault("librosa", lib)
+    sys.modules.setdefault("librosa.filters", filt)
+    from inference.ds_acoustic import DiffSingerAcousticInfer  # (reference)
+    from modules.fastspeech.tts_modules import LengthRegulator  # (reference)
+    from utils.infer_utils import cross_fade, resample_align_curve  # (reference)
+    from diffsinger_amd.harness import SimplePhonemeTable
+    out = {}
+    segs = make_ds_segments()
+    with open(os.path.join(HERE, "g11_segments.ds"), "w", encoding="utf8") as f:
+        json.dump(segs, f, indent=1)
+    set_hp(hop_size=512, audio_sample_rate=44100, use_spk_id=True, use_lang_id=False, use_energy_embed=True,
+           use_key_shift_embed=True, use_speed_embed=True,
+           augmentation_args=dict(random_pitch_shifting=dict(range=[-5.0, 5.0]), random_time_stretching=dict(range=[0.5, 2.0])))
+    fake = types.SimpleNamespace(device="cpu", timestep=512 / 44100, lang_map={}, spk_map={"alice": 0, "bob": 1, "carol": 2},
+                                 phoneme_dictionary=SimplePhonemeTable(["a", "b", "c", "d", "e"]),
+                                 variances_to_embed={"energy"}, lr=LengthRegulator())
+    fake.load_speaker_mix = types.MethodType(DiffSingerAcousticInfer.load_speaker_mix, fake)
+    import contextlib, io
+    for i, seg in enumerate(segs):
+        with contextlib.redirect_stdout(io.StringIO()):
+            batch = DiffSingerAcousticInfer.preprocess_input(fake, seg, idx=i)
+        for k, v in batch.items():
+            out[f"seg{i}_{k}"] = v.numpy()
+    # the small pieces on their own
+    rng = np.random.Generator(np.random.PCG64(1101))
+    dur = torch.from_numpy(rng.integers(0, 7, (3, 11)))
+    pad = torch.from_numpy(rng.integers(0, 2, (3, 11)) * (np.arange(11)[None] > 7))
+    out["lr_dur"], out["lr_pad"] = dur.numpy(), pad.numpy()
+    out["lr_mel2ph"] = LengthRegulator()(dur, pad.bool()).numpy()
+    out["lr_mel2ph_alpha"] = LengthRegulator()(dur, None, 1.3).numpy()
+    pts = rng.uniform(0, 1, 57).astype(np.float32)
+    out["rs_points"] = pts
+    out["rs_long"] = resample_align_curve(pts, 0.01, 512 / 44100, 80)
+    out["rs_short"] = resample_align_curve(pts, 0.01, 512 / 44100, 30)
+    a, b = rng.standard_normal(1000), rng.standard_normal(700)
+    out["cf_a"], out["cf_b"] = a, b
+    out["cf_out"] = cross_fade(a, b, 820)
+    save("g11_harness", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -684,3 +765,5 @@ if __name__ == "__main__":
         g9_acoustic_model()
     if "g10" in which:
         g10_vocoder()
+    if "g11" in which:
+        g11_harness()

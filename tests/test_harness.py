@@ -1,0 +1,102 @@
+"""Host-side `.ds` harness against fixtures produced by the reference's own
+`DiffSingerAcousticInfer.preprocess_input`, `LengthRegulator`, `resample_align_curve` and `cross_fade` (G11), plus the
+`--depth/--steps` arithmetic of scripts/infer.py.  Integer outputs must match exactly, float32 ones bit for bit
+(same numpy / torch CPU operations)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from diffsinger_amd import harness
+from diffsinger_amd.hparams import hparams
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HP = dict(hop_size=512, audio_sample_rate=44100, use_spk_id=True, use_lang_id=False, use_energy_embed=True,
+          use_key_shift_embed=True, use_speed_embed=True,
+          augmentation_args=dict(random_pitch_shifting=dict(range=[-5.0, 5.0]), random_time_stretching=dict(range=[0.5, 2.0])))
+
+
+@pytest.fixture
+def hp():
+    saved = dict(hparams)
+    hparams.clear()
+    hparams.update(HP)
+    yield hparams
+    hparams.clear()
+    hparams.update(saved)
+
+
+def test_preprocess_input_matches_reference(hp):
+    g = np.load(os.path.join(GOLDEN, "g11_harness.npz"))
+    segs = harness.load_ds(os.path.join(GOLDEN, "g11_segments.ds"))
+    assert len(segs) == 3
+    h = harness.AcousticHarness(None, None, harness.SimplePhonemeTable(["a", "b", "c", "d", "e"]),
+                                spk_map={"alice": 0, "bob": 1, "carol": 2}, device="cpu")
+    for i, seg in enumerate(segs):
+        batch = h.preprocess_input(seg, idx=i)
+        keys = {k[len(f"seg{i}_"):] for k in g.files if k.startswith(f"seg{i}_")}
+        assert set(batch) == keys
+        for k in keys:
+            got, want = batch[k].numpy(), g[f"seg{i}_{k}"]
+            assert got.shape == want.shape and got.dtype == want.dtype, (i, k)
+            np.testing.assert_array_equal(got, want, err_msg=f"segment {i} {k}")
+    # the mix proportions sum to one on every frame, padding-free mel2ph covers every token
+    assert np.allclose(g["seg1_spk_mix_value"].sum(-1), 1.0, atol=1e-6)
+    assert set(np.unique(g["seg1_mel2ph"])) == set(range(1, g["seg1_tokens"].shape[1] + 1))
+
+
+def test_length_regulator_resample_cross_fade():
+    g = np.load(os.path.join(GOLDEN, "g11_harness.npz"))
+    dur, pad = torch.from_numpy(g["lr_dur"]), torch.from_numpy(g["lr_pad"]).bool()
+    np.testing.assert_array_equal(harness.length_regulator(dur, pad).numpy(), g["lr_mel2ph"])
+    np.testing.assert_array_equal(harness.length_regulator(dur, None, 1.3).numpy(), g["lr_mel2ph_alpha"])
+    np.testing.assert_array_equal(harness.resample_align_curve(g["rs_points"], 0.01, 512 / 44100, 80), g["rs_long"])
+    np.testing.assert_array_equal(harness.resample_align_curve(g["rs_points"], 0.01, 512 / 44100, 30), g["rs_short"])
+    np.testing.assert_array_equal(harness.cross_fade(g["cf_a"], g["cf_b"], 820), g["cf_out"])
+
+
+def test_speaker_mix_checks(hp):
+    spk = {"alice": 0, "bob": 1}
+    with pytest.raises(AssertionError, match="multi-speaker"):
+        harness.load_speaker_mix({}, {}, spk, 0.0116, "cpu", mix_length=5)
+    with pytest.raises(AssertionError, match="not found"):
+        harness.load_speaker_mix({"spk_mix": {"zed": 1.0}}, {}, spk, 0.0116, "cpu", mix_length=5)
+    with pytest.raises(AssertionError, match="negative"):
+        harness.load_speaker_mix({"spk_mix": {"alice": -1.0, "bob": 2.0}}, {}, spk, 0.0116, "cpu", mix_length=5)
+    with pytest.raises(AssertionError, match="sum to zero"):
+        harness.load_speaker_mix({"spk_mix": {"alice": 0.0, "bob": 0.0}}, {}, spk, 0.0116, "cpu", mix_length=5)
+    summary = {}
+    ids, vals = harness.load_speaker_mix({"spk_mix": {"alice": 1.0, "bob": 3.0}}, summary, spk, 0.0116, "cpu", mix_length=5)
+    assert ids.tolist() == [[[0, 1]]] and np.allclose(vals.numpy(), [[[0.25, 0.75]]])
+    assert summary == {"spk_mix": "static(alice:1.000|bob:3.000)"}
+    ids, vals = harness.load_speaker_mix({"ph_spk_mix": {"alice": "1 0 1", "bob": 1.0}}, {}, spk, 0.0116, "cpu",
+                                         mix_mode="token", mix_length=3)
+    assert tuple(vals.shape) == (1, 3, 2) and np.allclose(vals.numpy()[0, :, 0], [0.5, 0.0, 0.5])
+
+
+def test_depth_and_steps_arithmetic():
+    """scripts/infer.py:168-198 on the reference fork's acoustic.yaml values."""
+    base = dict(use_shallow_diffusion=True, timesteps=1000, K_step=400, K_step_infer=400, diff_speedup=10)
+    hp1 = harness.apply_depth_steps(dict(base))
+    assert hp1["T_start"] == pytest.approx(0.6) and hp1["T_start_infer"] == pytest.approx(0.6)
+    assert hp1["sampling_steps"] == 40 and hp1["time_scale_factor"] == 1000
+    hp2 = harness.apply_depth_steps(dict(base), depth=0.3, steps=15)
+    assert hp2["K_step_infer"] == 300 and hp2["T_start_infer"] == pytest.approx(0.7)
+    assert hp2["diff_speedup"] == round(0.3 / 15 * 300) == 6 and hp2["sampling_steps"] == 15
+    with pytest.raises(AssertionError, match="Depth"):
+        harness.apply_depth_steps(dict(base), depth=0.5)
+    hp3 = harness.apply_depth_steps(dict(use_shallow_diffusion=False, timesteps=1000, K_step=1000, K_step_infer=1000,
+                                         pndm_speedup=20), steps=50)
+    assert hp3["diff_speedup"] == 20 and hp3["sampling_steps"] == 50
+
+
+def test_save_wav_roundtrip(tmp_path):
+    from scipy.io import wavfile
+    wav = np.sin(np.linspace(0, 40, 4410)) * 0.5
+    harness.save_wav(wav, tmp_path / "a.wav", 44100)
+    sr, data = wavfile.read(tmp_path / "a.wav")
+    assert sr == 44100 and data.dtype == np.int16 and np.array_equal(data, (wav * 32767).astype(np.int16))
+    table = harness.SimplePhonemeTable(["x", "y"])
+    assert len(table) == 5 and table.encode("SP x zh/y AP") == [2, 3, 4, 1]
