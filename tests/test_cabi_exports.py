@@ -149,3 +149,13 @@ def test_encoder_state_dict_matches_reference_layout():
           energy=torch.zeros(1, 5), tension=torch.zeros(1, 5), key_shift=torch.zeros(1, 5), speed=torch.ones(1, 5))
     hparams.clear()
     hparams.update(hidden_size=256)
+
+
+def test_header_is_plain_c99():
+    """include/dsdenoise.h must be consumable by a C compiler (no C++ in the boundary)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dsdenoise.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", header], check=True)
