@@ -98,7 +98,7 @@ struct dsd_handle {
     float* arena = nullptr;
     size_t arena_floats = 0;
     float *cond_i = nullptr, *cp = nullptr, *xh = nullptr, *z = nullptr, *skip = nullptr, *hbuf = nullptr;
-    float *xin = nullptr, *ubuf = nullptr, *vbuf = nullptr, *stats = nullptr;
+    float *xin = nullptr, *ubuf = nullptr, *vbuf = nullptr, *stats = nullptr, *lnpart = nullptr;
     float *io_in = nullptr, *io_out = nullptr;
     bool cond_ready = false;
     // sampler state buffers
@@ -749,7 +749,7 @@ int ensure_workspace(dsd_handle* h, int B, int T) {
     const size_t per = (size_t)B * Ts;
     const size_t o_cond = take(per * H), o_cp = is_aux(h) ? 0 : take(per * L * cp_rows(h)), o_xh = take(per * C);
     const size_t o_in = is_aux(h) ? 0 : take(per * FM), o_out = take(per * FM);
-    size_t o_z = 0, o_skip = 0, o_h = 0, o_xin = 0, o_u = 0, o_v = 0, o_st = 0;
+    size_t o_z = 0, o_skip = 0, o_h = 0, o_xin = 0, o_u = 0, o_v = 0, o_st = 0, o_lp = 0;
     if (is_aux(h)) {
         o_xin = take(per * C);
         o_u = take(per * 4 * C);
@@ -763,6 +763,7 @@ int ensure_workspace(dsd_handle* h, int B, int T) {
         o_u = take(per * inner_of(h));
         o_v = take(per * inner_of(h));
         o_st = take(per * 2);
+        o_lp = take(per * 2 * ((C + 63) / 64));
     }
     off += kGuard;
     float* a = nullptr;
@@ -775,7 +776,7 @@ int ensure_workspace(dsd_handle* h, int B, int T) {
     h->B = B; h->T = T; h->Ts = Ts;
     h->cond_i = a + o_cond; h->cp = a + o_cp; h->xh = a + o_xh; h->io_in = a + o_in; h->io_out = a + o_out;
     h->z = a + o_z; h->skip = a + o_skip; h->hbuf = a + o_h;
-    h->xin = a + o_xin; h->ubuf = a + o_u; h->vbuf = a + o_v; h->stats = a + o_st;
+    h->xin = a + o_xin; h->ubuf = a + o_u; h->vbuf = a + o_v; h->stats = a + o_st; h->lnpart = a + o_lp;
     return DSD_OK;
 }
 
@@ -880,7 +881,7 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
         int s16 = 16 + 2 * p.HL;
         while (s16 % 32 != 16) s16 += 4;
         const bool ok = (g.taps == 1 || g.taps == 3) && g.K % 64 == 0 && g.Kreal == g.K && stage != ST_LN &&
-                        epi != EP_SWIGLU && gemm_has_fast(g.taps, 0, s16);
+                        epi != EP_SWIGLU && epi != EP_LYNX_NEXT && gemm_has_fast(g.taps, 0, s16);
         if (ok && !generic_only && (force == 1 || (force != 0 && wg32 <= 192))) c.nb = 0;
     }
     const int BN = c.nb == 0 ? 16 : 32 * c.nb;
@@ -900,7 +901,7 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     c.fast = !generic_only && (g.taps == 1 || g.taps == 3) && (g.K % gemm_fast_chunk_rows(g.taps, c.nb) == 0) &&
              (g.Kreal == g.K) && gemm_has_fast(g.taps, c.nb, S);
     // small grids (one workgroup per CU, one wave per SIMD): all <= 4 chunks resident, no barrier in the K walk
-    if (c.fast && c.nb <= 1 && g.K <= 256 && g.taps == 1) c.fast = 2;
+    if (c.fast && c.nb <= 1 && g.K <= 256 && g.taps == 1 && epi != EP_LYNX_NEXT) c.fast = 2;
     p.lds_bytes = c.fast ? gemm_lds_bytes_fast(S, stage, g.taps, g.K, c.nb, c.fast == 2) : gemm_lds_bytes(p.KC, S);
     if (epi == EP_GATE || epi == EP_RESSKIP)        // the LDS-staged epilogue tile [64][BN + 4]
         p.lds_bytes = std::max(p.lds_bytes, 64 * (BN + 4) * 4);
@@ -974,10 +975,26 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
         (void)hipEventRecord(h->cal_pool[h->cal_used].second, st);
         ++h->cal_used;
     }
+    const bool lynx = !is_wavenet(h);
+    const int ln_tiles = (C + 63) / 64;
+    // LYNXNet layer transition, fused into the producing GEMM's epilogue (lynxnet.py:76-84): `next` = the layer whose
+    // conditioner / step projections are added (L = none: only the final LayerNorm follows)
+    auto lynx_next = [&](GemmCall& g, int next) {
+        g.p.out = h->xh; g.p.o_bstride = xs; g.p.o_rstride = Ts;
+        g.p.out2 = next < L ? h->xin : nullptr;
+        g.p.lnpart = h->lnpart; g.p.lnpart_ts = Ts;
+        g.p.strong = h->cfg.strong_cond;
+        if (next < L) {
+            g.p.cpn = h->cp + (long)next * C * Ts; g.p.cpn_bstride = (long)L * C * Ts; g.p.cpn_rstride = Ts;
+            g.p.film = h->D + (long)next * C * Ns; g.p.film_cstride = Ns; g.p.film_col0 = film_col0; g.p.film_colb = film_colb;
+        }
+    };
     {   // input projection (+ReLU for WaveNet, wavenet.py:86-88; GELU unless strong_cond for LYNXNet, lynxnet.py:141-143)
-        GemmCall g = make_gemm(h, h->g_inproj, xin_state, (long)FM * Ts, Ts, B, T, ST_PLAIN, EP_BIAS_ACT, 0);
+        GemmCall g = make_gemm(h, h->g_inproj, xin_state, (long)FM * Ts, Ts, B, T, ST_PLAIN,
+                               lynx ? EP_LYNX_NEXT : EP_BIAS_ACT, 0);
         g.p.act = is_wavenet(h) ? ACT_RELU : (h->cfg.strong_cond ? ACT_NONE : ACT_GELU);
         g.p.out = h->xh; g.p.o_bstride = xs; g.p.o_rstride = Ts;
+        if (lynx) lynx_next(g, 0);
         if ((rc = run_gemm(h, g, st))) return rc;
     }
     if (is_wavenet(h)) {
@@ -1009,14 +1026,19 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
     }
     // ---- LYNXNet (lynxnet.py:76-87, 145-154) ----
     const int inner = inner_of(h);
-    const long cps = (long)L * C * Ts, us = (long)inner * Ts;
+    const long us = (long)inner * Ts;
     hipError_t e;
-    for (int l = 0; l < L; ++l) {
-        e = launch_lynx_pre(h->xh, h->xin, h->cp + (long)l * C * Ts, cps, h->D + (long)l * C * Ns, Ns, film_col0,
-                            film_colb, xs, Ts, C, B, T, h->cfg.strong_cond, h->stats, Ts, 1e-5f, st);
-        if (e != hipSuccess) return fail(h, DSD_EHIP, "lynx_pre launch failed: %s", hipGetErrorString(e));
-        GemmCall g = make_gemm(h, h->g_pw1[l], h->xin, xs, Ts, B, T, ST_LN, EP_SWIGLU, 0);
+    // LayerNorm statistics of the next GEMM's input: merged from the producer's per-tile partials by a small kernel
+    // (merging inside the consuming GEMM's prologue was measured slower: every one of its ~1 k workgroups repeats it)
+    auto ln_input = [&](GemmCall& g) -> int {
+        hipError_t me = launch_ln_merge(h->lnpart, ln_tiles, C, B, T, Ts, 1e-5f, h->stats, st);
+        if (me != hipSuccess) return fail(h, DSD_EHIP, "LayerNorm merge launch failed: %s", hipGetErrorString(me));
         g.p.ln_stats = h->stats; g.p.ln_ts = Ts;
+        return DSD_OK;
+    };
+    for (int l = 0; l < L; ++l) {
+        GemmCall g = make_gemm(h, h->g_pw1[l], h->xin, xs, Ts, B, T, ST_LN, EP_SWIGLU, 0);
+        if ((rc = ln_input(g))) return rc;
         g.p.out = h->ubuf; g.p.o_bstride = us; g.p.o_rstride = Ts;
         timed_begin();
         rc = run_gemm(h, g, st);
@@ -1026,15 +1048,14 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                           h->cfg.kernel_size, h->cfg.activation,
                           h->dw_prelu[l] == SIZE_MAX ? nullptr : h->blob + h->dw_prelu[l], st);
         if (e != hipSuccess) return fail(h, DSD_EHIP, "dwconv launch failed: %s", hipGetErrorString(e));
-        GemmCall o = make_gemm(h, h->g_pw2[l], h->vbuf, us, Ts, B, T, ST_PLAIN, EP_BIAS_RES, 0);
+        GemmCall o = make_gemm(h, h->g_pw2[l], h->vbuf, us, Ts, B, T, ST_PLAIN, EP_LYNX_NEXT, 0);
+        o.p.act = ACT_NONE;
         o.p.aux = h->xh; o.p.aux_bstride = xs; o.p.aux_rstride = Ts;
-        o.p.out = h->xh; o.p.o_bstride = xs; o.p.o_rstride = Ts;
+        lynx_next(o, l + 1);
         if ((rc = run_gemm(h, o, st))) return rc;
     }
-    e = launch_lynx_pre(h->xh, nullptr, nullptr, 0, nullptr, 0, 0, 0, xs, Ts, C, B, T, 0, h->stats, Ts, 1e-5f, st);
-    if (e != hipSuccess) return fail(h, DSD_EHIP, "final LayerNorm stats launch failed: %s", hipGetErrorString(e));
     GemmCall f = make_gemm(h, h->g_out, h->xh, xs, Ts, B, T, ST_LN, EP_LINCOMB, 0);
-    f.p.ln_stats = h->stats; f.p.ln_ts = Ts;
+    if ((rc = ln_input(f))) return rc;
     f.p.nout = nout;
     for (int i = 0; i < nout; ++i) f.p.lo[i] = lo[i];
     f.p.o_bstride = (long)FM * Ts; f.p.o_rstride = Ts;

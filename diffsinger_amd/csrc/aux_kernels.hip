@@ -346,4 +346,53 @@ hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// LayerNorm statistics from per-tile partials (EP_LYNX_NEXT writes, per 64-row tile i: n_i rows, mean_i, M2_i = sum of
+// squared deviations from mean_i).  Parallel-variance merge:  mean = sum n_i mean_i / C,
+// M2 = sum M2_i + sum n_i (mean_i - mean)^2;  stats[b][0][t] = mean, stats[b][1][t] = 1 / sqrt(M2 / C + eps).
+// ---------------------------------------------------------------------------------------------
+// One workgroup = 16 frames x 16 tile slots: every thread fetches ONE partial pair (a single load round, coalesced
+// along the frames), the tiles are combined through LDS.
+__global__ __launch_bounds__(256) void ln_merge_kernel(const float* __restrict__ lnpart, int mtiles, int C, int T, int ts,
+                                                       float eps, float* __restrict__ stats) {
+    __shared__ float sm[16][17], sq[16][17], mean_s[16];
+    const int b = blockIdx.y;
+    const int f = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int t = min(blockIdx.x * 16 + f, ts - 1);
+    const float* lp = lnpart + (long)b * mtiles * 2 * ts + t;
+    float wsum = 0.f;                              // sum over this slot's tiles of n_i * mean_i
+    for (int i = slot; i < mtiles; i += 16) wsum += (float)min(64, C - i * 64) * lp[(long)i * 2 * ts];
+    sm[slot][f] = wsum;
+    __syncthreads();
+    if (slot == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sm[k][f];
+        mean_s[f] = s / (float)C;
+    }
+    __syncthreads();
+    const float mean = mean_s[f];
+    float m2 = 0.f;
+    for (int i = slot; i < mtiles; i += 16) {
+        const float d = lp[(long)i * 2 * ts] - mean;
+        m2 += lp[(long)i * 2 * ts + ts] + (float)min(64, C - i * 64) * d * d;
+    }
+    sq[slot][f] = m2;
+    __syncthreads();
+    if (slot == 0 && blockIdx.x * 16 + f < ts) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sq[k][f];
+        float* st = stats + (long)b * 2 * ts;
+        st[t] = mean;
+        st[ts + t] = 1.f / sqrtf(s / (float)C + eps);
+    }
+}
+
+hipError_t launch_ln_merge(const float* lnpart, int mtiles, int C, int B, int T, int ts, float eps, float* stats,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(ln_merge_kernel, dim3((ts + 15) / 16, B), dim3(256), 0, stream, lnpart, mtiles, C, T, ts, eps, stats);
+    return hipGetLastError();
+}
+
 }  // namespace dsd

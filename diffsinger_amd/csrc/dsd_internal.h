@@ -17,7 +17,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int padded_ts(int T) { return round_up(T, 64) + 32; }
 
 enum Stage { ST_PLAIN = 0, ST_FILM = 1, ST_LN = 2, ST_SCALE = 3, ST_LRELU = 4 };
-enum Epi { EP_BIAS_ACT = 0, EP_GATE = 1, EP_RESSKIP = 2, EP_LINCOMB = 3, EP_SWIGLU = 4, EP_BIAS_RES = 5, EP_SCATTER = 6 };
+enum Epi { EP_BIAS_ACT = 0, EP_GATE = 1, EP_RESSKIP = 2, EP_LINCOMB = 3, EP_SWIGLU = 4, EP_BIAS_RES = 5, EP_SCATTER = 6, EP_LYNX_NEXT = 7 };
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3, ACT_LRELU = 4, ACT_TANH = 5 };
 
 constexpr int kMaxTerms = 8;
@@ -81,6 +81,17 @@ struct GemmP {
     float* skip;            // EP_RESSKIP: running skip sum
     int first_layer;        // EP_RESSKIP: 1 = skip is written, not accumulated
     int up;                 // EP_SCATTER: upsampling factor u; row r*C + o, column t -> out[o][u*t + r] (C = p.C)
+    // EP_LYNX_NEXT (LYNXNet layer transition): v = act(acc + bias) (+ aux);  with the NEXT layer's conditioner
+    // projection cpn and step projection (film fields):  strong: x = v + cpn, xin = x + d;  else: x = v, xin = v + cpn + d;
+    // cpn == nullptr (after the last layer): x = xin = v.  out = x, out2 = xin (may be nullptr), and per 64-row tile the
+    // LayerNorm partials of xin over its rows: lnpart[b][mtile][0][t] = mean, [1][t] = sum of squared deviations.
+    float* out2;
+    const float* cpn;
+    long cpn_bstride;
+    int cpn_rstride;
+    int strong;
+    float* lnpart;
+    int lnpart_ts;
     int nout;               // EP_LINCOMB
     LinOut lo[kMaxOut];
 };
@@ -157,6 +168,8 @@ hipError_t launch_enc_attention(const float* qkv, const float* nonpad, float* ou
                                 hipStream_t st);
 hipError_t launch_enc_expand(const float* enc, const long long* mel2ph, const EncExpandArgs& a, int H, int B, int L, int Ls,
                              int T, float* cond, hipStream_t st);
+hipError_t launch_ln_merge(const float* lnpart, int mtiles, int C, int B, int T, int ts, float eps, float* stats,
+                           hipStream_t stream);
 hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T,
                          const float* w, const float* bias, int ksz, int act, const float* prelu, hipStream_t stream);
 

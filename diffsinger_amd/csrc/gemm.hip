@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(WN == 2 || (WN == 1 && SW > 0 && EPI != EP_SWIGLU && STAGE != ST_LN), "4x1 wave layout: fast path only");
     static_assert(SW == 0 || (STAGE != ST_LRELU && EPI != EP_SCATTER), "leaky-ReLU staging / scatter epilogue: generic path");
+    static_assert(EPI != EP_LYNX_NEXT || WN == 2, "LYNXNet transition epilogue: 2 x 2 wave layout");
     constexpr int WM = 4 / WN;                  // waves along rows
     constexpr int MB = 4 / WM;                  // 16-row blocks per wave
     constexpr int BN = 16 * NB * WN;
@@ -688,6 +689,77 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
                 }
             }
         }
+    } else if constexpr (EPI == EP_LYNX_NEXT) {
+        // LYNXNet layer transition (lynxnet.py:76-84 of the NEXT layer, fused into this GEMM's epilogue): residual
+        // stream x, next layer's pre-LayerNorm input xin, and the LayerNorm partials of xin over this tile's 64 rows
+        // (two-pass inside the tile: mean first, then squared deviations; tiles are merged by ln_merge_kernel with
+        // the parallel-variance formula, so no E[x^2] - mean^2 cancellation anywhere).
+        float xi[2][NB][4];
+        const int nrows = min(64, p.M - mtile * 64);                 // valid rows of this tile
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int t = t0 + wn * (16 * NB) + n * 16 + lcol;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mtile * 64 + (wm * 2 + mb) * 16 + rq + r;
+                    const int rowc = min(row, p.M - 1);
+                    float v = act_apply(acc[mb][n][r] + (p.bias ? p.bias[rowc] : 0.f), p.act);
+                    if (p.aux) v = v + p.aux[(long)b * p.aux_bstride + (long)rowc * p.aux_rstride + t];
+                    float xo = v, xin = v;
+                    if (p.cpn) {
+                        const float c = p.cpn[(long)b * p.cpn_bstride + (long)rowc * p.cpn_rstride + t];
+                        xin = v + c;
+                        if (p.strong) xo = xin;
+                    }
+                    if (p.film) xin = xin + p.film[(long)rowc * p.film_cstride + p.film_col0 + b * p.film_colb];
+                    if (row < p.M) {
+                        p.out[(long)b * p.o_bstride + (long)row * p.o_rstride + t] = xo;
+                        if (p.out2) p.out2[(long)b * p.o_bstride + (long)row * p.o_rstride + t] = xin;
+                    }
+                    xi[mb][n][r] = row < p.M ? xin : 0.f;
+                }
+        }
+        // column sums over the wave's 32 rows (8 per lane x the 4 lane groups), then over the two waves sharing wn
+        float* red = lds;                                  // [4 waves][16 * NB]  (the chunk buffers are dead)
+        __syncthreads();
+        float mean[NB];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                float s = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = mtile * 64 + (wm * 2 + mb) * 16 + rq + r;
+                        const float dlt = xi[mb][n][r] - (pass ? mean[n] : 0.f);
+                        s += (row < p.M) ? (pass ? dlt * dlt : dlt) : 0.f;
+                    }
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (lane < 16) red[wave * (16 * NB) + n * 16 + lane] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                // the partner wave with the same wn holds the other 32 rows
+                const float tot = red[(wn) * (16 * NB) + n * 16 + lcol] + red[(2 + wn) * (16 * NB) + n * 16 + lcol];
+                if (pass == 0) {
+                    mean[n] = tot / (float)nrows;
+                } else if (wm == 0 && lane < 16) {
+                    const int t = t0 + wn * (16 * NB) + n * 16 + lane;
+                    if (t < p.lnpart_ts) {
+                        float* lp = p.lnpart + ((long)b * p.mtiles + mtile) * 2 * p.lnpart_ts;
+                        lp[t] = mean[n];
+                        lp[p.lnpart_ts + t] = tot;
+                    }
+                }
+            }
+            __syncthreads();
+        }
     } else {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
@@ -896,6 +968,10 @@ hipError_t gemm_init_all() {
     if ((e = attr_all<ST_PLAIN, 1, EP_BIAS_RES>()) != hipSuccess) return e;
     if ((e = attr_all<ST_LN, 1, EP_LINCOMB>()) != hipSuccess) return e;
     if ((e = attr_all<ST_LN, 1, EP_BIAS_ACT>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 1, EP_LYNX_NEXT, 1, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 1, EP_LYNX_NEXT, 2, 0>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 1, EP_LYNX_NEXT, 1, 48>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 1, EP_LYNX_NEXT, 2, 80>()) != hipSuccess) return e;
     if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0>()) != hipSuccess) return e;
     if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0>()) != hipSuccess) return e;
     // NSF-HiFiGAN: leaky-ReLU staged k-tap convs, residual epilogue, transposed-conv scatter (generic path only)
@@ -923,6 +999,12 @@ hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int
     DSD_CASE(ST_PLAIN, 1, EP_BIAS_RES)
     DSD_CASE(ST_LN, 1, EP_LINCOMB)
     DSD_CASE(ST_LN, 1, EP_BIAS_ACT)
+    if (stage == ST_PLAIN && taps == 1 && epi == EP_LYNX_NEXT && nb >= 1) {       // 2 x 2 layout only, no resident variant
+        if (nb == 1) return (fast && p.S == 48) ? launch_one<ST_PLAIN, 1, EP_LYNX_NEXT, 1, 48>(p, batch, st)
+                                                : launch_one<ST_PLAIN, 1, EP_LYNX_NEXT, 1, 0>(p, batch, st);
+        return (fast && p.S == 80) ? launch_one<ST_PLAIN, 1, EP_LYNX_NEXT, 2, 80>(p, batch, st)
+                                   : launch_one<ST_PLAIN, 1, EP_LYNX_NEXT, 2, 0>(p, batch, st);
+    }
 #define DSD_DENSE(ST, EP)                                                                   \
     if (stage == ST && epi == EP && taps == p.taps && !fast && nb >= 1)                      \
         return nb == 1 ? launch_one<ST, 0, EP, 1, 0>(p, batch, st) : launch_one<ST, 0, EP, 2, 0>(p, batch, st);
