@@ -159,3 +159,10 @@ def test_header_is_plain_c99():
         pytest.skip("gcc not available")
     header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dsdenoise.h")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", header], check=True)
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: compiles (or finds up to date) every HIP source and imports the package."""
+    import importlib
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
