@@ -119,21 +119,22 @@ class AuxDecoderAdaptor(nn.Module):
             self.register_buffer('spec_min', spec_min, persistent=False)
             self.register_buffer('spec_max', spec_max, persistent=False)
 
+    def _affine(self):
+        """(k, b) of the spec <-> [-1, 1] map: half range and mid point of [spec_min, spec_max]."""
+        return (self.spec_max - self.spec_min) / 2., (self.spec_max + self.spec_min) / 2.
+
     def norm_spec(self, x):
-        k = (self.spec_max - self.spec_min) / 2.
-        b = (self.spec_max + self.spec_min) / 2.
+        k, b = self._affine()
         return (x - b) / k
 
     def denorm_spec(self, x):
-        k = (self.spec_max - self.spec_min) / 2.
-        b = (self.spec_max + self.spec_min) / 2.
+        k, b = self._affine()
         return x * k + b
 
     def forward(self, condition, infer=False):
         fuse = infer and self.n_feats == 1 and self.spec_min.numel() in (1, self.out_dims)
         if fuse:        # x * k + b rides on the decoder's output transpose
-            k = ((self.spec_max - self.spec_min) / 2.).reshape(-1).expand(self.out_dims)
-            b = ((self.spec_max + self.spec_min) / 2.).reshape(-1).expand(self.out_dims)
+            k, b = (v.reshape(-1).expand(self.out_dims) for v in self._affine())
             return self.decoder(condition, infer=True, out_scale=k, out_shift=b)
         x = self.decoder(condition, infer=infer)  # [B, T, F x C]
         if self.n_feats > 1:
