@@ -406,3 +406,22 @@ def test_config3_lynxnet_full_width_ddim_vs_oracle():
     err = rel_err(out, want)
     assert err < TOL_SAMPLER, err
     d.denoise_fn.release_native()
+
+
+def test_config4_per_gpu_batch_vs_oracle():
+    """BASELINE config 4's per-GPU share (8 utterances of the 20x256 WaveNet, T=1000: the 64-frame-tile kernels) with
+    DPM-Solver++ shortened to 10 steps so that the host-side oracle finishes in seconds; tolerance 5e-4."""
+    set_hp(diff_accelerator="dpm-solver", diff_speedup=100, K_step_infer=1000)
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    d = _gd(1000, in_dims=128, args=args, wseed=42)
+    bsz, t_len = 8, 1000
+    cond = synth.synth_normal((bsz, t_len, 256), 40)
+    noise = synth.synth_normal((bsz, 1, 128, t_len), 41)
+    out = d(dev(cond), infer=True, noise=dev(noise))
+    params = synth_params("wavenet", 128, 1, args, 42)
+    fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=4)   # noqa: E731
+    o = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
+    want = o.forward(cond, noise, diff_accelerator="dpm-solver", diff_speedup=100, K_step_infer=1000)
+    err = rel_err(out, want)
+    assert err < TOL_SAMPLER, err
+    d.denoise_fn.release_native()
