@@ -46,7 +46,8 @@ class DsdVocoderConfig(C.Structure):
                 ("upsample_initial_channel", C.c_int32), ("n_ups", C.c_int32), ("upsample_rates", C.c_int32 * 8),
                 ("upsample_kernel_sizes", C.c_int32 * 8), ("resblock", C.c_int32), ("n_kernels", C.c_int32),
                 ("resblock_kernel_sizes", C.c_int32 * 8), ("n_dilations", C.c_int32 * 8),
-                ("resblock_dilation_sizes", (C.c_int32 * 4) * 8), ("harmonic_num", C.c_int32), ("device", C.c_int32)]
+                ("resblock_dilation_sizes", (C.c_int32 * 4) * 8), ("harmonic_num", C.c_int32), ("mini_nsf", C.c_int32),
+                ("device", C.c_int32)]
 
 
 class DsdEncodeExtras(C.Structure):
@@ -117,7 +118,7 @@ def _load():
     lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     for name in EXPORTS:
         getattr(lib, name)
-    if lib.dsd_api_version() != 4:
+    if lib.dsd_api_version() != 5:
         raise NativeLibraryError("libdsdenoise.so API version mismatch")
     return lib
 

@@ -162,17 +162,26 @@ inline long voc_upp(const dsd_vocoder_config& v, int from) {     // product of u
 std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_voc(const dsd_vocoder_config& v) {
     std::vector<std::pair<std::string, std::vector<int64_t>>> out;
     auto add = [&](const std::string& n, std::vector<int64_t> s) { out.emplace_back(n, std::move(s)); };
-    add("m_source.l_linear.weight", {1, v.harmonic_num + 1});
-    add("m_source.l_linear.bias", {1});
+    if (!v.mini_nsf) {
+        add("m_source.l_linear.weight", {1, v.harmonic_num + 1});
+        add("m_source.l_linear.bias", {1});
+    }
     add("conv_pre.weight", {v.upsample_initial_channel, v.num_mels, 7});
     add("conv_pre.bias", {v.upsample_initial_channel});
     for (int i = 0; i < v.n_ups; ++i) {
         const int64_t ch = voc_stage_channels(v, i);
         add("ups." + std::to_string(i) + ".weight", {2 * ch, ch, v.upsample_kernel_sizes[i]});
         add("ups." + std::to_string(i) + ".bias", {ch});
-        const int64_t nk = i + 1 < v.n_ups ? 2 * voc_upp(v, i + 1) : 1;
-        add("noise_convs." + std::to_string(i) + ".weight", {ch, 1, nk});
-        add("noise_convs." + std::to_string(i) + ".bias", {ch});
+        if (v.mini_nsf) {
+            if (i == 1) {
+                add("source_conv.weight", {ch, 1, 1});
+                add("source_conv.bias", {ch});
+            }
+        } else {
+            const int64_t nk = i + 1 < v.n_ups ? 2 * voc_upp(v, i + 1) : 1;
+            add("noise_convs." + std::to_string(i) + ".weight", {ch, 1, nk});
+            add("noise_convs." + std::to_string(i) + ".bias", {ch});
+        }
         for (int j = 0; j < v.n_kernels; ++j) {
             const std::string p = "resblocks." + std::to_string(i * v.n_kernels + j) + ".";
             for (int d = 0; d < v.n_dilations[j]; ++d) {
@@ -522,8 +531,10 @@ int build_packed_voc(dsd_handle* h) {
         std::function<double(int)> bf = [b](int i) { return (double)b->data[i]; };
         return pack_gemm(h, rows, cin, ks, 0, w, &bf);
     };
-    h->v_linw = copy_vec("m_source.l_linear.weight");
-    h->v_linb = copy_vec("m_source.l_linear.bias");
+    if (!v.mini_nsf) {
+        h->v_linw = copy_vec("m_source.l_linear.weight");
+        h->v_linb = copy_vec("m_source.l_linear.bias");
+    }
     h->v_pre = dense("conv_pre", v.upsample_initial_channel, v.num_mels, 7);
     h->v_ups.resize(v.n_ups);
     h->v_uptaps.resize(v.n_ups);
@@ -553,14 +564,16 @@ int build_packed_voc(dsd_handle* h) {
         h->v_ups[i] = pack_gemm(h, u * ch, 2 * ch, taps, 0, w, nullptr);
         h->v_ups[i].bias_off = blob_reserve(h, (size_t)ch);
         memcpy(h->blob_host.data() + h->v_ups[i].bias_off, b->data.data(), sizeof(float) * ch);
-        {   // noise conv weights transposed to [k][C]: the kernel's threads run along the channels
-            const auto& wn = W(h, "noise_convs." + std::to_string(i) + ".weight");     // [ch, 1, k]
+        h->v_nw[i] = h->v_nb[i] = SIZE_MAX;
+        if (!v.mini_nsf || i == 1) {   // noise conv weights transposed to [k][C]: the kernel's threads run along the channels
+            const std::string nname = v.mini_nsf ? std::string("source_conv") : "noise_convs." + std::to_string(i);
+            const auto& wn = W(h, nname + ".weight");     // [ch, 1, k]
             const int nk = (int)wn.shape[2];
             h->v_nw[i] = blob_reserve(h, (size_t)nk * ch);
             for (int k = 0; k < nk; ++k)
                 for (int o = 0; o < ch; ++o) h->blob_host[h->v_nw[i] + (size_t)k * ch + o] = wn.data[(size_t)o * nk + k];
+            h->v_nb[i] = copy_vec(nname + ".bias");
         }
-        h->v_nb[i] = copy_vec("noise_convs." + std::to_string(i) + ".bias");
         for (int j = 0; j < v.n_kernels; ++j) {
             const std::string p = "resblocks." + std::to_string(i * v.n_kernels + j) + ".";
             auto& list = h->v_res[(size_t)i * v.n_kernels + j];
@@ -1402,6 +1415,7 @@ int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out) {
         cfg->n_kernels > DSD_VOC_MAX_KERNELS || (cfg->resblock != 1 && cfg->resblock != 2))
         return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: bad layer counts");
     if (cfg->harmonic_num < 0 || cfg->harmonic_num > 15) return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: harmonic_num must be in [0, 15]");
+    if (cfg->mini_nsf && cfg->n_ups < 2) return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: mini_nsf needs at least two upsampling stages");
     if (cfg->upsample_initial_channel % (1 << cfg->n_ups) != 0 || (cfg->upsample_initial_channel >> cfg->n_ups) < 1)
         return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: upsample_initial_channel must be divisible by 2^n_ups");
     for (int i = 0; i < cfg->n_ups; ++i) {
@@ -1443,8 +1457,10 @@ int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out) {
 
 int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_m, int64_t stride_t,
                const float* f0, const float* rand_ini, const float* noise, float* wav_out, void* stream) {
-    if (!h || !mel || !f0 || !rand_ini || !noise || !wav_out) return fail(h, DSD_EINVAL, "dsd_vocode: null argument");
+    if (!h || !mel || !f0 || !wav_out) return fail(h, DSD_EINVAL, "dsd_vocode: null argument");
     if (!is_voc(h)) return fail(h, DSD_ESTATE, "dsd_vocode: this handle is not a vocoder");
+    if (!h->vcfg.mini_nsf && (!rand_ini || !noise))
+        return fail(h, DSD_EINVAL, "dsd_vocode: rand_ini and noise are required (the SineGen source draws them, models.py:145,165)");
     if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_vocode: weights are not finalized");
     if (B < 1 || T < 1) return fail(h, DSD_EINVAL, "dsd_vocode: B and T must be positive (B=%d, T=%d)", B, T);
     if (stride_t != 1 && stride_m != 1)
@@ -1493,9 +1509,17 @@ int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t st
     int rc;
 #define VOC_OK(expr, what)                                                                        \
     if ((er = (expr)) != hipSuccess) return fail(h, DSD_EHIP, what " launch failed: %s", hipGetErrorString(er))
-    // harmonic-plus-noise source at the output rate  (models.py:120-168, 200-203, 266)
-    VOC_OK(launch_voc_source(f0, rand_ini, noise, blob + h->v_linw, blob + h->v_linb, B, T, (int)upp, v.harmonic_num + 1,
-                             (float)v.sampling_rate, 0.1f, 0.003f, h->v_phase, lts[NU], h->v_har, st), "source");
+    // source: harmonic-plus-noise at the output rate (models.py:120-168, 200-203, 266), or - mini_nsf - one interpolated
+    // sine at the rate after the second upsampling (models.py:215-217, 251-260, 264)
+    const long src_len = v.mini_nsf ? len[NU >= 2 ? 2 : NU] : len[NU];
+    if (v.mini_nsf) {
+        const int src_upp = (int)(src_len / T);
+        VOC_OK(launch_voc_fast_source(f0, B, T, src_upp, (float)v.sampling_rate / (float)voc_upp(v, 2), h->v_phase, lts[NU],
+                                      h->v_har, st), "source");
+    } else {
+        VOC_OK(launch_voc_source(f0, rand_ini, noise, blob + h->v_linw, blob + h->v_linb, B, T, (int)upp, v.harmonic_num + 1,
+                                 (float)v.sampling_rate, 0.1f, 0.003f, h->v_phase, lts[NU], h->v_har, st), "source");
+    }
     // conv_pre  (models.py:227, 267)
     VOC_OK(launch_pack(mel, stride_b, stride_m, stride_t, h->v_mel, B, v.num_mels, T, Ts0, st), "pack(mel)");
     {
@@ -1519,11 +1543,14 @@ int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t st
             g.p.out = x; g.p.o_bstride = xs; g.p.o_rstride = Tsq;
             if ((rc = run_gemm(h, g, st))) return rc;
         }
-        {   // + noise_convs[i](har_source)  (models.py:274-276)
+        if (!v.mini_nsf) {   // + noise_convs[i](har_source)  (models.py:274-276)
             const int sf = (int)voc_upp(v, i + 1);
             const int ksz = i + 1 < NU ? 2 * sf : 1;
             VOC_OK(launch_voc_noise_conv(x, h->v_har, blob + h->v_nw[i], blob + h->v_nb[i], B, ch, Tq, Tsq, sf, ksz,
                                          len[NU], lts[NU], st), "noise conv");
+        } else if (i == 1) {  // + source_conv(har_source): k = 1, same rate  (models.py:277-279)
+            VOC_OK(launch_voc_noise_conv(x, h->v_har, blob + h->v_nw[i], blob + h->v_nb[i], B, ch, Tq, Tsq, 1, 1, src_len,
+                                         lts[NU], st), "source conv");
         }
         for (int j = 0; j < v.n_kernels; ++j) {     // residual blocks  (models.py:280-286; ResBlock1 :62-69, ResBlock2 :92-97)
             const auto& cv = h->v_res[(size_t)i * v.n_kernels + j];

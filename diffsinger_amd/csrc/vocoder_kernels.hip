@@ -124,6 +124,64 @@ __global__ void voc_accum_kernel(float* __restrict__ acc, const float* __restric
     *reinterpret_cast<f32x4_t*>(acc + i) = a;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generator.fastsinegen (models.py:251-260, mini_nsf): no harmonics, no noise; the per-sample phase advance is
+// interpolated linearly towards the next frame's:
+//   s0 = f0 / sr;  ds0 = s0[t+1] - s0[t] (0 at the last frame);  rad(n) = s0 n + 0.5 ds0 n (n - 1) / upp,  n = 1..upp
+//   frame t starts from acc[t-1] = fmod(sum_{t' < t} (fmod(rad(upp) + 0.5, 1) - 0.5), 1);   out = sin(2 pi rad)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float voc_fast_rad(float s0, float ds0, int n, int upp) {
+    const float fn = (float)n;
+    return s0 * fn + 0.5f * ds0 * fn * (float)(n - 1) / (float)upp;
+}
+
+__global__ __launch_bounds__(256) void voc_fast_phase_kernel(const float* __restrict__ f0, int T, float sr, int upp,
+                                                             float* __restrict__ acc) {
+    __shared__ float buf[2048];
+    const int b = blockIdx.x;
+    float run = 0.f;
+    for (int base = 0; base < T; base += 2048) {
+        const int n = min(2048, T - base);
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int t = base + i;
+            const float s0 = f0[(long)b * T + t] / sr;
+            const float ds0 = t + 1 < T ? f0[(long)b * T + t + 1] / sr - s0 : 0.f;
+            buf[i] = fmodf(voc_fast_rad(s0, ds0, upp, upp) + 0.5f, 1.0f) - 0.5f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int i = 0; i < n; ++i) {
+                run += buf[i];
+                buf[i] = fmodf(run, 1.0f);
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) acc[(long)b * T + base + i] = buf[i];
+        __syncthreads();
+    }
+}
+
+__global__ void voc_fast_source_kernel(const float* __restrict__ f0, const float* __restrict__ acc, int T, int upp, float sr,
+                                       int Tsu, float* __restrict__ har) {
+    const int b = blockIdx.y;
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= (long)T * upp) return;
+    const int t = (int)(s / upp), n = (int)(s - (long)t * upp) + 1;
+    const float s0 = f0[(long)b * T + t] / sr;
+    const float ds0 = t + 1 < T ? f0[(long)b * T + t + 1] / sr - s0 : 0.f;
+    float rad = voc_fast_rad(s0, ds0, n, upp);
+    if (t > 0) rad += acc[(long)b * T + t - 1];
+    har[(long)b * Tsu + s] = sinf(6.283185307179586f * rad);
+}
+
+hipError_t launch_voc_fast_source(const float* f0, int B, int T, int upp, float source_sr, float* acc_tmp, int Tsu, float* har,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(voc_fast_phase_kernel, dim3(B), dim3(256), 0, st, f0, T, source_sr, upp, acc_tmp);
+    const long n = (long)T * upp;
+    hipLaunchKernelGGL(voc_fast_source_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, f0, acc_tmp, T, upp,
+                       source_sr, Tsu, har);
+    return hipGetLastError();
+}
+
 hipError_t launch_voc_source(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
                              const float* lin_b, int B, int T, int upp, int dim, float sr, float sine_amp, float noise_std,
                              float* acc_tmp, int Tsu, float* har, hipStream_t st) {

@@ -156,8 +156,10 @@ def nsf_hifigan_param_shapes(h):
     """state_dict of modules/nsf_hifigan/models.py:207-260 (Generator, mini_nsf = False) in its inference form,
     i.e. after `remove_weight_norm()`: plain `weight` / `bias` everywhere."""
     shapes = OrderedDict()
-    shapes["m_source.l_linear.weight"] = (1, 9)
-    shapes["m_source.l_linear.bias"] = (1,)
+    mini = bool(h.get("mini_nsf", False))
+    if not mini:
+        shapes["m_source.l_linear.weight"] = (1, 9)
+        shapes["m_source.l_linear.bias"] = (1,)
     ch = h["upsample_initial_channel"]
     rates = list(h["upsample_rates"])
     noise = OrderedDict()
@@ -179,12 +181,17 @@ def nsf_hifigan_param_shapes(h):
                 for d in range(len(rd)):
                     res[f"{pre}convs.{d}.weight"] = (ch, ch, rk)
                     res[f"{pre}convs.{d}.bias"] = (ch,)
-        if i + 1 < len(rates):
-            sf = int(np.prod(rates[i + 1:]))
-            noise[f"noise_convs.{i}.weight"] = (ch, 1, sf * 2)
+        if mini:
+            if i == 1:
+                noise["source_conv.weight"] = (ch, 1, 1)
+                noise["source_conv.bias"] = (ch,)
         else:
-            noise[f"noise_convs.{i}.weight"] = (ch, 1, 1)
-        noise[f"noise_convs.{i}.bias"] = (ch,)
+            if i + 1 < len(rates):
+                sf = int(np.prod(rates[i + 1:]))
+                noise[f"noise_convs.{i}.weight"] = (ch, 1, sf * 2)
+            else:
+                noise[f"noise_convs.{i}.weight"] = (ch, 1, 1)
+            noise[f"noise_convs.{i}.bias"] = (ch,)
     shapes.update(noise)
     shapes["conv_pre.weight"] = (h["upsample_initial_channel"], h["num_mels"], 7)
     shapes["conv_pre.bias"] = (h["upsample_initial_channel"],)

@@ -6,7 +6,8 @@ parameters under the reference's names in their inference form (after `remove_we
 still carries `weight_g` / `weight_v` pairs is folded on load (`w = g * v / ||v||`, the norm over all dims but 0,
 torch.nn.utils.weight_norm's default).  `forward(x, f0)` = models.py:262-290 with SineGen's two random draws
 (`torch.rand` initial phases, `torch.randn_like` noise) made on the caller's device, or passed in for
-reproducibility.  `mini_nsf` configurations are not implemented.  Inference only; no CPU path.
+reproducibility; `mini_nsf: true` generators (fastsinegen source, `source_conv`) have no random draws.
+Inference only; no CPU path.
 """
 from __future__ import annotations
 
@@ -45,8 +46,7 @@ class _Source(nn.Module):
 class Generator(_NativeBackbone):
     def __init__(self, h):
         super().__init__()
-        if _get(h, "mini_nsf", False):
-            raise NotImplementedError("mini_nsf generators are not implemented on the HIP path")
+        self.mini_nsf = bool(_get(h, "mini_nsf", False))
         self.h = h
         self.num_mels = int(_get(h, "num_mels"))
         self.sampling_rate = int(_get(h, "sampling_rate"))
@@ -62,8 +62,9 @@ class Generator(_NativeBackbone):
         self.harmonic_num = 8
         self.upp = int(np.prod(self.upsample_rates))
         self._hidden = self.num_mels
-        self.m_source = _Source(self.harmonic_num + 1)
-        self.noise_convs = nn.ModuleList()
+        if not self.mini_nsf:
+            self.m_source = _Source(self.harmonic_num + 1)
+            self.noise_convs = nn.ModuleList()
         self.conv_pre = nn.Conv1d(self.num_mels, self.upsample_initial_channel, 7, 1, padding=3)
         self.ups = nn.ModuleList()
         self.resblocks = nn.ModuleList()
@@ -73,7 +74,10 @@ class Generator(_NativeBackbone):
             self.ups.append(nn.ConvTranspose1d(2 * ch, ch, k, u, padding=(k - u) // 2))
             for rk, rd in zip(self.resblock_kernel_sizes, self.resblock_dilation_sizes):
                 self.resblocks.append(_ResBlock(self.resblock, ch, rk, rd))
-            if i + 1 < len(self.upsample_rates):
+            if self.mini_nsf:
+                if i == 1:
+                    self.source_conv = nn.Conv1d(1, ch, 1)
+            elif i + 1 < len(self.upsample_rates):
                 sf = int(np.prod(self.upsample_rates[i + 1:]))
                 self.noise_convs.append(nn.Conv1d(1, ch, kernel_size=sf * 2, stride=sf, padding=sf // 2))
             else:
@@ -109,6 +113,7 @@ class Generator(_NativeBackbone):
             for d, dv in enumerate(rd):
                 cfg.resblock_dilation_sizes[j][d] = dv
         cfg.harmonic_num = self.harmonic_num
+        cfg.mini_nsf = int(self.mini_nsf)
         cfg.device = device_index
         return cfg
 
@@ -134,6 +139,12 @@ class Generator(_NativeBackbone):
             sb, sm, st_ = x.stride()
         f0 = f0.detach().to(device=dev, dtype=torch.float32).contiguous()
         dim = self.harmonic_num + 1
+        if self.mini_nsf:           # deterministic source (models.py:251-260): nothing to draw
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(handle, _lib.lib().dsd_vocode(handle, C.c_void_p(x.data_ptr()), b, t, sb, sm, st_,
+                                                     C.c_void_p(f0.data_ptr()), None, None, C.c_void_p(out.data_ptr()),
+                                                     C.c_void_p(stream)), "dsd_vocode")
+            return out
         if rand_ini is None:
             rand_ini = torch.rand(dim, device=dev)                          # models.py:145
         if noise is None:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSD_API_VERSION 4
+#define DSD_API_VERSION 5
 
 /* error codes */
 #define DSD_OK 0
@@ -187,7 +187,8 @@ int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, 
  * checkpoint's config.json that Generator.__init__ reads (modules/nsf_hifigan/models.py:207-260), `mini_nsf: false`.
  * Weights: the Generator state_dict in its inference form, i.e. after remove_weight_norm() (models.py:292-302):
  * `m_source.l_linear.*`, `noise_convs.N.*`, `conv_pre.*`, `ups.N.*` ([C_in, C_out, K] as ConvTranspose1d stores it),
- * `resblocks.N.convs1.M.* / convs2.M.*` (ResBlock1) or `resblocks.N.convs.M.*` (ResBlock2), `conv_post.*`.
+ * `resblocks.N.convs1.M.* / convs2.M.*` (ResBlock1) or `resblocks.N.convs.M.*` (ResBlock2), `conv_post.*`;
+ * with mini_nsf: `source_conv.*` instead of `m_source.*` / `noise_convs.*`.
  */
 #define DSD_VOC_MAX_UPS 8
 #define DSD_VOC_MAX_KERNELS 8
@@ -206,6 +207,8 @@ typedef struct dsd_vocoder_config {
     int32_t n_dilations[DSD_VOC_MAX_KERNELS];
     int32_t resblock_dilation_sizes[DSD_VOC_MAX_KERNELS][DSD_VOC_MAX_DILS];
     int32_t harmonic_num;                              /* SourceModuleHnNSF(harmonic_num=8), models.py:221-224 */
+    int32_t mini_nsf;                                  /* h.mini_nsf (models.py:212-225): 1 = fastsinegen source, added
+                                                          once through `source_conv` after the second upsampling */
     int32_t device;
 } dsd_vocoder_config;
 
@@ -217,6 +220,7 @@ int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out);
  *   f0       [B, T] Hz, 0 = unvoiced
  *   rand_ini [harmonic_num + 1] uniform [0,1) initial phases (torch.rand, models.py:145; element 0 is ignored)
  *   noise    [B, T * prod(upsample_rates), harmonic_num + 1] standard normals (torch.randn_like, models.py:165)
+ *            (both may be NULL for a mini_nsf generator: its source is deterministic)
  *   wav_out  [B, T * prod(upsample_rates)]
  */
 int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_m,

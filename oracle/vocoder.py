@@ -76,6 +76,28 @@ def sine_source(p, f0, upp, sampling_rate, rand_ini, noise, harmonic_num=8, sine
     return np.swapaxes(merged, 1, 2)
 
 
+def fast_sine_source(f0, upp, source_sr):
+    """Generator.fastsinegen (models.py:251-260, mini_nsf): f0 [B,T] -> sines [B,1,T*upp]; phase advances linearly
+    interpolated between frames, no noise, no voiced/unvoiced switch."""
+    f0 = np.asarray(f0, dtype=F32)
+    n = np.arange(1, upp + 1, dtype=F32)
+    s0 = (f0[:, :, None] / F32(source_sr)).astype(F32)
+    ds0 = np.zeros_like(s0)
+    ds0[:, :-1] = s0[:, 1:] - s0[:, :-1]
+    rad = (s0 * n + F32(0.5) * ds0 * n * (n - 1) / F32(upp)).astype(F32)
+    rad2 = (np.fmod(rad[..., -1:] + F32(0.5), F32(1.0)) - F32(0.5)).astype(F32)
+    acc = np.zeros_like(rad2)
+    run = np.zeros((f0.shape[0], 1), dtype=F32)
+    for t in range(f0.shape[1]):
+        run = (run + rad2[:, t]).astype(F32)
+        acc[:, t] = run
+    rad_acc = np.fmod(acc, F32(1.0)).astype(F32)
+    rad = rad.copy()
+    rad[:, 1:] += rad_acc[:, :-1]
+    rad = rad.reshape(f0.shape[0], 1, -1)
+    return np.sin(F32(2 * np.pi) * rad).astype(F32)
+
+
 def resblock1(p, pre, x, kernel_size, dilations):
     for j, d in enumerate(dilations):
         xt = lrelu(x, LRELU_SLOPE)
@@ -95,23 +117,32 @@ def resblock2(p, pre, x, kernel_size, dilations):
     return x
 
 
-def generator_forward(p, h, mel, f0, rand_ini, noise):
+def generator_forward(p, h, mel, f0, rand_ini=None, noise=None):
     """Generator.forward: mel [B, num_mels, T] (natural-log mel), f0 [B, T] -> wav [B, 1, T*prod(upsample_rates)]."""
     rates, ksz = list(h["upsample_rates"]), list(h["upsample_kernel_sizes"])
     rk, rd = list(h["resblock_kernel_sizes"]), [list(d) for d in h["resblock_dilation_sizes"]]
-    upp = int(np.prod(rates))
-    har = sine_source(p, f0, upp, h["sampling_rate"], rand_ini, noise)
+    mini = bool(h.get("mini_nsf", False))
+    if mini:        # models.py:215-217, 264
+        upp = int(np.prod(rates[:2]))
+        har = fast_sine_source(f0, upp, h["sampling_rate"] / int(np.prod(rates[2:])))
+    else:
+        upp = int(np.prod(rates))
+        har = sine_source(p, f0, upp, h["sampling_rate"], rand_ini, noise)
     x = conv1d(np.asarray(mel, dtype=F32), p["conv_pre.weight"], p["conv_pre.bias"], padding=3)
     rb = resblock1 if str(h.get("resblock", "1")) == "1" else resblock2
     for i, (u, k) in enumerate(zip(rates, ksz)):
         x = lrelu(x, LRELU_SLOPE)
         x = conv_transpose1d(x, p[f"ups.{i}.weight"], p[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
-        if i + 1 < len(rates):
-            sf = int(np.prod(rates[i + 1:]))
-            xs = conv1d(har, p[f"noise_convs.{i}.weight"], p[f"noise_convs.{i}.bias"], stride=sf, padding=sf // 2)
+        if mini:
+            if i == 1:
+                x = (x + conv1d(har, p["source_conv.weight"], p["source_conv.bias"])).astype(F32)
         else:
-            xs = conv1d(har, p[f"noise_convs.{i}.weight"], p[f"noise_convs.{i}.bias"])
-        x = (x + xs).astype(F32)
+            if i + 1 < len(rates):
+                sf = int(np.prod(rates[i + 1:]))
+                xs = conv1d(har, p[f"noise_convs.{i}.weight"], p[f"noise_convs.{i}.bias"], stride=sf, padding=sf // 2)
+            else:
+                xs = conv1d(har, p[f"noise_convs.{i}.weight"], p[f"noise_convs.{i}.bias"])
+            x = (x + xs).astype(F32)
         acc = None
         for j in range(len(rk)):
             y = rb(p, f"resblocks.{i * len(rk) + j}.", x, rk[j], rd[j])
@@ -122,7 +153,7 @@ def generator_forward(p, h, mel, f0, rand_ini, noise):
     return np.tanh(x).astype(F32)
 
 
-def spec2wav(p, h, mel_btm, f0, rand_ini, noise, mel_base="10"):
+def spec2wav(p, h, mel_btm, f0, rand_ini=None, noise=None, mel_base="10"):
     """NsfHifiGAN.spec2wav_torch (vocoders/nsf_hifigan.py:54-70): mel [B,T,bins] -> wav [B*T*upp]."""
     c = np.swapaxes(np.asarray(mel_btm, dtype=F32), 1, 2)
     if mel_base != "e":

@@ -625,6 +625,10 @@ VOC_CASES = {
     "small_rb2": (dict(num_mels=32, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4],
                        upsample_initial_channel=64, resblock="2", resblock_kernel_sizes=[3, 5],
                        resblock_dilation_sizes=[[1, 2], [2, 6]], hop_size=16), 2, 37, 301),
+    "mini_nsf": (dict(mini_nsf=True), 2, 9, 302),
+    "mini_small": (dict(mini_nsf=True, num_mels=32, upsample_rates=[4, 4, 2], upsample_kernel_sizes=[8, 8, 4],
+                        upsample_initial_channel=128, resblock_kernel_sizes=[3, 7], resblock_dilation_sizes=[[1, 3, 5], [1, 2, 3]],
+                        hop_size=32), 3, 41, 303),
 }
 VOC_GAIN = 0.7
 
@@ -646,6 +650,7 @@ def g10_vocoder():
         rng = np.random.Generator(np.random.PCG64(wseed + 2))
         f0 = (220.0 * 2.0 ** rng.uniform(-1, 1, (bsz, t_len))).astype(np.float32)
         f0[:, : t_len // 4] = 0.0                                         # an unvoiced stretch
+        f0[:, t_len // 4] = 55.0                                          # a jump right after it (mini_nsf interpolates)
         rand_ini = rng.random(9).astype(np.float32)
         noise = synth.synth_normal((bsz, t_len * upp, 9), wseed + 3)
         orig_rand, orig_randn_like = torch.rand, torch.randn_like

@@ -20,6 +20,10 @@ OVER = {
     "default": dict(),
     "small_rb2": dict(num_mels=32, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4], upsample_initial_channel=64,
                       resblock="2", resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2], [2, 6]], hop_size=16),
+    "mini_nsf": dict(mini_nsf=True),
+    "mini_small": dict(mini_nsf=True, num_mels=32, upsample_rates=[4, 4, 2], upsample_kernel_sizes=[8, 8, 4],
+                       upsample_initial_channel=128, resblock_kernel_sizes=[3, 7],
+                       resblock_dilation_sizes=[[1, 3, 5], [1, 2, 3]], hop_size=32),
 }
 
 
@@ -53,7 +57,8 @@ def test_vocoder_vs_golden(tag):
     gen.release_native()
 
 
-@pytest.mark.parametrize("tag,bsz,t_len", [("small_rb2", 1, 1), ("small_rb2", 3, 130), ("default", 1, 33)])
+@pytest.mark.parametrize("tag,bsz,t_len", [("small_rb2", 1, 1), ("small_rb2", 3, 130), ("default", 1, 33),
+                                           ("mini_small", 1, 1), ("mini_small", 2, 2100)])     # 2100 > one scan chunk
 def test_vocoder_vs_oracle_sizes(tag, bsz, t_len):
     gen, h, params = build(OVER[tag], 410)
     upp = int(np.prod(h["upsample_rates"]))
@@ -64,6 +69,9 @@ def test_vocoder_vs_oracle_sizes(tag, bsz, t_len):
     rand_ini = rng.random(9).astype(np.float32)
     noise = synth.synth_normal((bsz, t_len * upp, 9), 412)
     want = ov.generator_forward(params, h, mel, f0, rand_ini, noise)
+    if h.get("mini_nsf"):               # deterministic source: the draws are not needed at all
+        with torch.no_grad():
+            assert torch.equal(gen(dev(mel), dev(f0)), gen(dev(mel), dev(f0), rand_ini=dev(rand_ini), noise=dev(noise)))
     with torch.no_grad():
         got = gen(dev(mel), dev(f0), rand_ini=dev(rand_ini), noise=dev(noise))
         got_t = gen(dev(np.ascontiguousarray(mel.transpose(0, 2, 1))).transpose(1, 2), dev(f0), rand_ini=dev(rand_ini),
@@ -85,8 +93,13 @@ def test_vocoder_errors_and_weight_norm_fold():
         with pytest.raises(ValueError):
             gen(torch.zeros(1, 31, 4).cuda(), torch.zeros(1, 4).cuda())
         assert tuple(gen(torch.zeros(0, 32, 4).cuda(), torch.zeros(0, 4).cuda()).shape) == (0, 1, 64)
-    with pytest.raises(NotImplementedError):
-        Generator(dict(h, mini_nsf=True))
+    with pytest.raises(RuntimeError, match="rand_ini and noise are required"):      # C-ABI: only mini_nsf may omit the draws
+        from diffsinger_amd import _lib
+        import ctypes as C
+        x = torch.zeros(1, 4, 32).cuda(); f = torch.zeros(1, 4).cuda(); o = torch.zeros(1, 64).cuda()
+        hd = gen.native_handle(x.device)
+        _lib.check(hd, _lib.lib().dsd_vocode(hd, C.c_void_p(x.data_ptr()), 1, 4, 128, 1, 32, C.c_void_p(f.data_ptr()), None, None,
+                                             C.c_void_p(o.data_ptr()), None), "dsd_vocode")
     # a checkpoint that still carries weight norm: weight_g / weight_v pairs are folded on load
     sd = {}
     for k, v in params.items():

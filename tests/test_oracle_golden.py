@@ -419,6 +419,10 @@ VOC_OVER = {
     "default": dict(),
     "small_rb2": dict(num_mels=32, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4], upsample_initial_channel=64,
                       resblock="2", resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2], [2, 6]], hop_size=16),
+    "mini_nsf": dict(mini_nsf=True),
+    "mini_small": dict(mini_nsf=True, num_mels=32, upsample_rates=[4, 4, 2], upsample_kernel_sizes=[8, 8, 4],
+                       upsample_initial_channel=128, resblock_kernel_sizes=[3, 7],
+                       resblock_dilation_sizes=[[1, 3, 5], [1, 2, 3]], hop_size=32),
 }
 VOC_GAIN = 0.7
 
