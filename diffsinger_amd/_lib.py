@@ -47,7 +47,7 @@ class DsdVocoderConfig(C.Structure):
                 ("upsample_kernel_sizes", C.c_int32 * 8), ("resblock", C.c_int32), ("n_kernels", C.c_int32),
                 ("resblock_kernel_sizes", C.c_int32 * 8), ("n_dilations", C.c_int32 * 8),
                 ("resblock_dilation_sizes", (C.c_int32 * 4) * 8), ("harmonic_num", C.c_int32), ("mini_nsf", C.c_int32),
-                ("device", C.c_int32)]
+                ("noise_sigma", C.c_float), ("device", C.c_int32)]
 
 
 class DsdEncodeExtras(C.Structure):
@@ -110,7 +110,7 @@ def _load():
     lib.dsd_sample.argtypes = [vp, C.POINTER(DsdProgram), vp, vp, vp, vp, vp, C.c_uint32, vp]
     lib.dsd_aux_decode.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, vp, vp, vp]
     lib.dsd_vocoder_create.argtypes = [C.POINTER(DsdVocoderConfig), C.POINTER(vp)]
-    lib.dsd_vocode.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp]
+    lib.dsd_vocode.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.dsd_encoder_create.argtypes = [C.POINTER(DsdEncoderConfig), C.POINTER(vp)]
     lib.dsd_encode.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.POINTER(DsdEncodeExtras), vp, vp]
     lib.dsd_get_stats.argtypes = [vp, C.POINTER(DsdStats)]

@@ -1415,6 +1415,7 @@ int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out) {
         cfg->n_kernels > DSD_VOC_MAX_KERNELS || (cfg->resblock != 1 && cfg->resblock != 2))
         return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: bad layer counts");
     if (cfg->harmonic_num < 0 || cfg->harmonic_num > 15) return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: harmonic_num must be in [0, 15]");
+    if (!(cfg->noise_sigma >= 0.f)) return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: noise_sigma must be >= 0");
     if (cfg->mini_nsf && cfg->n_ups < 2) return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: mini_nsf needs at least two upsampling stages");
     if (cfg->upsample_initial_channel % (1 << cfg->n_ups) != 0 || (cfg->upsample_initial_channel >> cfg->n_ups) < 1)
         return fail(nullptr, DSD_EINVAL, "dsd_vocoder_create: upsample_initial_channel must be divisible by 2^n_ups");
@@ -1456,11 +1457,14 @@ int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out) {
 }
 
 int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_m, int64_t stride_t,
-               const float* f0, const float* rand_ini, const float* noise, float* wav_out, void* stream) {
+               const float* f0, const float* rand_ini, const float* noise, const float* pre_noise, float* wav_out,
+               void* stream) {
     if (!h || !mel || !f0 || !wav_out) return fail(h, DSD_EINVAL, "dsd_vocode: null argument");
     if (!is_voc(h)) return fail(h, DSD_ESTATE, "dsd_vocode: this handle is not a vocoder");
     if (!h->vcfg.mini_nsf && (!rand_ini || !noise))
         return fail(h, DSD_EINVAL, "dsd_vocode: rand_ini and noise are required (the SineGen source draws them, models.py:145,165)");
+    if (h->vcfg.noise_sigma > 0.f && !pre_noise)
+        return fail(h, DSD_EINVAL, "dsd_vocode: pre_noise is required when noise_sigma > 0 (models.py:272-273)");
     if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_vocode: weights are not finalized");
     if (B < 1 || T < 1) return fail(h, DSD_EINVAL, "dsd_vocode: B and T must be positive (B=%d, T=%d)", B, T);
     if (stride_t != 1 && stride_m != 1)
@@ -1527,6 +1531,8 @@ int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t st
         g.p.act = ACT_NONE; g.p.out = h->v_pre_out; g.p.o_bstride = (long)C0 * Ts0; g.p.o_rstride = Ts0;
         if ((rc = run_gemm(h, g, st))) return rc;
     }
+    if (v.noise_sigma > 0.f)      // x += noise_sigma * randn_like(x)  (models.py:272-273)
+        VOC_OK(launch_voc_add_noise(h->v_pre_out, pre_noise, B, C0, T, Ts0, v.noise_sigma, st), "pre-noise");
     const float* cur = h->v_pre_out;
     int cur_c = C0;
     for (int i = 0; i < NU; ++i) {

@@ -142,6 +142,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 hipError_t launch_voc_source(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
                              const float* lin_b, int B, int T, int upp, int dim, float sr, float sine_amp, float noise_std,
                              float* acc_tmp, int Tsu, float* har, hipStream_t st);
+hipError_t launch_voc_add_noise(float* x, const float* noise, int B, int C, int T, int Ts, float sigma, hipStream_t st);
 hipError_t launch_voc_fast_source(const float* f0, int B, int T, int upp, float source_sr, float* acc_tmp, int Tsu, float* har,
                                   hipStream_t st);
 hipError_t launch_voc_noise_conv(float* x, const float* har, const float* w, const float* bias, int B, int C, int Tq,

@@ -202,6 +202,19 @@ hipError_t launch_voc_noise_conv(float* x, const float* har, const float* w, con
     return hipGetLastError();
 }
 
+// x[row][t] += sigma * noise[row][t]  (models.py:272-273; x rows are padded to Ts, the caller's noise is dense)
+__global__ void voc_add_noise_kernel(float* __restrict__ x, const float* __restrict__ noise, int T, int Ts, float sigma) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const long row = (long)blockIdx.z * gridDim.y + blockIdx.y;
+    x[row * Ts + t] += sigma * noise[row * T + t];
+}
+
+hipError_t launch_voc_add_noise(float* x, const float* noise, int B, int C, int T, int Ts, float sigma, hipStream_t st) {
+    hipLaunchKernelGGL(voc_add_noise_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, st, x, noise, T, Ts, sigma);
+    return hipGetLastError();
+}
+
 hipError_t launch_voc_accum(float* acc, const float* r, long n, int first, float div, hipStream_t st) {
     hipLaunchKernelGGL(voc_accum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, acc, r, n, first, div);
     return hipGetLastError();

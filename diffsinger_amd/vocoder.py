@@ -56,9 +56,7 @@ class Generator(_NativeBackbone):
         self.resblock = 1 if str(_get(h, "resblock", "1")) == "1" else 2
         self.resblock_kernel_sizes = [int(v) for v in _get(h, "resblock_kernel_sizes")]
         self.resblock_dilation_sizes = [[int(d) for d in ds] for ds in _get(h, "resblock_dilation_sizes")]
-        self.noise_sigma = _get(h, "noise_sigma", None)
-        if self.noise_sigma is not None and self.noise_sigma > 0:
-            raise NotImplementedError("noise_sigma > 0 (extra noise after conv_pre, models.py:268-269) is not implemented")
+        self.noise_sigma = _get(h, "noise_sigma", None)          # models.py:213: > 0 adds sigma * randn after conv_pre
         self.harmonic_num = 8
         self.upp = int(np.prod(self.upsample_rates))
         self._hidden = self.num_mels
@@ -114,13 +112,14 @@ class Generator(_NativeBackbone):
                 cfg.resblock_dilation_sizes[j][d] = dv
         cfg.harmonic_num = self.harmonic_num
         cfg.mini_nsf = int(self.mini_nsf)
+        cfg.noise_sigma = float(self.noise_sigma) if self.noise_sigma is not None and self.noise_sigma > 0 else 0.0
         cfg.device = device_index
         return cfg
 
     def prepare_cond(self, cond, layout="BHT"):
         raise RuntimeError("the vocoder has no conditioner; call forward(mel, f0)")
 
-    def forward(self, x, f0, *, rand_ini=None, noise=None):
+    def forward(self, x, f0, *, rand_ini=None, noise=None, pre_noise=None):
         """x: [B, num_mels, T] natural-log mel, f0: [B, T] -> [B, 1, T * prod(upsample_rates)]."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("diffsinger_amd.vocoder.Generator is inference-only: call it under torch.no_grad()")
@@ -139,11 +138,20 @@ class Generator(_NativeBackbone):
             sb, sm, st_ = x.stride()
         f0 = f0.detach().to(device=dev, dtype=torch.float32).contiguous()
         dim = self.harmonic_num + 1
+        pre_ptr = None
+        if self.noise_sigma is not None and self.noise_sigma > 0:           # models.py:272-273
+            c0 = self.upsample_initial_channel
+            if pre_noise is None:
+                pre_noise = torch.randn((b, c0, t), device=dev)
+            pre_noise = pre_noise.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if tuple(pre_noise.shape) != (b, c0, t):
+                raise ValueError(f"pre_noise [{b}, {c0}, {t}] expected")
+            pre_ptr = C.c_void_p(pre_noise.data_ptr())
         if self.mini_nsf:           # deterministic source (models.py:251-260): nothing to draw
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(handle, _lib.lib().dsd_vocode(handle, C.c_void_p(x.data_ptr()), b, t, sb, sm, st_,
-                                                     C.c_void_p(f0.data_ptr()), None, None, C.c_void_p(out.data_ptr()),
-                                                     C.c_void_p(stream)), "dsd_vocode")
+                                                     C.c_void_p(f0.data_ptr()), None, None, pre_ptr,
+                                                     C.c_void_p(out.data_ptr()), C.c_void_p(stream)), "dsd_vocode")
             return out
         if rand_ini is None:
             rand_ini = torch.rand(dim, device=dev)                          # models.py:145
@@ -156,7 +164,7 @@ class Generator(_NativeBackbone):
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(handle, _lib.lib().dsd_vocode(handle, C.c_void_p(x.data_ptr()), b, t, sb, sm, st_,
                                                  C.c_void_p(f0.data_ptr()), C.c_void_p(rand_ini.data_ptr()),
-                                                 C.c_void_p(noise.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(noise.data_ptr()), pre_ptr, C.c_void_p(out.data_ptr()),
                                                  C.c_void_p(stream)), "dsd_vocode")
         return out
 
@@ -177,5 +185,5 @@ class NsfHifiGAN:
             f0 = kwargs.get('f0')
             if f0 is None:
                 raise ValueError("the NSF generator needs f0 (models.py:262)")
-            extra = {k: kwargs[k] for k in ("rand_ini", "noise") if kwargs.get(k) is not None}
+            extra = {k: kwargs[k] for k in ("rand_ini", "noise", "pre_noise") if kwargs.get(k) is not None}
             return self.model(c, f0, **extra).view(-1)

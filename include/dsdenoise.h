@@ -209,6 +209,8 @@ typedef struct dsd_vocoder_config {
     int32_t harmonic_num;                              /* SourceModuleHnNSF(harmonic_num=8), models.py:221-224 */
     int32_t mini_nsf;                                  /* h.mini_nsf (models.py:212-225): 1 = fastsinegen source, added
                                                           once through `source_conv` after the second upsampling */
+    float noise_sigma;                                 /* h.noise_sigma (models.py:213,272-273): > 0 adds
+                                                          noise_sigma * pre_noise after conv_pre; 0 = off */
     int32_t device;
 } dsd_vocoder_config;
 
@@ -221,11 +223,13 @@ int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out);
  *   rand_ini [harmonic_num + 1] uniform [0,1) initial phases (torch.rand, models.py:145; element 0 is ignored)
  *   noise    [B, T * prod(upsample_rates), harmonic_num + 1] standard normals (torch.randn_like, models.py:165)
  *            (both may be NULL for a mini_nsf generator: its source is deterministic)
+ *   pre_noise [B, upsample_initial_channel, T] standard normals (torch.randn_like(x), models.py:273); required when the
+ *            configuration's noise_sigma > 0, ignored (may be NULL) otherwise
  *   wav_out  [B, T * prod(upsample_rates)]
  */
 int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_m,
-               int64_t stride_t, const float* f0, const float* rand_ini, const float* noise, float* wav_out,
-               void* stream);
+               int64_t stride_t, const float* f0, const float* rand_ini, const float* noise, const float* pre_noise,
+               float* wav_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sampling programs.  Every sampler of the reference (ddpm.py:149-204,221-351 p_sample /

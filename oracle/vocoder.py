@@ -117,7 +117,7 @@ def resblock2(p, pre, x, kernel_size, dilations):
     return x
 
 
-def generator_forward(p, h, mel, f0, rand_ini=None, noise=None):
+def generator_forward(p, h, mel, f0, rand_ini=None, noise=None, pre_noise=None):
     """Generator.forward: mel [B, num_mels, T] (natural-log mel), f0 [B, T] -> wav [B, 1, T*prod(upsample_rates)]."""
     rates, ksz = list(h["upsample_rates"]), list(h["upsample_kernel_sizes"])
     rk, rd = list(h["resblock_kernel_sizes"]), [list(d) for d in h["resblock_dilation_sizes"]]
@@ -129,6 +129,9 @@ def generator_forward(p, h, mel, f0, rand_ini=None, noise=None):
         upp = int(np.prod(rates))
         har = sine_source(p, f0, upp, h["sampling_rate"], rand_ini, noise)
     x = conv1d(np.asarray(mel, dtype=F32), p["conv_pre.weight"], p["conv_pre.bias"], padding=3)
+    sigma = h.get("noise_sigma", None)
+    if sigma is not None and sigma > 0:                  # models.py:272-273
+        x = (x + F32(sigma) * np.asarray(pre_noise, dtype=F32)).astype(F32)
     rb = resblock1 if str(h.get("resblock", "1")) == "1" else resblock2
     for i, (u, k) in enumerate(zip(rates, ksz)):
         x = lrelu(x, LRELU_SLOPE)
@@ -153,9 +156,9 @@ def generator_forward(p, h, mel, f0, rand_ini=None, noise=None):
     return np.tanh(x).astype(F32)
 
 
-def spec2wav(p, h, mel_btm, f0, rand_ini=None, noise=None, mel_base="10"):
+def spec2wav(p, h, mel_btm, f0, rand_ini=None, noise=None, mel_base="10", pre_noise=None):
     """NsfHifiGAN.spec2wav_torch (vocoders/nsf_hifigan.py:54-70): mel [B,T,bins] -> wav [B*T*upp]."""
     c = np.swapaxes(np.asarray(mel_btm, dtype=F32), 1, 2)
     if mel_base != "e":
         c = (F32(2.30259) * c).astype(F32)
-    return generator_forward(p, h, c, f0, rand_ini, noise).reshape(-1)
+    return generator_forward(p, h, c, f0, rand_ini, noise, pre_noise).reshape(-1)

@@ -629,6 +629,13 @@ VOC_CASES = {
     "mini_small": (dict(mini_nsf=True, num_mels=32, upsample_rates=[4, 4, 2], upsample_kernel_sizes=[8, 8, 4],
                         upsample_initial_channel=128, resblock_kernel_sizes=[3, 7], resblock_dilation_sizes=[[1, 3, 5], [1, 2, 3]],
                         hop_size=32), 3, 41, 303),
+    # noise_sigma > 0: sigma * randn_like(x) after conv_pre (models.py:272-273); the draw is synth_normal(seed + 4)
+    "small_sigma": (dict(num_mels=32, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4],
+                         upsample_initial_channel=64, resblock="2", resblock_kernel_sizes=[3, 5],
+                         resblock_dilation_sizes=[[1, 2], [2, 6]], hop_size=16, noise_sigma=0.3), 2, 21, 304),
+    "mini_sigma": (dict(mini_nsf=True, num_mels=32, upsample_rates=[4, 4, 2], upsample_kernel_sizes=[8, 8, 4],
+                        upsample_initial_channel=128, resblock_kernel_sizes=[3, 7], resblock_dilation_sizes=[[1, 3, 5], [1, 2, 3]],
+                        hop_size=32, noise_sigma=0.2), 2, 19, 305),
 }
 VOC_GAIN = 0.7
 
@@ -655,7 +662,8 @@ def g10_vocoder():
         noise = synth.synth_normal((bsz, t_len * upp, 9), wseed + 3)
         orig_rand, orig_randn_like = torch.rand, torch.randn_like
         torch.rand = lambda *a, **k: to_t(rand_ini).reshape(1, 1, 9).clone()
-        torch.randn_like = lambda x, **k: to_t(noise).clone()
+        pre_noise = synth.synth_normal((bsz, h["upsample_initial_channel"], t_len), wseed + 4)
+        torch.randn_like = lambda x, **k: to_t(noise if x.shape[-1] == 9 else pre_noise).clone()
         try:
             with torch.no_grad():
                 c = 2.30259 * to_t(mel).transpose(2, 1)                   # vocoders/nsf_hifigan.py:59-64

@@ -24,6 +24,12 @@ OVER = {
     "mini_small": dict(mini_nsf=True, num_mels=32, upsample_rates=[4, 4, 2], upsample_kernel_sizes=[8, 8, 4],
                        upsample_initial_channel=128, resblock_kernel_sizes=[3, 7],
                        resblock_dilation_sizes=[[1, 3, 5], [1, 2, 3]], hop_size=32),
+    "small_sigma": dict(num_mels=32, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4], upsample_initial_channel=64,
+                        resblock="2", resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2], [2, 6]], hop_size=16,
+                        noise_sigma=0.3),
+    "mini_sigma": dict(mini_nsf=True, num_mels=32, upsample_rates=[4, 4, 2], upsample_kernel_sizes=[8, 8, 4],
+                       upsample_initial_channel=128, resblock_kernel_sizes=[3, 7],
+                       resblock_dilation_sizes=[[1, 3, 5], [1, 2, 3]], hop_size=32, noise_sigma=0.2),
 }
 
 
@@ -50,15 +56,17 @@ def test_vocoder_vs_golden(tag):
     gen, h, _ = build(OVER[tag], wseed)
     mel = (synth.synth_normal((bsz, t_len, h["num_mels"]), wseed + 1) * 1.5 - 5.0).astype(np.float32)
     noise = synth.synth_normal((bsz, t_len * upp, 9), wseed + 3)
+    pre = synth.synth_normal((bsz, h["upsample_initial_channel"], t_len), wseed + 4)
     wav = NsfHifiGAN(gen).spec2wav_torch(dev(mel), f0=dev(g[f"{tag}_f0"]), rand_ini=dev(g[f"{tag}_rand_ini"]),
-                                         noise=dev(noise))
+                                         noise=dev(noise), pre_noise=dev(pre))
     want = g[f"{tag}_wav"].reshape(-1)
     assert rel_err(wav, want) < TOL
     gen.release_native()
 
 
 @pytest.mark.parametrize("tag,bsz,t_len", [("small_rb2", 1, 1), ("small_rb2", 3, 130), ("default", 1, 33),
-                                           ("mini_small", 1, 1), ("mini_small", 2, 2100)])     # 2100 > one scan chunk
+                                           ("mini_small", 1, 1), ("mini_small", 2, 2100),          # 2100 > one scan chunk
+                                           ("small_sigma", 2, 70), ("mini_sigma", 1, 5)])
 def test_vocoder_vs_oracle_sizes(tag, bsz, t_len):
     gen, h, params = build(OVER[tag], 410)
     upp = int(np.prod(h["upsample_rates"]))
@@ -68,14 +76,15 @@ def test_vocoder_vs_oracle_sizes(tag, bsz, t_len):
     f0[:, ::7] = 0.0
     rand_ini = rng.random(9).astype(np.float32)
     noise = synth.synth_normal((bsz, t_len * upp, 9), 412)
-    want = ov.generator_forward(params, h, mel, f0, rand_ini, noise)
-    if h.get("mini_nsf"):               # deterministic source: the draws are not needed at all
+    pre = synth.synth_normal((bsz, h["upsample_initial_channel"], t_len), 413)
+    want = ov.generator_forward(params, h, mel, f0, rand_ini, noise, pre)
+    if h.get("mini_nsf") and not h.get("noise_sigma"):      # deterministic source: the draws are not needed at all
         with torch.no_grad():
             assert torch.equal(gen(dev(mel), dev(f0)), gen(dev(mel), dev(f0), rand_ini=dev(rand_ini), noise=dev(noise)))
     with torch.no_grad():
-        got = gen(dev(mel), dev(f0), rand_ini=dev(rand_ini), noise=dev(noise))
+        got = gen(dev(mel), dev(f0), rand_ini=dev(rand_ini), noise=dev(noise), pre_noise=dev(pre))
         got_t = gen(dev(np.ascontiguousarray(mel.transpose(0, 2, 1))).transpose(1, 2), dev(f0), rand_ini=dev(rand_ini),
-                    noise=dev(noise))                       # [B, T, M] storage viewed as [B, M, T]
+                    noise=dev(noise), pre_noise=dev(pre))                       # [B, T, M] storage viewed as [B, M, T]
         drawn = gen(dev(mel), dev(f0))                      # device-side draws: same shape, finite, bounded by tanh
     assert tuple(got.shape) == (bsz, 1, t_len * upp)
     assert rel_err(got, want) < TOL
@@ -99,7 +108,14 @@ def test_vocoder_errors_and_weight_norm_fold():
         x = torch.zeros(1, 4, 32).cuda(); f = torch.zeros(1, 4).cuda(); o = torch.zeros(1, 64).cuda()
         hd = gen.native_handle(x.device)
         _lib.check(hd, _lib.lib().dsd_vocode(hd, C.c_void_p(x.data_ptr()), 1, 4, 128, 1, 32, C.c_void_p(f.data_ptr()), None, None,
+                                             None, C.c_void_p(o.data_ptr()), None), "dsd_vocode")
+    gs, _, _ = build(OVER["small_sigma"], 421)
+    with pytest.raises(RuntimeError, match="pre_noise is required"):
+        hd = gs.native_handle(x.device)
+        _lib.check(hd, _lib.lib().dsd_vocode(hd, C.c_void_p(x.data_ptr()), 1, 4, 128, 1, 32, C.c_void_p(f.data_ptr()),
+                                             C.c_void_p(f.data_ptr()), C.c_void_p(f.data_ptr()), None,
                                              C.c_void_p(o.data_ptr()), None), "dsd_vocode")
+    gs.release_native()
     # a checkpoint that still carries weight norm: weight_g / weight_v pairs are folded on load
     sd = {}
     for k, v in params.items():

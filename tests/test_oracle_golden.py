@@ -423,6 +423,12 @@ VOC_OVER = {
     "mini_small": dict(mini_nsf=True, num_mels=32, upsample_rates=[4, 4, 2], upsample_kernel_sizes=[8, 8, 4],
                        upsample_initial_channel=128, resblock_kernel_sizes=[3, 7],
                        resblock_dilation_sizes=[[1, 3, 5], [1, 2, 3]], hop_size=32),
+    "small_sigma": dict(num_mels=32, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4], upsample_initial_channel=64,
+                        resblock="2", resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2], [2, 6]], hop_size=16,
+                        noise_sigma=0.3),
+    "mini_sigma": dict(mini_nsf=True, num_mels=32, upsample_rates=[4, 4, 2], upsample_kernel_sizes=[8, 8, 4],
+                       upsample_initial_channel=128, resblock_kernel_sizes=[3, 7],
+                       resblock_dilation_sizes=[[1, 3, 5], [1, 2, 3]], hop_size=32, noise_sigma=0.2),
 }
 VOC_GAIN = 0.7
 
@@ -434,7 +440,8 @@ def voc_case(g, tag):
     params = synth.synth_state_dict(synth.nsf_hifigan_param_shapes(h), seed=wseed, gain=VOC_GAIN)
     mel = (synth.synth_normal((bsz, t_len, h["num_mels"]), wseed + 1) * 1.5 - 5.0).astype(np.float32)
     noise = synth.synth_normal((bsz, t_len * upp, 9), wseed + 3)
-    return h, params, mel, g[f"{tag}_f0"], g[f"{tag}_rand_ini"], noise
+    pre = synth.synth_normal((bsz, h["upsample_initial_channel"], t_len), wseed + 4)       # used when noise_sigma > 0
+    return h, params, mel, g[f"{tag}_f0"], g[f"{tag}_rand_ini"], noise, pre
 
 
 @pytest.mark.parametrize("tag", sorted(VOC_OVER))
@@ -442,8 +449,8 @@ def test_g10_nsf_hifigan_generator(tag):
     """NSF-HiFiGAN generator restatement (sine source with injected phases/noise, transposed-conv upsampling, noise
     convs, ResBlock1/2, tanh) vs the reference; tolerance 5e-5 of the waveform range."""
     g = load("g10_vocoder")
-    h, params, mel, f0, rand_ini, noise = voc_case(g, tag)
-    wav = ov.spec2wav(params, h, mel, f0, rand_ini, noise)
+    h, params, mel, f0, rand_ini, noise, pre = voc_case(g, tag)
+    wav = ov.spec2wav(params, h, mel, f0, rand_ini, noise, pre_noise=pre)
     want = g[f"{tag}_wav"].reshape(-1)
     assert wav.shape == want.shape
     assert rel_err(wav, want) < 5e-5
