@@ -39,14 +39,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1000, help="mel frames per utterance (T)")
-    ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100", "acoustic_default", "acoustic_e2e", "acoustic_wav"])
+    ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100", "acoustic_default", "acoustic_e2e", "acoustic_wav", "variance_reflow20"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(kind, params, bargs, bsz, t_len):
+def cpu_baseline(kind, params, bargs, bsz, t_len, bins=128):
     """The numpy oracle (a port of the reference algorithm, parity-pinned by tests/golden) timed on the host
     cores of this box on a bounded sample of the same workload: backbone evaluations (NFE) of the same network at
     the same (B, T) - including, like the reference, the per-NFE conditioner projections.  10-15 s of CPU work."""
@@ -60,7 +60,7 @@ def cpu_baseline(kind, params, bargs, bsz, t_len):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))          # the GPU box gives one GPU a 16-core CPU share
     limiter = threadpool_limits(limits=cores)
-    x = synth.synth_normal((bsz, 1, 128, t_len), 1)
+    x = synth.synth_normal((bsz, 1, bins, t_len), 1)
     cond = synth.synth_normal((bsz, 256, t_len), 0)
     t = np.full((bsz,), 500.0, np.float32)
     if kind == "wavenet":
@@ -108,7 +108,16 @@ def main():
     from diffsinger_amd.diffusion import GaussianDiffusion
 
     B, T = args.batch, args.frames
-    if args.workload == "wavenet_dpm50":
+    variance = None
+    if args.workload == "variance_reflow20":
+        # BASELINE config 5 per GPU (configs/variance.yaml:63-72,89-96,101-110): the pitch denoiser (20x256 WaveNet, cycle 5,
+        # 64 repeat bins) and the multi-variance denoiser (10x192, cycle 4, 48 bins = energy + breathiness), rectified
+        # flow, euler 20 each, on the same condition.  One "denoise step" = one NFE of each.
+        kind, bargs = "wavenet", dict(num_layers=20, num_channels=256, dilation_cycle_length=5)
+        hp = dict(sampling_algorithm="euler", sampling_steps=20)
+        nfe, wname = 20, ("variance: pitch WaveNet 20x256 (cycle 5, 64 bins) + energy/breathiness WaveNet 10x192 "
+                          "(cycle 4, 2x24 bins), rectified flow euler 20 each (configs/variance.yaml)")
+    elif args.workload == "wavenet_dpm50":
         kind, bargs = "wavenet", dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
         hp = dict(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
         nfe, wname = 50, "WaveNet 20x256 (cycle 4, 128 bins), DPM-Solver++ 2M 1000->50"
@@ -117,7 +126,8 @@ def main():
                                       activation="PReLU", strong_cond=True)
         hp = dict(diff_accelerator="ddim", diff_speedup=10, K_step_infer=1000)
         nfe, wname = 100, "LYNXNet 6x1024 (k31, strong_cond), DDIM 1000->100"
-    shapes = synth.backbone_param_shapes(kind, 128, 1, hidden_size=256, **bargs)
+    shapes = synth.backbone_param_shapes(kind, 64 if args.workload == "variance_reflow20" else 128, 1, hidden_size=256,
+                                         **bargs)
     params = synth.synth_state_dict(shapes, seed=42)
     hparams.clear()
     acoustic = None
@@ -159,6 +169,20 @@ def main():
             vgen.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(
                 synth.nsf_hifigan_param_shapes(vh), seed=45, gain=0.7).items()}, strict=True)
             vocoder = NsfHifiGAN(vgen.to(device).eval())
+    elif args.workload == "variance_reflow20":
+        from diffsinger_amd.diffusion import MultiVarianceRectifiedFlow, PitchRectifiedFlow
+        hparams.update(hidden_size=256, schedule_type="linear", use_shallow_diffusion=False, infer=False, **hp)
+        d = PitchRectifiedFlow(vmin=-8.0, vmax=8.0, cmin=-12.0, cmax=12.0, repeat_bins=64, backbone_type=kind,
+                               backbone_args=bargs)
+        d.velocity_fn.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        vargs = dict(num_layers=10, num_channels=192, dilation_cycle_length=4)
+        variance = MultiVarianceRectifiedFlow(ranges=[(-96.0, -12.0), (-96.0, -20.0)], clamps=[(-96.0, 0.0), (-96.0, 0.0)],
+                                              repeat_bins=24, backbone_type=kind, backbone_args=vargs)
+        variance.velocity_fn.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(
+            synth.backbone_param_shapes(kind, 24, 2, hidden_size=256, **vargs), seed=46).items()}, strict=True)
+        d, variance = d.to(device).eval(), variance.to(device).eval()
+        d.denoise_fn = d.velocity_fn
+        variance.use_graph = not args.no_graph
     else:
         hparams.update(hidden_size=256, schedule_type="linear", use_shallow_diffusion=False, infer=False, **hp)
         d = GaussianDiffusion(128, 1, timesteps=1000, k_step=1000, backbone_type=kind, backbone_args=bargs,
@@ -172,7 +196,8 @@ def main():
     if rank == 0:
         cond_all = torch.from_numpy(synth.synth_normal((n_utt, T, 256), 0)).to(device)
     mine = sharding.shard_ranges(n_utt, world)[rank]
-    noise = sharding.utterance_noise((1, 128, T), mine, seed=1, device=device)      # x_T, resident before timing
+    noise = sharding.utterance_noise((1, 64 if variance is not None else 128, T), mine, seed=1, device=device)  # x_T, resident
+    noise_v = sharding.utterance_noise((2, 24, T), mine, seed=2, device=device) if variance is not None else None
     cond_local = cond_all if not use_dist else None
 
     n_tok = 120
@@ -194,6 +219,8 @@ def main():
                 if args.workload == "acoustic_e2e":     # the condition comes from the encoder on this GPU
                     return acoustic(tokens, mel2ph, f0, infer=True, noise=noise).diff_out
                 return acoustic(c, mel2ph, infer=True, noise=noise).diff_out
+        if variance is not None:        # [n, T, 3]: delta pitch, energy, breathiness (toplevel.py:262-309 runs them in this order)
+            return torch.stack([d(c, infer=True, noise=noise)] + list(variance(c, infer=True, noise=noise_v)), dim=-1)
         return d(c, infer=True, noise=noise)
 
     def step():
@@ -226,7 +253,11 @@ def main():
     frames = n_utt * T * nfe
     value = frames / sec_per_step
 
-    stats = d.denoise_fn.stats()
+    stats = dict(d.denoise_fn.stats())
+    if variance is not None:
+        for k, v in variance.velocity_fn.stats().items():
+            if k in ("flops_per_frame_nfe", "bytes_per_frame_nfe"):
+                stats[k] += v
     result = {
         "metric": "mel-frames/sec (128-bin, 44.1 kHz hop) per denoise step; end-to-end RTF",
         "value": round(value, 1),
@@ -302,7 +333,7 @@ def main():
                               "hbm_achieved_GBps": round(kbytes / sec / 1e9, 1) if sec > 0 else 0.0,
                               "hbm_frac": round(kbytes / sec / 1e9 / PEAK_HBM_GBPS, 5) if sec > 0 else 0.0}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(kind, params, bargs, B, T)
+        result["cpu_baseline"] = cpu_baseline(kind, params, bargs, B, T, bins=64 if variance is not None else 128)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

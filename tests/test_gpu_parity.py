@@ -425,3 +425,47 @@ def test_config4_per_gpu_batch_vs_oracle():
     err = rel_err(out, want)
     assert err < TOL_SAMPLER, err
     d.denoise_fn.release_native()
+
+
+def test_config5_variance_full_size_vs_oracle():
+    """BASELINE config 5's two denoisers at the sizes of configs/variance.yaml (pitch: 20x256 WaveNet, cycle 5, 64 repeat
+    bins; variances: 10x192, cycle 4, 48 bins for 2 parameters), rectified flow, euler 20, against the numpy oracle."""
+    from diffsinger_amd.diffusion import MultiVarianceRectifiedFlow, PitchRectifiedFlow
+    bsz, t_len = 2, 211
+    cond = synth.synth_normal((bsz, t_len, 256), 80)
+    cond_t = np.ascontiguousarray(np.swapaxes(cond, 1, 2))
+    set_hp(sampling_algorithm="euler", sampling_steps=20)
+    # pitch
+    pargs = dict(num_layers=20, num_channels=256, dilation_cycle_length=5)
+    p = PitchRectifiedFlow(vmin=-8.0, vmax=8.0, cmin=-12.0, cmax=12.0, repeat_bins=64, backbone_type="wavenet",
+                           backbone_args=pargs)
+    params = synth_params("wavenet", 64, 1, pargs, 81)
+    load_synth(p.velocity_fn, params)
+    p = p.cuda().eval()
+    noise = synth.synth_normal((bsz, 1, 64, t_len), 82)
+    out = p(dev(cond), infer=True, noise=dev(noise))
+    fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=5)
+    nf, smin, smax = od.repetitive_spec_ranges(-8.0, 8.0)
+    o = od.RectifiedFlow(fn, 64, nf, spec_min=smin, spec_max=smax)
+    want = od.pitch_denorm(o, o.inference(cond_t, noise, sampling_algorithm="euler", sampling_steps=20), -12.0, 12.0)
+    assert tuple(out.shape) == want.shape == (bsz, t_len)
+    assert np.abs(out.cpu().numpy() - want).max() < 2e-4 * max(1.0, np.abs(want).max())
+    p.velocity_fn.release_native()
+    # energy + breathiness
+    vargs = dict(num_layers=10, num_channels=192, dilation_cycle_length=4)
+    ranges, clamps = [(-96.0, -12.0), (-96.0, -20.0)], [(-96.0, 0.0), (-96.0, 0.0)]
+    m = MultiVarianceRectifiedFlow(ranges=ranges, clamps=clamps, repeat_bins=24, backbone_type="wavenet",
+                                   backbone_args=vargs)
+    params2 = synth_params("wavenet", 24, 2, vargs, 83)
+    load_synth(m.velocity_fn, params2)
+    m = m.cuda().eval()
+    noise2 = synth.synth_normal((bsz, 2, 24, t_len), 84)
+    outs = m(dev(cond), infer=True, noise=dev(noise2))
+    fn2 = lambda x, t, c: ob.wavenet_forward(params2, x, t, c, dilation_cycle_length=4)
+    nf, smin, smax = od.repetitive_spec_ranges([r[0] for r in ranges], [r[1] for r in ranges])
+    orf = od.RectifiedFlow(fn2, 24, nf, spec_min=smin, spec_max=smax)
+    want2 = od.multivar_denorm(orf, orf.inference(cond_t, noise2, sampling_algorithm="euler", sampling_steps=20), clamps)
+    assert len(outs) == 2
+    for a, w in zip(outs, want2):
+        assert np.abs(a.cpu().numpy() - w).max() < 2e-4 * max(1.0, np.abs(w).max())
+    m.velocity_fn.release_native()
