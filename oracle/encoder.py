@@ -46,12 +46,13 @@ def rope(t, freqs):
     return (t * np.cos(ang).astype(F32) + rot * np.sin(ang).astype(F32)).astype(F32)
 
 
-def self_attention_rope(x, p, pre, num_heads, pad_mask):
+def self_attention_rope(x, p, pre, num_heads, pad_mask, freqs=None):
     bsz, seq, dim = x.shape
     hd = dim // num_heads
     qkv = (x @ p[pre + "in_proj.weight"].T).astype(F32)
     q, k, v = (qkv[..., i * dim:(i + 1) * dim].reshape(bsz, seq, num_heads, hd).transpose(0, 2, 1, 3) for i in range(3))
-    freqs = p[pre + "rotary_embed.freqs"]
+    if freqs is None:
+        freqs = p[pre + "rotary_embed.freqs"]
     q, k = rope(q, freqs), rope(k, freqs)
     scores = (np.matmul(q, k.transpose(0, 1, 3, 2)) / F32(np.sqrt(hd))).astype(F32)
     scores = np.where(pad_mask[:, None, None, :], F32(-np.inf), scores)
@@ -87,7 +88,9 @@ def fs2_encoder(p, main_embed, extra_embed, pad_mask, num_heads, prefix="encoder
         pre = f"{prefix}layers.{l}.op."
         res = x
         y = _ln(x, p[pre + "layer_norm1.weight"], p[pre + "layer_norm1.bias"])
-        y = self_attention_rope(y, p, pre + "self_attn.", num_heads, pad_mask)
+        # one RotaryEmbedding module is shared by all layers (tts_modules.py:366-373): a parameter list names it once
+        freqs = p.get(pre + "self_attn.rotary_embed.freqs", p.get(f"{prefix}layers.0.op.self_attn.rotary_embed.freqs"))
+        y = self_attention_rope(y, p, pre + "self_attn.", num_heads, pad_mask, freqs)
         x = ((res + y) * nonpad).astype(F32)
         res = x
         y = _ln(x, p[pre + "layer_norm2.weight"], p[pre + "layer_norm2.bias"])

@@ -677,6 +677,49 @@ def g10_vocoder():
     save("g10_vocoder", **out)
 
 
+# --------------------------------------------------------------------------- G12: DiffSingerVariance, tokens -> dur / pitch / variances
+def g12_variance_model():
+    """The reference's own top-level variance model (modules/toplevel.py:125-309), infer branch, small nets; configurations
+    and seeded inputs in tests/variance_cases.py; weights = synth_state_dict over the NAME-sorted parameters."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import variance_cases as vc
+    from modules.toplevel import DiffSingerVariance  # (reference)
+    out = {}
+    for tag, c in vc.CASES.items():
+        hp = vc.case_hparams(tag)
+        set_hp(**hp)
+        model = DiffSingerVariance(c["vocab"])
+        shapes = vc.sorted_param_shapes(model.named_parameters())
+        sd = vc.synth_weights(shapes, c["seed"] + 1)
+        model.load_state_dict({k: to_t(v) for k, v in sd.items()}, strict=False)
+        model.eval()
+        inp = vc.case_inputs(tag)
+        kw = {k: (None if v is None else ({n: to_t(a) for n, a in v.items()} if isinstance(v, dict) else to_t(v)))
+              for k, v in inp.items()}
+        with InjectRandn(c["seed"] + 2) as inj, torch.no_grad():
+            dur, pitch, var = model(infer=True, **kw)
+        out[f"{tag}_params"] = np.array([f"{n}:{'x'.join(map(str, sh))}" for n, sh in shapes.items()])
+        out[f"{tag}_randn"] = np.array(inj.seeds, dtype=np.int64)
+        msg = f"  variance {tag}: {len(shapes)} tensors, randn calls={len(inj.seeds)}"
+        if dur is not None:
+            out[f"{tag}_dur"] = dur.numpy()
+            msg += f" dur[0]={np.round(dur[0].numpy(), 2).tolist()}"
+            if "word_dur" in inp and c["t_len"]:
+                from modules.fastspeech.tts_modules import LengthRegulator, RhythmRegulator  # (reference)
+                aligned = RhythmRegulator()(dur, kw["ph2word"], kw["word_dur"])
+                out[f"{tag}_dur_aligned"] = aligned.numpy()
+                out[f"{tag}_mel2ph"] = LengthRegulator()(aligned).numpy()
+        if pitch is not None:
+            out[f"{tag}_pitch"] = pitch.numpy()
+            msg += f" pitch absmax={pitch.abs().max():.3f}"
+        for n, v in (var or {}).items():
+            out[f"{tag}_{n}"] = v.numpy()
+            msg += f" {n}[{v.min():.1f},{v.max():.1f}]"
+        print(msg)
+    save("g12_variance_model", **out)
+
+
+
 # --------------------------------------------------------------------------- G11: .ds harness (host-side wire format)
 def make_ds_segments():
     """A synthetic three-segment project in the .ds wire format (written next to the fixtures as g11_segments.ds)."""
@@ -759,7 +802,7 @@ def g11_harness():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -778,5 +821,7 @@ if __name__ == "__main__":
         g9_acoustic_model()
     if "g10" in which:
         g10_vocoder()
+    if "g12" in which:
+        g12_variance_model()
     if "g11" in which:
         g11_harness()

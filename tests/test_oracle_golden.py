@@ -6,6 +6,7 @@ Tolerances are stated per test.  Reference = torch 2.10 CPU (oneDNN) fp32; oracl
 for one backbone evaluation and degrades with the number of solver steps.
 """
 import os
+from collections import OrderedDict
 
 import numpy as np
 import pytest
@@ -454,3 +455,67 @@ def test_g10_nsf_hifigan_generator(tag):
     want = g[f"{tag}_wav"].reshape(-1)
     assert wav.shape == want.shape
     assert rel_err(wav, want) < 5e-5
+
+
+# --------------------------------------------------------------------------- G12 (BASELINE config 5's callers)
+import variance_cases as vc  # noqa: E402
+from oracle import variance as ovar  # noqa: E402
+
+
+def variance_case(g, tag, named_shapes=None):
+    """hparams, weights (numpy, flat), inputs and the injected x_T of a G12 case."""
+    hp = vc.case_hparams(tag)
+    shapes = OrderedDict()
+    for item in g[f"{tag}_params"]:
+        name, shp = str(item).split(":")
+        shapes[name] = tuple(int(s) for s in shp.split("x")) if shp else ()
+    if named_shapes is not None:
+        assert list(named_shapes.items()) == list(shapes.items()), "parameter names / shapes differ from the reference's"
+    c = vc.CASES[tag]
+    params = vc.synth_weights(shapes, c["seed"] + 1)
+    inp = vc.case_inputs(tag)
+    names = [n for n in ovar.VARIANCE_CHECKLIST if hp.get("predict_" + n)]
+    t_len, bsz, seed = c["t_len"], c["bsz"], c["seed"] + 2
+    noise = {}
+    if hp["predict_pitch"]:
+        noise["noise_pitch"] = synth.synth_normal((bsz, 1, hp["pitch_prediction_args"]["repeat_bins"], t_len), seed)
+        seed += 1
+    if names:
+        rb = hp["variances_prediction_args"]["total_repeat_bins"] // len(names)
+        noise["noise_var"] = synth.synth_normal((bsz, len(names), rb, t_len), seed)
+    assert len(g[f"{tag}_randn"]) == len(noise)
+    return hp, params, inp, noise, names
+
+
+@pytest.mark.parametrize("tag", list(vc.CASES))
+def test_g12_variance_model(tag):
+    """DiffSingerVariance.forward(infer=True) restatement (word / phoneme encoder, duration predictor, rhythm + length
+    regulators, melody encoder, retake embeddings, pitch and multi-variance denoisers) vs the reference."""
+    g = load("g12_variance_model")
+    hp, params, inp, noise, names = variance_case(g, tag)
+
+    def make_fn(prefix, args):
+        sub = ovar.sub(params, prefix)
+        return lambda x, t, c: ob.wavenet_forward(sub, x, t, c, dilation_cycle_length=args["dilation_cycle_length"])
+
+    variances = {n: inp.pop(n) for n in list(inp) if n in ovar.VARIANCE_CHECKLIST}
+    dur, pitch, var = ovar.variance_model_forward(params, hp, make_fn, variances=variances, **inp, **noise)
+    if hp["predict_dur"]:
+        want = g[f"{tag}_dur"]
+        assert np.abs(dur - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+        if f"{tag}_mel2ph" in g.files:
+            aligned = ovar.rhythm_regulator(dur, inp["ph2word"], inp["word_dur"])
+            assert np.array_equal(aligned, g[f"{tag}_dur_aligned"])
+            assert np.array_equal(ovar.length_regulator(aligned), g[f"{tag}_mel2ph"])
+    else:
+        assert dur is None
+    if hp["predict_pitch"]:
+        want = g[f"{tag}_pitch"]
+        assert (np.abs(want) < 11.99).mean() > 0.5          # mostly inside the clip range: the comparison means something
+        assert np.abs(pitch - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+    else:
+        assert pitch is None
+    assert list(var) == names
+    for n in names:
+        want = g[f"{tag}_{n}"]
+        assert np.abs(var[n] - want).max() < 1e-4 * np.abs(want).max()

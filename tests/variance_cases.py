@@ -1,0 +1,149 @@
+"""Configurations and seeded inputs of the G12 fixtures (DiffSingerVariance, modules/toplevel.py:125-309), shared by
+tests/golden/make_golden.py (which runs the reference on them) and the oracle / GPU tests (which rebuild the inputs
+and the weights from the same seeds; only the reference's outputs are stored)."""
+from collections import OrderedDict
+
+import numpy as np
+
+ENC_HP = dict(hidden_size=256, enc_layers=2, enc_ffn_kernel_size=3, ffn_act="gelu", dropout=0.1, num_heads=2,
+              use_pos_embed=True, rel_pos=True, use_rope=True, use_spk_id=False, num_spk=1, use_lang_id=False, num_lang=1,
+              predict_dur=False, predict_pitch=False, predict_energy=False, predict_breathiness=False,
+              predict_voicing=False, predict_tension=False, use_melody_encoder=False, use_glide_embed=False,
+              glide_types=["up", "down"], glide_embed_scale=11.313708498984760,
+              energy_db_min=-96.0, energy_db_max=-12.0, breathiness_db_min=-96.0, breathiness_db_max=-20.0,
+              voicing_db_min=-96.0, voicing_db_max=-12.0, tension_logit_min=-10.0, tension_logit_max=10.0,
+              timesteps=1000, K_step=1000, time_scale_factor=1000, schedule_type="linear", max_beta=0.02,
+              dur_prediction_args=dict(arch="fs2", hidden_size=192, dropout=0.1, num_layers=3, kernel_size=3, log_offset=1.0,
+                                       loss_type="mse"),
+              melody_encoder_args=dict(hidden_size=128, enc_layers=2),
+              pitch_prediction_args=dict(pitd_norm_min=-8.0, pitd_norm_max=8.0, pitd_clip_min=-12.0, pitd_clip_max=12.0,
+                                         repeat_bins=32, backbone_type="wavenet",
+                                         backbone_args=dict(num_layers=4, num_channels=64, dilation_cycle_length=2)),
+              variances_prediction_args=dict(total_repeat_bins=48, backbone_type="wavenet",
+                                             backbone_args=dict(num_layers=3, num_channels=64, dilation_cycle_length=3)))
+
+CASES = OrderedDict(
+    # inference "from file" (toplevel.py:228-231): durations predicted, aligned to the word durations, regulated to mel2ph
+    word_reflow=dict(hp=dict(predict_dur=True, predict_pitch=True, predict_energy=True, predict_breathiness=True,
+                             diffusion_type="reflow", sampling_algorithm="euler", sampling_steps=6),
+                     vocab=30, bsz=2, n_ph=11, n_word=5, t_len=57, seed=1200),
+    # phoneme mode, melody encoder + glide, speaker and language ids, DDIM, a retake mask with an expressiveness curve
+    melody_ddim=dict(hp=dict(predict_pitch=True, use_melody_encoder=True, use_glide_embed=True, use_spk_id=True, num_spk=3,
+                             use_lang_id=True, num_lang=2, diffusion_type="ddpm", diff_accelerator="ddim", diff_speedup=200,
+                             dur_prediction_args=dict(arch="fs2", hidden_size=512, dropout=0.1, num_layers=5,
+                                                      kernel_size=3, log_offset=1.0, loss_type="mse")),
+                     vocab=24, bsz=2, n_ph=9, n_word=4, t_len=44, seed=1210),
+    # variances only, three of them, with retake masks; pitch given
+    var_only=dict(hp=dict(predict_energy=True, predict_voicing=True, predict_tension=True, diffusion_type="reflow",
+                          sampling_algorithm="rk2", sampling_steps=3),
+                  vocab=18, bsz=3, n_ph=7, n_word=3, t_len=31, seed=1220),
+    # duration predictor alone (toplevel.py:225-226), the default predictor size, a padded batch
+    dur_only=dict(hp=dict(predict_dur=True, diffusion_type="reflow",
+                          dur_prediction_args=dict(arch="fs2", hidden_size=512, dropout=0.1, num_layers=5, kernel_size=3,
+                                                   log_offset=1.0, loss_type="mse")),
+                  vocab=40, bsz=3, n_ph=17, n_word=6, t_len=0, seed=1230),
+)
+
+
+def case_hparams(tag):
+    hp = dict(ENC_HP)
+    hp.update(CASES[tag]["hp"])
+    return hp
+
+
+def case_inputs(tag):
+    """Seeded inputs of DiffSingerVariance.forward for a case: a dict of numpy arrays / None."""
+    c, hp = CASES[tag], case_hparams(tag)
+    rng = np.random.Generator(np.random.PCG64(c["seed"]))
+    bsz, n_ph, n_word, t_len = c["bsz"], c["n_ph"], c["n_word"], c["t_len"]
+    tokens = rng.integers(1, c["vocab"], (bsz, n_ph)).astype(np.int64)
+    ph2word = np.zeros((bsz, n_ph), dtype=np.int64)
+    lens = [n_ph - 2 * b for b in range(bsz)]                       # later utterances are padded
+    for b in range(bsz):
+        cuts = np.sort(rng.choice(np.arange(1, lens[b]), n_word - 1, replace=False))
+        ph2word[b, :lens[b]] = np.searchsorted(cuts, np.arange(lens[b]), side="right") + 1
+        tokens[b, lens[b]:] = 0
+    midi = rng.integers(40, 80, (bsz, n_ph)).astype(np.int64) * (tokens > 0)
+    out = dict(txt_tokens=tokens, midi=midi, ph2word=ph2word)
+    t_eff = t_len if t_len else 40
+    ph_dur = np.zeros((bsz, n_ph), dtype=np.int64)
+    for b in range(bsz):
+        w = rng.random(lens[b]) + 0.3
+        d = np.maximum(1, np.floor(w / w.sum() * (t_eff - b * 5)).astype(np.int64))
+        ph_dur[b, :lens[b]] = d
+    word_dur = np.zeros((bsz, n_word), dtype=np.int64)
+    for b in range(bsz):
+        np.add.at(word_dur[b], ph2word[b, :lens[b]] - 1, ph_dur[b, :lens[b]])
+    if hp["predict_dur"]:
+        out["word_dur"] = word_dur
+    else:
+        out["ph_dur"] = ph_dur
+        mel2ph = np.zeros((bsz, t_len), dtype=np.int64)
+        for b in range(bsz):
+            seq = np.repeat(np.arange(1, n_ph + 1), ph_dur[b])
+            mel2ph[b, :len(seq)] = seq[:t_len]
+        out["mel2ph"] = mel2ph
+    if hp.get("use_lang_id"):
+        out["languages"] = rng.integers(1, hp["num_lang"] + 1, (bsz, n_ph)).astype(np.int64) * (tokens > 0)
+    if hp.get("use_spk_id"):
+        out["spk_id"] = rng.integers(0, hp["num_spk"], (bsz,)).astype(np.int64)
+    if t_len:
+        out["base_pitch"] = (60.0 + 6.0 * np.sin(np.arange(t_len)[None, :] / 7.0 + np.arange(bsz)[:, None])).astype(np.float32)
+    if hp["predict_pitch"] and hp.get("use_melody_encoder"):
+        n_note = 6
+        note_midi = rng.uniform(48, 72, (bsz, n_note)).astype(np.float32)
+        note_rest = rng.random((bsz, n_note)) < 0.25
+        note_dur = np.zeros((bsz, n_note), dtype=np.int64)
+        mel2note = np.zeros((bsz, t_len), dtype=np.int64)
+        for b in range(bsz):
+            n_b = n_note - b
+            note_midi[b, n_b:] = -1.0                               # padding notes
+            w = rng.random(n_b) + 0.4
+            d = np.maximum(1, np.floor(w / w.sum() * (t_len - 3 * b)).astype(np.int64))
+            note_dur[b, :n_b] = d
+            seq = np.repeat(np.arange(1, n_b + 1), d)
+            mel2note[b, :len(seq)] = seq[:t_len]
+        out.update(note_midi=note_midi, note_rest=note_rest, note_dur=note_dur, mel2note=mel2note,
+                   note_glide=rng.integers(0, 3, (bsz, n_note)).astype(np.int64) * (note_midi >= 0))
+    if tag == "melody_ddim":
+        retake = np.zeros((bsz, t_len), dtype=bool)
+        retake[:, t_len // 3: 2 * t_len // 3] = True
+        out["pitch_retake"] = retake
+        out["pitch"] = (out["base_pitch"] + rng.normal(0, 0.5, (bsz, t_len))).astype(np.float32)
+        out["pitch_expr"] = rng.random((bsz, t_len)).astype(np.float32)
+    if tag == "var_only":
+        out["pitch"] = (out["base_pitch"] + rng.normal(0, 0.5, (bsz, t_len))).astype(np.float32)
+        out["variance_retake"] = {n: rng.random((bsz, t_len)) < 0.5 for n in ("energy", "voicing", "tension")}
+        out["energy"] = rng.uniform(-60, -10, (bsz, t_len)).astype(np.float32)
+        out["voicing"] = rng.uniform(-60, -10, (bsz, t_len)).astype(np.float32)
+        out["tension"] = rng.uniform(-5, 5, (bsz, t_len)).astype(np.float32)
+    return out
+
+
+def sorted_param_shapes(named_parameters):
+    """name -> shape in NAME order: the order synth_state_dict draws in must not depend on module construction order."""
+    return OrderedDict(sorted((n, tuple(int(s) for s in p.shape)) for n, p in named_parameters))
+
+
+# Linear(1, H) embeddings of inputs that are O(10)-O(100) (frame counts, MIDI pitch, dB) would drown everything else with
+# N(0, 1) weights, and the duration predictor's head should spread its log-domain output around 1: rescale those
+# after the generic draw (same draw order, so every other tensor is unaffected).
+_RESCALE = (("word_dur_embed.weight", 0.05), ("ph_dur_embed.weight", 0.05), ("note_dur_embed.weight", 0.05),
+            ("note_midi_embed.weight", 0.02), ("base_pitch_embed.weight", 0.02), ("pitch_embed.weight", 0.02),
+            ("delta_pitch_embed.weight", 0.3))
+
+
+def synth_weights(shapes, seed):
+    from diffsinger_amd import synth
+    sd = synth.synth_state_dict(shapes, seed=seed)
+    for name, w in sd.items():
+        for suffix, k in _RESCALE:
+            if name.endswith(suffix):
+                sd[name] = (w * np.float32(k)).astype(np.float32)
+        if "variance_embeds." in name and name.endswith(".weight"):
+            sd[name] = (w * np.float32(0.02)).astype(np.float32)
+        if "dur_predictor.conv." in name and name.endswith(".weight") and w.ndim == 1:
+            sd[name] = (1.0 + w * np.sqrt(np.float32(w.shape[0])) * 0.1).astype(np.float32)     # LayerNorm gains around 1
+        if name.endswith("dur_predictor.linear.bias"):
+            sd[name] = (1.0 + w).astype(np.float32)
+    return sd
