@@ -25,6 +25,7 @@ EXPORTS = [
     "dsd_api_version", "dsd_create", "dsd_destroy", "dsd_last_error", "dsd_load_weight",
     "dsd_finalize_weights", "dsd_prepare_cond", "dsd_denoise", "dsd_sample", "dsd_get_stats",
     "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode", "dsd_vocoder_create", "dsd_vocode",
+    "dsd_token_encoder_create", "dsd_token_encode", "dsd_predict_dur", "dsd_cond_assemble",
 ]
 EMBED_FLAGS = {"energy": 1, "breathiness": 2, "voicing": 4, "tension": 8, "key_shift": 16, "speed": 32}
 
@@ -48,6 +49,26 @@ class DsdVocoderConfig(C.Structure):
                 ("resblock_kernel_sizes", C.c_int32 * 8), ("n_dilations", C.c_int32 * 8),
                 ("resblock_dilation_sizes", (C.c_int32 * 4) * 8), ("harmonic_num", C.c_int32), ("mini_nsf", C.c_int32),
                 ("noise_sigma", C.c_float), ("device", C.c_int32)]
+
+
+class DsdTokenEncoderConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("hidden_size", C.c_int32), ("enc_layers", C.c_int32), ("num_heads", C.c_int32),
+                ("ffn_kernel_size", C.c_int32), ("out_dims", C.c_int32), ("dur_layers", C.c_int32), ("dur_chans", C.c_int32),
+                ("dur_kernel_size", C.c_int32), ("dur_offset", C.c_float), ("device", C.c_int32)]
+
+
+class _AssembleGather(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("batch_stride", C.c_int64), ("rows", C.c_int64), ("idx", C.c_void_p),
+                ("idx_offset", C.c_int64), ("scale", C.c_float), ("row_scale", C.c_void_p)]
+
+
+class _AssembleTerm(C.Structure):
+    _fields_ = [("s", C.c_void_p), ("v", C.c_void_p)]
+
+
+class DsdAssembleArgs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32),
+                ("n_gather", C.c_int32), ("n_terms", C.c_int32), ("gather", _AssembleGather * 4), ("term", _AssembleTerm * 16)]
 
 
 class DsdEncodeExtras(C.Structure):
@@ -112,13 +133,17 @@ def _load():
     lib.dsd_vocoder_create.argtypes = [C.POINTER(DsdVocoderConfig), C.POINTER(vp)]
     lib.dsd_vocode.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.dsd_encoder_create.argtypes = [C.POINTER(DsdEncoderConfig), C.POINTER(vp)]
+    lib.dsd_token_encoder_create.argtypes = [C.POINTER(DsdTokenEncoderConfig), C.POINTER(vp)]
+    lib.dsd_token_encode.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.dsd_predict_dur.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.dsd_cond_assemble.argtypes = [C.POINTER(DsdAssembleArgs), vp, vp]
     lib.dsd_encode.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.POINTER(DsdEncodeExtras), vp, vp]
     lib.dsd_get_stats.argtypes = [vp, C.POINTER(DsdStats)]
     lib.dsd_kernel_timing.argtypes = [vp, i32]
     lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     for name in EXPORTS:
         getattr(lib, name)
-    if lib.dsd_api_version() != 5:
+    if lib.dsd_api_version() != 6:
         raise NativeLibraryError("libdsdenoise.so API version mismatch")
     return lib
 

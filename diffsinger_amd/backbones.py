@@ -70,6 +70,10 @@ class _NativeBackbone(nn.Module):
     def _extra_weights(self):
         return {}
 
+    def _native_state(self):
+        """name -> tensor of what the native handle loads (default: the whole state_dict)."""
+        return dict(self.state_dict())
+
     def native_handle(self, device):
         if device.type != "cuda":
             raise RuntimeError(
@@ -83,6 +87,7 @@ class _NativeBackbone(nn.Module):
             cfg = self._config(idx)
             hp = C.c_void_p()
             create = (lib.dsd_encoder_create if isinstance(cfg, _lib.DsdEncoderConfig) else
+                      lib.dsd_token_encoder_create if isinstance(cfg, _lib.DsdTokenEncoderConfig) else
                       lib.dsd_vocoder_create if isinstance(cfg, _lib.DsdVocoderConfig) else lib.dsd_create)
             rc = create(C.byref(cfg), C.byref(hp))
             if rc != 0:
@@ -90,7 +95,7 @@ class _NativeBackbone(nn.Module):
             self._handle, self._handle_device = hp, idx
             self._weights_dirty = True
         if self._weights_dirty:
-            tensors = dict(self.state_dict())
+            tensors = self._native_state()
             tensors.update(self._extra_weights())
             for name, t in tensors.items():
                 t = t.detach().to(device=device, dtype=torch.float32).contiguous()

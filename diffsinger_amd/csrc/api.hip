@@ -90,6 +90,14 @@ struct dsd_handle {
     float *e_x = nullptr, *e_y = nullptr, *e_qkv = nullptr, *e_mid = nullptr, *e_nonpad = nullptr;
     int* e_dur = nullptr;
     float* e_arena = nullptr;
+    // token encoder (variance model): FastSpeech2Encoder + out_proj / DurationPredictor
+    dsd_token_encoder_config tcfg;
+    PackedGemm g_tout;
+    std::vector<PackedGemm> g_dconv;
+    std::vector<size_t> d_lng, d_lnb;
+    size_t d_linw = 0, d_linb = 0;
+    float *d_a = nullptr, *d_b = nullptr, *d_in = nullptr;
+    int dC = 0;
     size_t freqs_off = 0;
     int emb_act = ACT_MISH;
 
@@ -149,6 +157,7 @@ inline int inner_of(const dsd_handle* h) { return h->cfg.num_channels * h->cfg.e
 inline bool is_wavenet(const dsd_handle* h) { return h->cfg.backbone == DSD_BACKBONE_WAVENET; }
 inline bool is_aux(const dsd_handle* h) { return h->cfg.backbone == DSD_AUX_CONVNEXT; }
 inline bool is_enc(const dsd_handle* h) { return h->cfg.backbone == DSD_ENC_FS2_ACOUSTIC; }
+inline bool is_tok(const dsd_handle* h) { return h->cfg.backbone == DSD_ENC_FS2_TOKENS; }
 inline bool is_voc(const dsd_handle* h) { return h->cfg.backbone == DSD_VOC_NSF_HIFIGAN; }
 
 inline int voc_stage_channels(const dsd_vocoder_config& v, int i) { return v.upsample_initial_channel >> (i + 1); }
@@ -212,22 +221,17 @@ inline bool lin_present(const dsd_encoder_config& e, int k) {
     return (e.embed_flags & bit[k]) != 0;
 }
 
-// FastSpeech2Acoustic state_dict (acoustic_encoder.py:15-63; tts_modules.py:353-383; common_layers.py:120-234)
-std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_enc(const dsd_encoder_config& e) {
-    std::vector<std::pair<std::string, std::vector<int64_t>>> v;
-    const int64_t H = e.hidden_size, ks = e.ffn_kernel_size;
+// FastSpeech2Encoder state_dict (tts_modules.py:353-383; common_layers.py:120-234)
+void expected_fs2_layers(std::vector<std::pair<std::string, std::vector<int64_t>>>& v, int64_t H, int layers, int heads,
+                         int64_t ks) {
     auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
-    add("txt_embed.weight", {e.vocab_size, H});
-    if (e.num_lang > 0) add("lang_embed.weight", {e.num_lang + 1, H});
-    add("dur_embed.weight", {H, 1});
-    add("dur_embed.bias", {H});
-    for (int l = 0; l < e.enc_layers; ++l) {
+    for (int l = 0; l < layers; ++l) {
         const std::string p = "encoder.layers." + std::to_string(l) + ".op.";
         add(p + "layer_norm1.weight", {H});
         add(p + "layer_norm1.bias", {H});
         add(p + "self_attn.in_proj.weight", {3 * H, H});
         add(p + "self_attn.out_proj.weight", {H, H});
-        add(p + "self_attn.rotary_embed.freqs", {H / e.num_heads / 2});
+        add(p + "self_attn.rotary_embed.freqs", {H / heads / 2});
         add(p + "layer_norm2.weight", {H});
         add(p + "layer_norm2.bias", {H});
         add(p + "ffn.ffn_1.weight", {4 * H, H, ks});
@@ -237,6 +241,43 @@ std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_enc(co
     }
     add("encoder.layer_norm.weight", {H});
     add("encoder.layer_norm.bias", {H});
+}
+
+// token encoder of the variance model: FastSpeech2Encoder + MelodyEncoder.out_proj (variance_encoder.py:126) and / or
+// DurationPredictor (tts_modules.py:77-100: Sequential(Identity, Conv1d, ReLU, LayerNorm, Dropout) x n, Linear(C, 1))
+std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_tok(const dsd_token_encoder_config& t) {
+    std::vector<std::pair<std::string, std::vector<int64_t>>> v;
+    const int64_t H = t.hidden_size;
+    auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
+    expected_fs2_layers(v, H, t.enc_layers, t.num_heads, t.ffn_kernel_size);
+    if (t.out_dims > 0) {
+        add("out_proj.weight", {t.out_dims, H});
+        add("out_proj.bias", {t.out_dims});
+    }
+    for (int l = 0; l < t.dur_layers; ++l) {
+        const std::string p = "dur_predictor.conv." + std::to_string(l) + ".";
+        add(p + "1.weight", {t.dur_chans, l == 0 ? H : (int64_t)t.dur_chans, t.dur_kernel_size});
+        add(p + "1.bias", {t.dur_chans});
+        add(p + "3.weight", {t.dur_chans});
+        add(p + "3.bias", {t.dur_chans});
+    }
+    if (t.dur_layers > 0) {
+        add("dur_predictor.linear.weight", {1, t.dur_chans});
+        add("dur_predictor.linear.bias", {1});
+    }
+    return v;
+}
+
+// FastSpeech2Acoustic state_dict (acoustic_encoder.py:15-63; tts_modules.py:353-383; common_layers.py:120-234)
+std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_enc(const dsd_encoder_config& e) {
+    std::vector<std::pair<std::string, std::vector<int64_t>>> v;
+    const int64_t H = e.hidden_size, ks = e.ffn_kernel_size;
+    auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
+    add("txt_embed.weight", {e.vocab_size, H});
+    if (e.num_lang > 0) add("lang_embed.weight", {e.num_lang + 1, H});
+    add("dur_embed.weight", {H, 1});
+    add("dur_embed.bias", {H});
+    expected_fs2_layers(v, H, e.enc_layers, e.num_heads, ks);
     for (int k = 0; k < 7; ++k)
         if (lin_present(e, k)) {
             add(std::string(kLinNames[k]) + ".weight", {H, 1});
@@ -434,23 +475,24 @@ int build_packed_aux(dsd_handle* h) {
 
 // FastSpeech2 acoustic encoder: 1x1 / k-tap GEMM operands in fragment order, everything else copied as is.
 // The FFN's `x * kernel_size ** -0.5` (common_layers.py:146) is folded into ffn_1's weights and bias.
+size_t blob_copy_vec(dsd_handle* h, const std::string& name) {
+    const auto& d = W(h, name).data;
+    const size_t off = blob_reserve(h, d.size());
+    memcpy(h->blob_host.data() + off, d.data(), sizeof(float) * d.size());
+    return off;
+}
+
+void pack_fs2_layers(dsd_handle* h, int H, int L, int ks);
+
 int build_packed_enc(dsd_handle* h) {
     const dsd_encoder_config& e = h->ecfg;
     const int H = e.hidden_size, L = e.enc_layers, ks = e.ffn_kernel_size;
     h->blob_host.clear();
-    auto copy_vec = [&](const std::string& name) {
-        const auto& d = W(h, name).data;
-        const size_t off = blob_reserve(h, d.size());
-        memcpy(h->blob_host.data() + off, d.data(), sizeof(float) * d.size());
-        return off;
-    };
+    auto copy_vec = [&](const std::string& name) { return blob_copy_vec(h, name); };
     h->e_txt = copy_vec("txt_embed.weight");
     h->e_lang = e.num_lang > 0 ? copy_vec("lang_embed.weight") : SIZE_MAX;
     h->e_durw = copy_vec("dur_embed.weight");
     h->e_durb = copy_vec("dur_embed.bias");
-    h->e_freqs = copy_vec("encoder.layers.0.op.self_attn.rotary_embed.freqs");     // one shared RotaryEmbedding
-    h->e_lng = copy_vec("encoder.layer_norm.weight");
-    h->e_lnb = copy_vec("encoder.layer_norm.bias");
     h->e_spk = e.num_spk > 0 ? copy_vec("spk_embed.weight") : SIZE_MAX;
     for (int k = 0; k < 7; ++k) {
         h->e_linw[k] = h->e_linb[k] = SIZE_MAX;
@@ -459,6 +501,47 @@ int build_packed_enc(dsd_handle* h) {
             h->e_linb[k] = copy_vec(std::string(kLinNames[k]) + ".bias");
         }
     }
+    pack_fs2_layers(h, H, L, ks);
+    return DSD_OK;
+}
+
+// token encoder: the shared layers, then out_proj as a 1x1 GEMM and the duration predictor's convolutions as k-tap GEMMs
+int build_packed_tok(dsd_handle* h) {
+    const dsd_token_encoder_config& t = h->tcfg;
+    const int H = t.hidden_size;
+    h->blob_host.clear();
+    pack_fs2_layers(h, H, t.enc_layers, t.ffn_kernel_size);
+    if (t.out_dims > 0) {
+        const HostTensor* w = &W(h, "out_proj.weight");
+        const HostTensor* b = &W(h, "out_proj.bias");
+        std::function<double(int)> bf = [b](int i) { return (double)b->data[i]; };
+        h->g_tout = pack_gemm(h, t.out_dims, H, 1, 0, WGet([w, H](int r, int k, int) { return (double)w->data[(size_t)r * H + k]; }), &bf);
+    }
+    const int Cd = t.dur_chans, kd = t.dur_kernel_size;
+    h->g_dconv.resize(t.dur_layers); h->d_lng.resize(t.dur_layers); h->d_lnb.resize(t.dur_layers);
+    for (int l = 0; l < t.dur_layers; ++l) {
+        const std::string p = "dur_predictor.conv." + std::to_string(l) + ".";
+        const int cin = l == 0 ? H : Cd;
+        const HostTensor* w = &W(h, p + "1.weight");
+        const HostTensor* b = &W(h, p + "1.bias");
+        std::function<double(int)> bf = [b](int i) { return (double)b->data[i]; };
+        h->g_dconv[l] = pack_gemm(h, Cd, cin, kd, 0,
+                                  WGet([w, cin, kd](int r, int k, int tap) { return (double)w->data[((size_t)r * cin + k) * kd + tap]; }), &bf);
+        h->d_lng[l] = blob_copy_vec(h, p + "3.weight");
+        h->d_lnb[l] = blob_copy_vec(h, p + "3.bias");
+    }
+    if (t.dur_layers > 0) {
+        h->d_linw = blob_copy_vec(h, "dur_predictor.linear.weight");
+        h->d_linb = blob_copy_vec(h, "dur_predictor.linear.bias");
+    }
+    return DSD_OK;
+}
+
+void pack_fs2_layers(dsd_handle* h, int H, int L, int ks) {
+    auto copy_vec = [&](const std::string& name) { return blob_copy_vec(h, name); };
+    h->e_freqs = copy_vec("encoder.layers.0.op.self_attn.rotary_embed.freqs");     // one shared RotaryEmbedding
+    h->e_lng = copy_vec("encoder.layer_norm.weight");
+    h->e_lnb = copy_vec("encoder.layer_norm.bias");
     h->g_qkv.resize(L); h->g_oproj.resize(L); h->g_ffn1.resize(L); h->g_ffn2.resize(L);
     h->e_ln1g.resize(L); h->e_ln1b.resize(L); h->e_ln2g.resize(L); h->e_ln2b.resize(L);
     const double fscale = 1.0 / sqrt((double)ks);
@@ -485,7 +568,6 @@ int build_packed_enc(dsd_handle* h) {
         std::function<double(int)> b2f = [b2](int i) { return (double)b2->data[i]; };
         h->g_ffn2[l] = pack_gemm(h, H, 4 * H, 1, 0, lin(p + "ffn.ffn_2.weight", 4 * H), &b2f);
     }
-    return DSD_OK;
 }
 
 // NSF-HiFiGAN generator.  A ConvTranspose1d(C_in, C_out, K, stride u, padding (K-u)/2) becomes an ordinary odd-tap
@@ -603,9 +685,15 @@ int build_packed_voc(dsd_handle* h) {
     return DSD_OK;
 }
 
+std::vector<std::pair<std::string, std::vector<int64_t>>> expected_for(const dsd_handle* h) {
+    return is_enc(h) ? expected_params_enc(h->ecfg) : is_tok(h) ? expected_params_tok(h->tcfg)
+         : is_voc(h) ? expected_params_voc(h->vcfg) : expected_params(h->cfg);
+}
+
 int build_packed(dsd_handle* h) {
     if (is_aux(h)) return build_packed_aux(h);
     if (is_enc(h)) return build_packed_enc(h);
+    if (is_tok(h)) return build_packed_tok(h);
     if (is_voc(h)) return build_packed_voc(h);
     const dsd_config& c = h->cfg;
     const int C = c.num_channels, M = FM_of(h), H = c.hidden_size, L = c.num_layers;
@@ -1161,12 +1249,12 @@ int dsd_load_weight(dsd_handle* h, const char* name, const float* data, const in
     const std::string n(name);
     std::vector<int64_t> shp(shape, shape + ndim);
     bool found = false;
-    if (n == "diffusion_embedding.freqs" && !is_enc(h) && !is_voc(h)) {
+    if (n == "diffusion_embedding.freqs" && !is_enc(h) && !is_voc(h) && !is_tok(h)) {
         if (ndim != 1 || shp[0] != h->cfg.num_channels / 2)
             return fail(h, DSD_EINVAL, "diffusion_embedding.freqs must have shape [%d]", h->cfg.num_channels / 2);
         found = true;
     } else {
-        for (auto& e : (is_enc(h) ? expected_params_enc(h->ecfg) : is_voc(h) ? expected_params_voc(h->vcfg) : expected_params(h->cfg))) {
+        for (auto& e : expected_for(h)) {
             if (e.first != n) continue;
             if (e.second != shp) {
                 std::string want, got;
@@ -1198,7 +1286,7 @@ int dsd_load_weight(dsd_handle* h, const char* name, const float* data, const in
 int dsd_finalize_weights(dsd_handle* h) {
     if (!h) return DSD_EINVAL;
     std::string missing;
-    for (auto& e : (is_enc(h) ? expected_params_enc(h->ecfg) : is_voc(h) ? expected_params_voc(h->vcfg) : expected_params(h->cfg)))
+    for (auto& e : expected_for(h))
         if (!h->raw.count(e.first)) missing += (missing.empty() ? "" : ", ") + e.first;
     if (!missing.empty()) return fail(h, DSD_ESTATE, "missing keys in state_dict: %s", missing.c_str());
     HIP_OK(h, hipSetDevice(h->cfg.device));
@@ -1222,7 +1310,7 @@ int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int
                      int64_t stride_t, void* stream) {
     if (!h || !cond) return fail(h, DSD_EINVAL, "dsd_prepare_cond: null argument");
     if (is_aux(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is an aux decoder (use dsd_aux_decode)");
-    if (is_enc(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is an encoder (use dsd_encode)");
+    if (is_enc(h) || is_tok(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is an encoder (use dsd_encode / dsd_token_encode)");
     if (is_voc(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is a vocoder (use dsd_vocode)");
     if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_prepare_cond: weights are not finalized");
     if (B < 1 || T < 1) return fail(h, DSD_EINVAL, "dsd_prepare_cond: B and T must be positive (B=%d, T=%d)", B, T);
@@ -1281,6 +1369,77 @@ int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out) {
     return DSD_OK;
 }
 
+// workspace of an encoder pass over (B, L): x, y [H], qkv [3H], mid [4H], nonpad, dur (+ two [Cd] buffers and one [H]
+// input buffer for the duration predictor)
+static int enc_workspace(dsd_handle* h, int B, int L, int H, int Cd) {
+    const int Ls = padded_ts(L);
+    if (h->e_arena && h->eB == B && h->eL == L && h->dC == Cd) return DSD_OK;
+    if (h->e_arena) (void)hipFree(h->e_arena);
+    h->e_arena = nullptr;
+    const size_t per = (size_t)B * Ls;
+    size_t off = kGuard;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += (n + 63) / 64 * 64 + 64;
+        return o;
+    };
+    const size_t o_x = take(per * H), o_y = take(per * H), o_qkv = take(per * 3 * H), o_mid = take(per * 4 * H);
+    const size_t o_np = take(per), o_dur = take((size_t)B * L);
+    const size_t o_da = take(per * Cd), o_db = take(per * Cd), o_di = take(Cd > 0 ? per * H : 0);
+    off += kGuard;
+    float* a = nullptr;
+    if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
+        return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the encoder workspace failed", off * 4);
+    if (hipMemset(a, 0, off * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(encoder workspace) failed");
+    h->e_arena = a;
+    h->eB = B; h->eL = L; h->eLs = Ls; h->dC = Cd;
+    h->e_x = a + o_x; h->e_y = a + o_y; h->e_qkv = a + o_qkv; h->e_mid = a + o_mid; h->e_nonpad = a + o_np;
+    h->e_dur = reinterpret_cast<int*>(a + o_dur);
+    h->d_a = a + o_da; h->d_b = a + o_db; h->d_in = a + o_di;
+    return DSD_OK;
+}
+
+// FastSpeech2Encoder.forward after the embedding (tts_modules.py:412-424): e_x (already masked) -> e_y = LN(x) * nonpad
+static int run_fs2_layers(dsd_handle* h, int H, int NL, int heads, int ffn_ks, int B, int L, hipStream_t st) {
+    const int Ls = h->eLs;
+    const float* blob = h->blob;
+    const long xs = (long)H * Ls;
+    hipError_t er;
+    int rc;
+#define ENC_OK(expr, what)                                                                        \
+    if ((er = (expr)) != hipSuccess) return fail(h, DSD_EHIP, what " launch failed: %s", hipGetErrorString(er))
+    for (int l = 0; l < NL; ++l) {      // EncSALayer.forward  (common_layers.py:236-268)
+        ENC_OK(launch_enc_layernorm(h->e_x, h->e_y, blob + h->e_ln1g[l], blob + h->e_ln1b[l], nullptr, H, B, L, Ls, 1e-5f, st),
+               "layer_norm1");
+        GemmCall q = make_gemm(h, h->g_qkv[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_ACT, 0);
+        q.p.act = ACT_NONE; q.p.out = h->e_qkv; q.p.o_bstride = 3 * xs; q.p.o_rstride = Ls;
+        if ((rc = run_gemm(h, q, st))) return rc;
+        ENC_OK(launch_enc_rope(h->e_qkv, blob + h->e_freqs, H, H / heads, B, L, Ls, st), "rope");
+        ENC_OK(launch_enc_attention(h->e_qkv, h->e_nonpad, h->e_y, H, heads, B, L, Ls, st), "attention");
+        GemmCall o = make_gemm(h, h->g_oproj[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_RES, 0);
+        o.p.aux = h->e_x; o.p.aux_bstride = xs; o.p.aux_rstride = Ls;
+        o.p.out = h->e_x; o.p.o_bstride = xs; o.p.o_rstride = Ls;
+        if ((rc = run_gemm(h, o, st))) return rc;
+        ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
+        ENC_OK(launch_enc_layernorm(h->e_x, h->e_y, blob + h->e_ln2g[l], blob + h->e_ln2b[l], nullptr, H, B, L, Ls, 1e-5f, st),
+               "layer_norm2");
+        // TransformerFFNLayer (common_layers.py:142-151): Conv1d(H, 4H, k) * k^-0.5 -> GELU -> Linear(4H, H)
+        GemmCall f1 = make_gemm(h, h->g_ffn1[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_ACT, 1, ffn_ks > 1);
+        f1.p.act = ACT_GELU; f1.p.out = h->e_mid; f1.p.o_bstride = 4 * xs; f1.p.o_rstride = Ls;
+        if ((rc = run_gemm(h, f1, st))) return rc;
+        GemmCall f2 = make_gemm(h, h->g_ffn2[l], h->e_mid, 4 * xs, Ls, B, L, ST_PLAIN, EP_BIAS_RES, 0);
+        f2.p.aux = h->e_x; f2.p.aux_bstride = xs; f2.p.aux_rstride = Ls;
+        f2.p.out = h->e_x; f2.p.o_bstride = xs; f2.p.o_rstride = Ls;
+        if ((rc = run_gemm(h, f2, st))) return rc;
+        ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
+    }
+    // final LayerNorm * nonpadding  (tts_modules.py:424)
+    ENC_OK(launch_enc_layernorm(h->e_x, h->e_y, blob + h->e_lng, blob + h->e_lnb, h->e_nonpad, H, B, L, Ls, 1e-5f, st),
+           "final layer_norm");
+#undef ENC_OK
+    return DSD_OK;
+}
+
 int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, const float* f0, int32_t B, int32_t L,
                int32_t T, const dsd_encode_extras* ex, float* cond_out, void* stream) {
     if (!h || !txt_tokens || !mel2ph || !f0 || !cond_out) return fail(h, DSD_EINVAL, "dsd_encode: null argument");
@@ -1300,34 +1459,11 @@ int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, 
         if (lin_present(e, k) && !feats[k]) return fail(h, DSD_EINVAL, "dsd_encode: input for %s is missing", kLinNames[k]);
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(h, hipSetDevice(e.device));
-    const int H = e.hidden_size, NL = e.enc_layers, Ls = padded_ts(L);
-    // workspace for (B, L)
-    if (!h->e_arena || h->eB != B || h->eL != L) {
-        if (h->e_arena) (void)hipFree(h->e_arena);
-        h->e_arena = nullptr;
-        const size_t per = (size_t)B * Ls;
-        size_t off = kGuard;
-        auto take = [&](size_t n) {
-            size_t o = off;
-            off += (n + 63) / 64 * 64 + 64;
-            return o;
-        };
-        const size_t o_x = take(per * H), o_y = take(per * H), o_qkv = take(per * 3 * H), o_mid = take(per * 4 * H);
-        const size_t o_np = take(per), o_dur = take((size_t)B * L);
-        off += kGuard;
-        float* a = nullptr;
-        if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
-            return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the encoder workspace failed", off * 4);
-        if (hipMemset(a, 0, off * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(encoder workspace) failed");
-        h->e_arena = a;
-        h->eB = B; h->eL = L; h->eLs = Ls;
-        h->e_x = a + o_x; h->e_y = a + o_y; h->e_qkv = a + o_qkv; h->e_mid = a + o_mid; h->e_nonpad = a + o_np;
-        h->e_dur = reinterpret_cast<int*>(a + o_dur);
-    }
+    const int H = e.hidden_size, Ls = padded_ts(L);
+    int rc = enc_workspace(h, B, L, H, 0);
+    if (rc) return rc;
     const float* blob = h->blob;
-    const long xs = (long)H * Ls;
     hipError_t er;
-    int rc;
 #define ENC_OK(expr, what)                                                                        \
     if ((er = (expr)) != hipSuccess) return fail(h, DSD_EHIP, what " launch failed: %s", hipGetErrorString(er))
     // mel2ph_to_dur + forward_embedding  (acoustic_encoder.py:89-96, tts_modules.py:385-398)
@@ -1336,34 +1472,7 @@ int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, 
                             e.vocab_size, h->e_lang == SIZE_MAX ? nullptr : blob + h->e_lang, e.num_lang + 1,
                             blob + h->e_durw, blob + h->e_durb, sqrtf((float)H), H, B, L, Ls, h->e_x, h->e_nonpad, st),
            "embed");
-    for (int l = 0; l < NL; ++l) {      // EncSALayer.forward  (common_layers.py:236-268)
-        ENC_OK(launch_enc_layernorm(h->e_x, h->e_y, blob + h->e_ln1g[l], blob + h->e_ln1b[l], nullptr, H, B, L, Ls, 1e-5f, st),
-               "layer_norm1");
-        GemmCall q = make_gemm(h, h->g_qkv[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_ACT, 0);
-        q.p.act = ACT_NONE; q.p.out = h->e_qkv; q.p.o_bstride = 3 * xs; q.p.o_rstride = Ls;
-        if ((rc = run_gemm(h, q, st))) return rc;
-        ENC_OK(launch_enc_rope(h->e_qkv, blob + h->e_freqs, H, H / e.num_heads, B, L, Ls, st), "rope");
-        ENC_OK(launch_enc_attention(h->e_qkv, h->e_nonpad, h->e_y, H, e.num_heads, B, L, Ls, st), "attention");
-        GemmCall o = make_gemm(h, h->g_oproj[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_RES, 0);
-        o.p.aux = h->e_x; o.p.aux_bstride = xs; o.p.aux_rstride = Ls;
-        o.p.out = h->e_x; o.p.o_bstride = xs; o.p.o_rstride = Ls;
-        if ((rc = run_gemm(h, o, st))) return rc;
-        ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
-        ENC_OK(launch_enc_layernorm(h->e_x, h->e_y, blob + h->e_ln2g[l], blob + h->e_ln2b[l], nullptr, H, B, L, Ls, 1e-5f, st),
-               "layer_norm2");
-        // TransformerFFNLayer (common_layers.py:142-151): Conv1d(H, 4H, k) * k^-0.5 -> GELU -> Linear(4H, H)
-        GemmCall f1 = make_gemm(h, h->g_ffn1[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_ACT, 1, e.ffn_kernel_size > 1);
-        f1.p.act = ACT_GELU; f1.p.out = h->e_mid; f1.p.o_bstride = 4 * xs; f1.p.o_rstride = Ls;
-        if ((rc = run_gemm(h, f1, st))) return rc;
-        GemmCall f2 = make_gemm(h, h->g_ffn2[l], h->e_mid, 4 * xs, Ls, B, L, ST_PLAIN, EP_BIAS_RES, 0);
-        f2.p.aux = h->e_x; f2.p.aux_bstride = xs; f2.p.aux_rstride = Ls;
-        f2.p.out = h->e_x; f2.p.o_bstride = xs; f2.p.o_rstride = Ls;
-        if ((rc = run_gemm(h, f2, st))) return rc;
-        ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
-    }
-    // final LayerNorm * nonpadding  (tts_modules.py:424)
-    ENC_OK(launch_enc_layernorm(h->e_x, h->e_y, blob + h->e_lng, blob + h->e_lnb, h->e_nonpad, H, B, L, Ls, 1e-5f, st),
-           "final layer_norm");
+    if ((rc = run_fs2_layers(h, H, e.enc_layers, e.num_heads, e.ffn_kernel_size, B, L, st))) return rc;
     EncExpandArgs a;
     memset(&a, 0, sizeof(a));
     for (int k = 0; k < 7; ++k)
@@ -1382,6 +1491,152 @@ int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, 
     }
     ENC_OK(launch_enc_expand(h->e_y, (const long long*)mel2ph, a, H, B, L, Ls, T, cond_out, st), "expand");
 #undef ENC_OK
+    return DSD_OK;
+}
+
+int dsd_token_encoder_create(const dsd_token_encoder_config* cfg, dsd_handle** out) {
+    if (!cfg || !out) return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(dsd_token_encoder_config))
+        return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: struct_size %d != %zu", cfg->struct_size,
+                    sizeof(dsd_token_encoder_config));
+    if (cfg->enc_layers < 1 || cfg->num_heads < 1) return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: non-positive dimension");
+    if (cfg->hidden_size < 32 || cfg->hidden_size % 32 != 0 || cfg->hidden_size % (2 * cfg->num_heads) != 0)
+        return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: hidden_size must be a multiple of 32 and of 2 * num_heads");
+    if (cfg->hidden_size / cfg->num_heads > 256 || (cfg->hidden_size / cfg->num_heads) % 8 != 0)
+        return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: head dimension must be a multiple of 8, at most 256");
+    if (cfg->ffn_kernel_size < 1 || cfg->ffn_kernel_size % 2 == 0 || cfg->ffn_kernel_size > 15)
+        return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: enc_ffn_kernel_size must be odd and <= 15");
+    if (cfg->out_dims < 0 || cfg->dur_layers < 0) return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: negative size");
+    if (cfg->dur_layers > 0 && (cfg->dur_chans < 1 || cfg->dur_kernel_size < 1 || cfg->dur_kernel_size % 2 == 0 ||
+                                cfg->dur_kernel_size > 15))
+        return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: duration predictor needs channels >= 1 and an odd kernel size <= 15");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, DSD_EHIP, "dsd_token_encoder_create: no HIP device is visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: device %d out of range [0, %d)", cfg->device, ndev);
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_token_encoder_create: hipSetDevice failed");
+    hipError_t ie = gemm_init_all();
+    if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_token_encoder_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
+    dsd_handle* h = new dsd_handle();
+    memset(&h->cfg, 0, sizeof(h->cfg));
+    h->cfg.struct_size = sizeof(dsd_config);
+    h->cfg.backbone = DSD_ENC_FS2_TOKENS;
+    h->cfg.in_dims = cfg->hidden_size;
+    h->cfg.n_feats = 1;
+    h->cfg.num_layers = cfg->enc_layers;
+    h->cfg.num_channels = cfg->hidden_size;
+    h->cfg.hidden_size = cfg->hidden_size;
+    h->cfg.kernel_size = cfg->ffn_kernel_size;
+    h->cfg.device = cfg->device;
+    h->tcfg = *cfg;
+    *out = h;
+    return DSD_OK;
+}
+
+static int tok_common(dsd_handle* h, const char* who, const void* a, const void* b, const void* c, int B, int L) {
+    if (!h || !a || !b || !c) return fail(h, DSD_EINVAL, "%s: null argument", who);
+    if (!is_tok(h)) return fail(h, DSD_ESTATE, "%s: this handle is not a token encoder", who);
+    if (!h->finalized) return fail(h, DSD_ESTATE, "%s: weights are not finalized", who);
+    if (B < 1 || L < 1) return fail(h, DSD_EINVAL, "%s: B and L must be positive (%d, %d)", who, B, L);
+    if (L > 2048) return fail(h, DSD_EINVAL, "%s: L = %d tokens exceeds the supported 2048", who, L);
+    return DSD_OK;
+}
+
+int dsd_token_encode(dsd_handle* h, const float* embed, const uint8_t* padding_mask, int32_t B, int32_t L, float* enc_out,
+                     void* stream) {
+    int rc = tok_common(h, "dsd_token_encode", embed, padding_mask, enc_out, B, L);
+    if (rc) return rc;
+    const dsd_token_encoder_config& t = h->tcfg;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(h, hipSetDevice(t.device));
+    const int H = t.hidden_size;
+    if ((rc = enc_workspace(h, B, L, H, t.dur_layers > 0 ? t.dur_chans : 0))) return rc;
+    const int Ls = h->eLs;
+    hipError_t er;
+#define ENC_OK(expr, what)                                                                        \
+    if ((er = (expr)) != hipSuccess) return fail(h, DSD_EHIP, what " launch failed: %s", hipGetErrorString(er))
+    // x = (embed_scale * main + extra) * nonpadding  (tts_modules.py:401-412), [B, L, H] -> [B][H][Ls]
+    ENC_OK(launch_enc_nonpad(padding_mask, B, L, Ls, h->e_nonpad, st), "nonpad");
+    ENC_OK(launch_pack(embed, (long)L * H, 1, H, h->e_x, B, H, L, Ls, st), "pack(embed)");
+    ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
+    if ((rc = run_fs2_layers(h, H, t.enc_layers, t.num_heads, t.ffn_kernel_size, B, L, st))) return rc;
+    const float* res = h->e_y;
+    int Ho = H;
+    if (t.out_dims > 0) {      // MelodyEncoder.out_proj (variance_encoder.py:147)
+        GemmCall o = make_gemm(h, h->g_tout, h->e_y, (long)H * Ls, Ls, B, L, ST_PLAIN, EP_BIAS_ACT, 0);
+        o.p.act = ACT_NONE; o.p.out = h->e_mid; o.p.o_bstride = (long)t.out_dims * Ls; o.p.o_rstride = Ls;
+        if ((rc = run_gemm(h, o, st))) return rc;
+        res = h->e_mid;
+        Ho = t.out_dims;
+    }
+    ENC_OK(launch_unpack(res, Ls, enc_out, B, 1, Ho, L, 1, nullptr, nullptr, st), "unpack(enc_out)");
+#undef ENC_OK
+    return DSD_OK;
+}
+
+int dsd_predict_dur(dsd_handle* h, const float* dur_cond, const uint8_t* padding_mask, int32_t B, int32_t L, float* dur_out,
+                    void* stream) {
+    int rc = tok_common(h, "dsd_predict_dur", dur_cond, padding_mask, dur_out, B, L);
+    if (rc) return rc;
+    const dsd_token_encoder_config& t = h->tcfg;
+    if (t.dur_layers < 1) return fail(h, DSD_ESTATE, "dsd_predict_dur: this encoder was created without a duration predictor");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(h, hipSetDevice(t.device));
+    const int H = t.hidden_size, Cd = t.dur_chans;
+    if ((rc = enc_workspace(h, B, L, H, Cd))) return rc;
+    const int Ls = h->eLs;
+    const float* blob = h->blob;
+    hipError_t er;
+#define ENC_OK(expr, what)                                                                        \
+    if ((er = (expr)) != hipSuccess) return fail(h, DSD_EHIP, what " launch failed: %s", hipGetErrorString(er))
+    ENC_OK(launch_enc_nonpad(padding_mask, B, L, Ls, h->e_nonpad, st), "nonpad");
+    ENC_OK(launch_pack(dur_cond, (long)L * H, 1, H, h->d_in, B, H, L, Ls, st), "pack(dur_cond)");
+    const float* cur = h->d_in;
+    int cin = H;
+    for (int l = 0; l < t.dur_layers; ++l) {      // Conv1d -> ReLU -> LayerNorm(channels, eps 1e-12) -> * mask  (tts_modules.py:124-127)
+        GemmCall g = make_gemm(h, h->g_dconv[l], cur, (long)cin * Ls, Ls, B, L, ST_PLAIN, EP_BIAS_ACT, 1, t.dur_kernel_size > 1);
+        g.p.act = ACT_RELU; g.p.out = h->d_a; g.p.o_bstride = (long)Cd * Ls; g.p.o_rstride = Ls;
+        if ((rc = run_gemm(h, g, st))) return rc;
+        ENC_OK(launch_enc_layernorm(h->d_a, h->d_b, blob + h->d_lng[l], blob + h->d_lnb[l], h->e_nonpad, Cd, B, L, Ls, 1e-12f, st),
+               "dur layer_norm");
+        cur = h->d_b;
+        cin = Cd;
+    }
+    ENC_OK(launch_enc_dur_head(cur, blob + h->d_linw, blob + h->d_linb, h->e_nonpad, Cd, B, L, Ls, t.dur_offset, dur_out, st),
+           "dur head");
+#undef ENC_OK
+    return DSD_OK;
+}
+
+int dsd_cond_assemble(const dsd_assemble_args* args, float* out, void* stream) {
+    if (!args || !out) return fail(nullptr, DSD_EINVAL, "dsd_cond_assemble: null argument");
+    if (args->struct_size != (int32_t)sizeof(dsd_assemble_args))
+        return fail(nullptr, DSD_EINVAL, "dsd_cond_assemble: struct_size %d != %zu", args->struct_size, sizeof(dsd_assemble_args));
+    if (args->B < 1 || args->T < 1 || args->H < 1) return fail(nullptr, DSD_EINVAL, "dsd_cond_assemble: B, T and H must be positive");
+    if (args->n_gather < 0 || args->n_gather > DSD_ASSEMBLE_MAX_GATHER || args->n_terms < 0 || args->n_terms > DSD_ASSEMBLE_MAX_TERMS)
+        return fail(nullptr, DSD_EINVAL, "dsd_cond_assemble: at most %d gathers and %d terms", DSD_ASSEMBLE_MAX_GATHER, DSD_ASSEMBLE_MAX_TERMS);
+    AssembleArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = args->B; a.T = args->T; a.H = args->H; a.n_gather = args->n_gather; a.n_terms = args->n_terms;
+    for (int g = 0; g < a.n_gather; ++g) {
+        if (!args->gather[g].table || !args->gather[g].idx || args->gather[g].rows < 1)
+            return fail(nullptr, DSD_EINVAL, "dsd_cond_assemble: gather %d needs a table, an index and rows >= 1", g);
+        a.g_table[g] = args->gather[g].table; a.g_bstride[g] = args->gather[g].batch_stride; a.g_rows[g] = args->gather[g].rows;
+        a.g_idx[g] = (const long long*)args->gather[g].idx; a.g_off[g] = args->gather[g].idx_offset;
+        a.g_scale[g] = args->gather[g].scale; a.g_rowscale[g] = args->gather[g].row_scale;
+    }
+    for (int k = 0; k < a.n_terms; ++k) {
+        if (!args->term[k].v) return fail(nullptr, DSD_EINVAL, "dsd_cond_assemble: term %d has no vector", k);
+        a.t_s[k] = args->term[k].s; a.t_v[k] = args->term[k].v;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, DSD_EHIP, "dsd_cond_assemble: no HIP device is visible (this library has no CPU path)");
+    if (args->device < 0 || args->device >= ndev) return fail(nullptr, DSD_EINVAL, "dsd_cond_assemble: device %d out of range", args->device);
+    if (hipSetDevice(args->device) != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_cond_assemble: hipSetDevice failed");
+    hipError_t er = launch_assemble(a, out, (hipStream_t)stream);
+    if (er != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_cond_assemble: launch failed: %s", hipGetErrorString(er));
     return DSD_OK;
 }
 
@@ -1819,8 +2074,8 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
     const int64_t C = C_of(h), M = FM_of(h), L = L_of(h);
     out->weight_bytes = (int64_t)h->blob_floats * 4;
     out->workspace_bytes = (int64_t)h->arena_floats * 4;
-    if (is_enc(h)) {        // per TOKEN per encoder pass (attention excluded: it depends on the sequence length)
-        const int64_t H = h->ecfg.hidden_size, ks = h->ecfg.ffn_kernel_size, NL = h->ecfg.enc_layers;
+    if (is_enc(h) || is_tok(h)) {        // per TOKEN per encoder pass (attention excluded: it depends on the sequence length)
+        const int64_t H = h->cfg.hidden_size, ks = h->cfg.kernel_size, NL = h->cfg.num_layers;
         out->flops_per_frame_nfe = 2 * NL * (3 * H * H + H * H + ks * H * 4 * H + 4 * H * H);
         out->bytes_per_frame_nfe = 0;
         out->kernels_per_nfe = 3 + 11 * (int)NL + 2;

@@ -159,6 +159,20 @@ struct EncExpandArgs {
     long spk_mix_bstride, spk_mix_tstride;
     int num_spk;
 };
+struct AssembleArgs {             // dsd_cond_assemble, device view
+    int B, T, H, n_gather, n_terms;
+    const float* g_table[4];
+    long g_bstride[4], g_rows[4], g_off[4];
+    const long long* g_idx[4];
+    float g_scale[4];
+    const float* g_rowscale[4];
+    const float* t_s[16];
+    const float* t_v[16];
+};
+hipError_t launch_enc_nonpad(const unsigned char* pad, int B, int L, int Ls, float* nonpad, hipStream_t st);
+hipError_t launch_enc_dur_head(const float* x, const float* w, const float* bias, const float* nonpad, int C, int B, int L,
+                               int Ls, float offset, float* dur, hipStream_t st);
+hipError_t launch_assemble(const AssembleArgs& a, float* out, hipStream_t st);
 hipError_t launch_enc_dur(const long long* mel2ph, int B, int T, int L, int* dur, hipStream_t st);
 hipError_t launch_enc_embed(const long long* tokens, const long long* langs, const int* dur, const float* txt_embed,
                             int vocab, const float* lang_embed, int n_lang_rows, const float* dur_w, const float* dur_b,

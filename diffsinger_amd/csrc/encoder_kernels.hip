@@ -280,7 +280,66 @@ __global__ __launch_bounds__(256) void enc_expand_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Variance model glue (dsd_token_encode / dsd_predict_dur / dsd_cond_assemble).
+// ---------------------------------------------------------------------------------------------
+// nonpad[b][l] = !padding_mask[b][l]   (tts_modules.py:402: `1 - padding_mask.float()`)
+__global__ void enc_nonpad_kernel(const unsigned char* __restrict__ pad, int L, int Ls, float* __restrict__ nonpad) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (l < L) nonpad[(long)b * Ls + l] = pad[(long)b * L + l] ? 0.f : 1.f;
+}
+
+// DurationPredictor head (tts_modules.py:128-134): Linear(C, 1) over the channels, mask, exp - offset, clamp at 0.
+// Lanes run along the tokens; the channel loop reads x[b][c][l] coalesced.
+__global__ void enc_dur_head_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                    const float* __restrict__ nonpad, int C, int L, int Ls, float offset,
+                                    float* __restrict__ dur) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (l >= L) return;
+    const float* xb = x + (long)b * C * Ls + l;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc += xb[(long)c * Ls] * w[c];
+    const float v = (acc + bias[0]) * nonpad[(long)b * Ls + l];
+    dur[(long)b * L + l] = fmaxf(expf(v) - offset, 0.f);
+}
+
+// dsd_cond_assemble: out[b][t][:] = sum_g scale_g * rowscale_g[b,t] * table_g[b][idx_g[b,t] + offset_g][:] + sum_k s_k[b,t] * v_k[:]
+// One workgroup per (b, t) row, lanes along H: every table row and v_k is read contiguously.
+__global__ __launch_bounds__(256) void assemble_kernel(const AssembleArgs a, float* __restrict__ out) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const long bt = (long)b * a.T + t;
+    for (int h = threadIdx.x; h < a.H; h += blockDim.x) {
+        float acc = 0.f;
+        for (int g = 0; g < a.n_gather; ++g) {
+            const long row = (long)a.g_idx[g][bt] + a.g_off[g];
+            if (row < 0 || row >= a.g_rows[g]) continue;
+            float v = a.g_table[g][(long)b * a.g_bstride[g] + row * a.H + h] * a.g_scale[g];
+            if (a.g_rowscale[g]) v *= a.g_rowscale[g][bt];
+            acc += v;
+        }
+        for (int k = 0; k < a.n_terms; ++k) acc += (a.t_s[k] ? a.t_s[k][bt] : 1.f) * a.t_v[k][h];
+        out[bt * a.H + h] = acc;
+    }
+}
+
 // ------------------------------------------- launchers -------------------------------------------
+hipError_t launch_enc_nonpad(const unsigned char* pad, int B, int L, int Ls, float* nonpad, hipStream_t st) {
+    hipLaunchKernelGGL(enc_nonpad_kernel, dim3((L + 63) / 64, B), dim3(64), 0, st, pad, L, Ls, nonpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_enc_dur_head(const float* x, const float* w, const float* bias, const float* nonpad, int C, int B, int L,
+                               int Ls, float offset, float* dur, hipStream_t st) {
+    hipLaunchKernelGGL(enc_dur_head_kernel, dim3((L + 63) / 64, B), dim3(64), 0, st, x, w, bias, nonpad, C, L, Ls, offset, dur);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(const AssembleArgs& a, float* out, hipStream_t st) {
+    if (a.T > 2147483647 || a.B > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(assemble_kernel, dim3(a.T, a.B), dim3(a.H >= 256 ? 256 : 64), 0, st, a, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_enc_dur(const long long* mel2ph, int B, int T, int L, int* dur, hipStream_t st) {
     hipError_t e = hipMemsetAsync(dur, 0, sizeof(int) * (size_t)B * L, st);
     if (e != hipSuccess) return e;

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSD_API_VERSION 5
+#define DSD_API_VERSION 6
 
 /* error codes */
 #define DSD_OK 0
@@ -46,7 +46,10 @@ enum { DSD_BACKBONE_WAVENET = 0, DSD_BACKBONE_LYNXNET = 1,
        DSD_ENC_FS2_ACOUSTIC = 3,
        /* modules/nsf_hifigan/models.py:207  Generator (NSF-HiFiGAN vocoder: mel + f0 -> waveform; see dsd_vocode);
           created with dsd_vocoder_create */
-       DSD_VOC_NSF_HIFIGAN = 4 };
+       DSD_VOC_NSF_HIFIGAN = 4,
+       /* modules/fastspeech/tts_modules.py:353  FastSpeech2Encoder on caller-assembled embeddings (+ DurationPredictor /
+          out_proj): the encoders of the variance model; created with dsd_token_encoder_create */
+       DSD_ENC_FS2_TOKENS = 5 };
 /* modules/backbones/lynxnet.py:38-42  activation_classes */
 enum { DSD_ACT_PRELU = 0, DSD_ACT_SILU = 1, DSD_ACT_RELU = 2 };
 
@@ -181,6 +184,81 @@ int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out);
  */
 int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, const float* f0, int32_t B,
                int32_t T_txt, int32_t T, const dsd_encode_extras* extras, float* cond_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Variance model (modules/toplevel.py:125-309, BASELINE config 5): the pieces between the tokens and the pitch /
+ * multi-variance denoisers, which are ordinary dsd_create handles.
+ *
+ * A "token encoder" is the FastSpeech2Encoder (tts_modules.py:353-428, rotary configuration) on embeddings the caller
+ * assembled (dsd_cond_assemble below), with the two heads the variance model hangs on it:
+ *   - FastSpeech2Variance (variance_encoder.py:14-99): encoder + DurationPredictor (tts_modules.py:53-134)
+ *   - MelodyEncoder (variance_encoder.py:102-148): encoder + out_proj Linear(hidden, out_dims)
+ * Weights: `encoder.layers.N.op.*`, `encoder.layer_norm.*` as for dsd_encoder_create; `out_proj.{weight,bias}` when
+ * out_dims > 0; `dur_predictor.conv.N.1.{weight,bias}` (Conv1d), `dur_predictor.conv.N.3.{weight,bias}` (LayerNorm over
+ * channels, eps 1e-12) and `dur_predictor.linear.{weight,bias}` when dur_layers > 0.
+ */
+typedef struct dsd_token_encoder_config {
+    int32_t struct_size;      /* sizeof(dsd_token_encoder_config)                                     */
+    int32_t hidden_size;      /* hparams['hidden_size'] (melody encoder: melody_encoder_args.hidden_size) */
+    int32_t enc_layers;
+    int32_t num_heads;
+    int32_t ffn_kernel_size;  /* odd                                                                  */
+    int32_t out_dims;         /* MelodyEncoder.out_proj output size; 0 = no projection                */
+    int32_t dur_layers;       /* dur_prediction_args.num_layers; 0 = no duration predictor            */
+    int32_t dur_chans;        /* dur_prediction_args.hidden_size                                      */
+    int32_t dur_kernel_size;  /* dur_prediction_args.kernel_size (odd)                                */
+    float dur_offset;         /* dur_prediction_args.log_offset                                       */
+    int32_t device;
+} dsd_token_encoder_config;
+
+int dsd_token_encoder_create(const dsd_token_encoder_config* cfg, dsd_handle** out);
+/*
+ * Replaces: FastSpeech2Encoder.forward(main_embed, extra_embed, padding_mask) (tts_modules.py:400-428) [+ out_proj,
+ * variance_encoder.py:147].  embed [B, L, H] = embed_scale * main_embed + extra_embed (tts_modules.py:387-389; no additive
+ * positions in the rotary configuration), padding_mask [B, L] bytes (non-zero = padding), enc_out [B, L, H or out_dims].
+ */
+int dsd_token_encode(dsd_handle* h, const float* embed, const uint8_t* padding_mask, int32_t B, int32_t L,
+                     float* enc_out, void* stream);
+/*
+ * Replaces: DurationPredictor.forward(xs, x_masks, infer=True) (tts_modules.py:112-134): dur_cond [B, L, H] ->
+ * dur_out [B, L] = clamp(exp(linear(...)) - offset, min 0), zero at padding.
+ */
+int dsd_predict_dur(dsd_handle* h, const float* dur_cond, const uint8_t* padding_mask, int32_t B, int32_t L,
+                    float* dur_out, void* stream);
+
+/*
+ * Gather-and-add assembly of a [B, T, H] tensor: every embedding sum of the variance model
+ * (variance_encoder.py:70-96,137-146; toplevel.py:233-236,246-276,289-298) is an instance of
+ *   out[b,t,:] = sum_g scale_g * rowscale_g[b,t] * table_g[b*batch_stride_g + idx_g[b,t], :]
+ *              + sum_k s_k[b,t] * v_k[:]
+ * - an nn.Embedding lookup is a gather with batch_stride 0; `torch.gather(F.pad(x, [0,0,1,0]), 1, mel2ph)` is a gather
+ *   from x with idx - 1 (`idx_offset` = -1; a negative row reads as zeros);
+ * - Linear(1, H)(x) is the two terms (s = x, v = weight[:, 0]) and (s = 1, v = bias); s = NULL means 1.
+ * Terms are added in the order given (gathers first).  No handle: nothing here has weights of its own.
+ */
+#define DSD_ASSEMBLE_MAX_GATHER 4
+#define DSD_ASSEMBLE_MAX_TERMS 16
+typedef struct dsd_assemble_args {
+    int32_t struct_size;      /* sizeof(dsd_assemble_args) */
+    int32_t device;
+    int32_t B, T, H;
+    int32_t n_gather, n_terms;
+    struct {
+        const float* table;       /* [rows, H] (batch_stride 0) or [B, rows, H]                     */
+        int64_t batch_stride;     /* in elements                                                    */
+        int64_t rows;             /* rows per batch item; an index outside [0, rows) reads as zeros */
+        const int64_t* idx;       /* [B, T]                                                         */
+        int64_t idx_offset;       /* added to every index                                           */
+        float scale;
+        const float* row_scale;   /* [B, T] or NULL                                                 */
+    } gather[DSD_ASSEMBLE_MAX_GATHER];
+    struct {
+        const float* s;           /* [B, T] or NULL (= 1)                                           */
+        const float* v;           /* [H]                                                            */
+    } term[DSD_ASSEMBLE_MAX_TERMS];
+} dsd_assemble_args;
+
+int dsd_cond_assemble(const dsd_assemble_args* args, float* out, void* stream);
 
 /*
  * NSF-HiFiGAN generator (the step after the loop: mel -> waveform).  The constructor arguments are the fields of the
