@@ -86,3 +86,46 @@ for bsz, t_len in ((1, 1000), (4, 1000)):
     flops += 2 * 128 * 512 * 7 + rate * 2 * ch * 7
     print(f"vocoder B={bsz} T={t_len}: {dt*1e3:.2f} ms/pass  RTF {dt / (bsz * t_len * 512 / 44100):.5f}  "
           f"{flops * bsz * t_len / dt / 1e12:.1f} TFLOP/s", flush=True)
+
+# ---- variance model at the sizes of configs/variance.yaml: tokens -> durations, pitch, energy + breathiness
+import importlib.util
+spec = importlib.util.spec_from_file_location("variance_cases", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "variance_cases.py"))
+vc = importlib.util.module_from_spec(spec); spec.loader.exec_module(vc)
+from diffsinger_amd.variance import DiffSingerVariance
+hp = dict(vc.ENC_HP)
+hp.update(enc_layers=4, predict_dur=True, predict_pitch=True, predict_energy=True, predict_breathiness=True,
+          diffusion_type="reflow", sampling_algorithm="euler", sampling_steps=20, infer=True,
+          dur_prediction_args=dict(arch="fs2", hidden_size=512, dropout=0.1, num_layers=5, kernel_size=3, log_offset=1.0, loss_type="mse"),
+          pitch_prediction_args=dict(pitd_norm_min=-8.0, pitd_norm_max=8.0, pitd_clip_min=-12.0, pitd_clip_max=12.0, repeat_bins=64,
+                                     backbone_type="wavenet", backbone_args=dict(num_layers=20, num_channels=256, dilation_cycle_length=5)),
+          variances_prediction_args=dict(total_repeat_bins=48, backbone_type="wavenet",
+                                         backbone_args=dict(num_layers=10, num_channels=192, dilation_cycle_length=4)))
+hparams.clear(); hparams.update(hp)
+vm = DiffSingerVariance(60)
+shapes = vc.sorted_param_shapes(vm.named_parameters())
+vm.load_state_dict({k: torch.from_numpy(v) for k, v in vc.synth_weights(shapes, 9).items()}, strict=False)
+vm = vm.cuda().eval()
+for bsz, n_ph, t_len in ((1, 120, 1000), (8, 120, 1000)):
+    n_word = 40
+    tokens = (torch.arange(n_ph, device="cuda") % 59 + 1)[None].expand(bsz, n_ph).contiguous()
+    ph2word = (torch.arange(n_ph, device="cuda") // 3 + 1)[None].expand(bsz, n_ph).contiguous()
+    midi = torch.full((bsz, n_ph), 60, device="cuda", dtype=torch.long)
+    word_dur = torch.full((bsz, n_word), t_len // n_word, device="cuda", dtype=torch.long)
+    base_pitch = torch.full((bsz, t_len), 60.0, device="cuda")
+    call = lambda: vm(tokens, midi, ph2word, word_dur=word_dur, base_pitch=base_pitch, infer=True)
+    with torch.no_grad():
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        n = 20
+        t0 = time.perf_counter()
+        for _ in range(n):
+            call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        t1 = time.perf_counter()
+        for _ in range(n):
+            vm.fs2(tokens, midi=midi, ph2word=ph2word, word_dur=word_dur)
+        torch.cuda.synchronize()
+        dt_enc = (time.perf_counter() - t1) / n
+    print(f"variance model B={bsz} T_ph={n_ph} T={t_len}: {dt*1e3:.3f} ms per call (encoder + duration predictor {dt_enc*1e3:.3f} ms)", flush=True)
