@@ -18,6 +18,7 @@ the oracle and the HIP path are later fed.
 """
 from __future__ import annotations
 
+import copy
 import os
 import sys
 import types
@@ -720,6 +721,80 @@ def g12_variance_model():
 
 
 
+# --------------------------------------------------------------------------- G13: variance .ds harness (host-side wire format)
+def g13_variance_harness():
+    """The reference's own DiffSingerVarianceInfer (inference/ds_variance.py) - its real __init__, preprocess_input and
+    run_inference - on the synthetic project of tests/variance_cases.py, around a stand-in model (FakeVarianceModel) so
+    that no checkpoint is needed.  librosa is absent: its three functions the harness calls (note_to_midi, hz_to_midi,
+    midi_to_hz) are supplied from diffsinger_amd.variance_harness, so THOSE are not pinned by this fixture (known-answer
+    checks in tests/test_variance_harness.py); everything else is the reference's arithmetic."""
+    import contextlib
+    import io
+    import json
+    import pathlib
+    import shutil
+    import types
+    sys.path.insert(0, os.path.dirname(HERE))
+    import variance_cases as vc
+    from diffsinger_amd import variance_harness as vh
+    from diffsinger_amd.harness import SimplePhonemeTable
+    lib = sys.modules.get("librosa") or types.ModuleType("librosa")
+    lib.__path__ = []
+    lib.note_to_midi = lambda n, round_midi=True: vh.note_to_midi(n)
+    lib.hz_to_midi, lib.midi_to_hz = vh.hz_to_midi, vh.midi_to_hz
+    filt = types.ModuleType("librosa.filters")
+    filt.mel = lambda *a, **k: None
+    sys.modules["librosa"] = lib
+    sys.modules.setdefault("librosa.filters", filt)
+    import inference.ds_variance as dv  # (reference)
+    work = pathlib.Path(HERE) / "_g13_work"
+    work.mkdir(exist_ok=True)
+    try:
+        with open(work / "spk_map.json", "w") as f:
+            json.dump(vc.HARNESS_SPK, f)
+        set_hp(work_dir=str(work), **vc.HARNESS_HP)
+        dv.load_phoneme_dictionary = lambda: SimplePhonemeTable(vc.HARNESS_PHONES)
+        segs = vc.make_variance_segments()
+        with open(os.path.join(HERE, "g13_variance_segments.ds"), "w", encoding="utf8") as f:
+            json.dump(segs, f, indent=1)
+        out = {}
+        for mode, predictions in (("auto", set()), ("pitch_only", {"pitch"}), ("dur_energy", {"dur", "energy"})):
+            model = vc.FakeVarianceModel()
+
+            class Infer(dv.DiffSingerVarianceInfer):
+                def build_model(self, ckpt_steps=None):
+                    return model
+
+            infer = Infer(device="cpu", predictions=predictions)
+            recorded = []
+            orig = infer.preprocess_input
+
+            def spy(param, idx=0, load_dur=False, load_pitch=False, _orig=orig, _rec=recorded):
+                batch = _orig(param, idx=idx, load_dur=load_dur, load_pitch=load_pitch)
+                _rec.append((load_dur, load_pitch, batch))
+                return batch
+
+            infer.preprocess_input = spy
+            with contextlib.redirect_stdout(io.StringIO()):
+                infer.run_inference(copy.deepcopy(segs), out_dir=work, title=mode, num_runs=1, seed=11)
+            with open(work / f"{mode}.ds", encoding="utf8") as f:
+                done = json.load(f)
+            with open(os.path.join(HERE, f"g13_out_{mode}.ds"), "w", encoding="utf8") as f:
+                json.dump(done, f, indent=1)
+            out[f"{mode}_calls"] = np.array(json.dumps(model.calls))
+            for i, (ld, lp, batch) in enumerate(recorded):
+                out[f"{mode}_seg{i}_load"] = np.array([ld, lp])
+                for k, v in batch.items():
+                    if v is not None:
+                        out[f"{mode}_seg{i}_{k}"] = v.numpy()
+            print(f"  variance harness {mode}: {len(recorded)} segments, loads {[(a, b) for a, b, _ in recorded]}")
+        out["smooth_kernel"] = infer.smooth.weight.data.numpy().reshape(-1)
+        save("g13_variance_harness", **out)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+
 # --------------------------------------------------------------------------- G11: .ds harness (host-side wire format)
 def make_ds_segments():
     """A synthetic three-segment project in the .ds wire format (written next to the fixtures as g11_segments.ds)."""
@@ -802,7 +877,7 @@ def g11_harness():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -823,5 +898,7 @@ if __name__ == "__main__":
         g10_vocoder()
     if "g12" in which:
         g12_variance_model()
+    if "g13" in which:
+        g13_variance_harness()
     if "g11" in which:
         g11_harness()

@@ -153,3 +153,45 @@ def test_cond_assemble_matches_torch_and_rejects_bad_arguments():
     a = _lib.DsdAssembleArgs()
     assert _lib.lib().dsd_cond_assemble(a, None, None) != 0
     assert b"null argument" in _lib.lib().dsd_last_error(None)
+
+
+def test_ds_project_completed_on_gpu(tmp_path):
+    """`.ds` segments -> VarianceHarness -> DiffSingerVariance on the GPU -> completed `.ds`: durations, f0 and the two
+    variance curves are filled in for the segment that lacks them, given curves are kept, a fixed seed reproduces."""
+    import copy
+    from diffsinger_amd.harness import SimplePhonemeTable
+    from diffsinger_amd.variance import DiffSingerVariance
+    from diffsinger_amd.variance_harness import VarianceHarness
+    hp = vc.case_hparams("word_reflow")
+    hp.update(vc.HARNESS_HP, hidden_size=256, use_melody_encoder=True, num_spk=3, infer=True)
+    hparams.clear()
+    hparams.update(hp)
+    table = SimplePhonemeTable(vc.HARNESS_PHONES)
+    model = DiffSingerVariance(len(table))
+    shapes = vc.sorted_param_shapes(model.named_parameters())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in vc.synth_weights(shapes, 77).items()}, strict=False)
+    model = model.cuda().eval()
+    h = VarianceHarness(model, table, spk_map=vc.HARNESS_SPK, device="cuda")
+    segs = vc.make_variance_segments()
+    a = h.run_inference(copy.deepcopy(segs), out_dir=tmp_path, title="song", seed=5)[0]
+    b = h.run_inference(copy.deepcopy(segs), seed=5)[0]
+    assert a == b
+    assert (tmp_path / "song.ds").exists()
+    timestep = 512 / 44100
+    for src, done in zip(segs, a):
+        n_ph = len(src["ph_seq"].split())
+        frames = len(done["breathiness"].split())
+        assert len(done["ph_dur"].split()) == n_ph
+        assert frames == len(done["breathiness"].split())
+        if "ph_dur" not in src:     # predicted durations, rescaled word by word: never longer than the notes (a word whose
+            total = sum(float(v) for v in done["ph_dur"].split())        # phones were all predicted 0 keeps 0 frames)
+            assert 0 <= total <= (frames + 0.5 * n_ph) * timestep
+        for key in ("ph_dur", "f0_seq", "energy"):
+            if key in src:
+                assert done[key] == src[key]          # given curves are not overwritten
+        if "f0_seq" not in src:
+            f0 = np.array(done["f0_seq"].split(), float)
+            assert len(f0) == frames and np.isfinite(f0).all() and (f0 > 20).all() and (f0 < 5000).all()
+    for m in model.modules():
+        if hasattr(m, "release_native"):
+            m.release_native()

@@ -147,3 +147,107 @@ def synth_weights(shapes, seed):
         if name.endswith("dur_predictor.linear.bias"):
             sd[name] = (1.0 + w).astype(np.float32)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------ G13: variance .ds harness
+HARNESS_HP = dict(hop_size=512, audio_sample_rate=44100, midi_smooth_width=0.06, use_spk_id=True, use_lang_id=False,
+                  predict_dur=True, predict_pitch=True, use_glide_embed=True, glide_types=["up", "down"], hidden_size=16)
+HARNESS_SPK = {"alice": 0, "bob": 1, "carol": 2}
+HARNESS_PHONES = ["a", "b", "c", "d", "e"]
+
+
+def make_variance_segments():
+    """Four segments of a synthetic variance project: nothing given / durations given / durations and f0 given /
+    all-rest notes; static and curve-valued `expr` and speaker mixes; glides; a per-segment seed."""
+    rng = np.random.Generator(np.random.PCG64(1300))
+    notes = ["C4", "D#4", "rest", "F4+30", "Gb4", "A3-15", "rest", "B3", "C#5", "E4"]
+    segs = []
+    for i in range(4):
+        n_word = 5 + i
+        ph_num = rng.integers(1, 4, n_word)
+        n_ph = int(ph_num.sum())
+        phones = [HARNESS_PHONES[j] for j in rng.integers(0, 5, n_ph)]
+        slur = [0]
+        while sum(1 for s in slur if s == 0) < n_word:
+            slur.append(int(rng.random() < 0.25 and slur[-1] == 0))
+        if slur[-1] == 1 and sum(1 for s in slur if s == 0) > n_word:
+            slur = slur[:-1]
+        n_note = len(slur)
+        seq = ["rest"] * n_note if i == 3 else [notes[j] for j in rng.integers(0, len(notes), n_note)]
+        if i != 3 and all(n == "rest" for n in seq):
+            seq[0] = "C4"
+        note_dur = rng.uniform(0.12, 0.5, n_note).round(4)
+        seg = dict(offset=float(i), ph_seq=" ".join(phones), ph_num=" ".join(str(v) for v in ph_num),
+                   note_seq=" ".join(seq), note_dur=" ".join(str(v) for v in note_dur),
+                   note_slur=" ".join(str(s) for s in slur))
+        total = float(note_dur.sum())
+        if i in (1, 2):
+            w = rng.random(n_ph) + 0.2
+            seg["ph_dur"] = " ".join(str(v) for v in (w / w.sum() * total * (0.93 if i == 1 else 1.0)).round(5))
+        if i == 2:
+            f0 = 220.0 * 2.0 ** rng.uniform(-0.5, 0.5, 60)
+            f0[10:17] = 0.0
+            f0[-4:] = 0.0
+            seg["f0_seq"] = " ".join(str(v) for v in f0.round(1))
+            seg["f0_timestep"] = str(round(total / 59, 5))
+            seg["energy"] = " ".join(str(v) for v in rng.uniform(-50, -10, 30).round(2))
+            seg["energy_timestep"] = str(round(total / 29, 5))
+        if i == 0:
+            seg["expr"] = 0.8
+            seg["spk_mix"] = {"alice": 0.25, "bob": 0.75}
+            seg["ph_spk_mix"] = {"alice": 0.25, "bob": 0.75}
+            seg["seed"] = 77
+        elif i == 1:
+            seg["expr"] = " ".join(str(v) for v in rng.uniform(0, 1, 33).round(3))
+            seg["expr_timestep"] = str(round(total / 32, 5))
+            seg["note_glide"] = " ".join(["none", "up", "down", "wiggle"][j] for j in rng.integers(0, 4, n_note))
+            seg["spk_mix"] = {"alice": " ".join(str(v) for v in rng.uniform(0, 1, 25).round(3)), "carol": 0.5}
+            seg["spk_mix_timestep"] = str(round(total / 24, 5))
+            seg["ph_spk_mix"] = {"alice": " ".join(str(v) for v in rng.uniform(0.1, 1, n_ph).round(3)), "carol": 0.5}
+        else:
+            seg["spk_mix"] = {"bob": 1.0}
+            seg["ph_spk_mix"] = {"bob": 1.0}
+        segs.append(seg)
+    return segs
+
+
+class FakeVarianceModel:
+    """Stands in for DiffSingerVariance behind either harness: the predictor flags and tables the harness reads, and a
+    forward that returns simple deterministic functions of its inputs (so a harness's bookkeeping - which inputs it
+    passes, what it does with the outputs - shows up in the written project)."""
+
+    def __init__(self, variance_list=("energy", "breathiness")):
+        import types
+        import torch
+        self.predict_dur = self.predict_pitch = self.predict_variances = True
+        self.variance_prediction_list = list(variance_list)
+        self.fs2 = types.SimpleNamespace(predict_dur=True)
+        gen = torch.Generator().manual_seed(5)
+        self.spk_embed = torch.nn.Embedding(3, 16)
+        with torch.no_grad():
+            self.spk_embed.weight.copy_(torch.randn(3, 16, generator=gen))
+        self.calls = []
+
+    def __call__(self, txt_tokens, midi=None, ph2word=None, word_dur=None, ph_dur=None, mel2ph=None, base_pitch=None,
+                 pitch=None, pitch_expr=None, ph_spk_mix_embed=None, spk_mix_embed=None, infer=True, **kw):
+        import torch
+        self.calls.append(dict(ph_dur=ph_dur is not None, mel2ph=mel2ph is not None, pitch=pitch is not None,
+                               expr=None if pitch_expr is None else tuple(pitch_expr.shape),
+                               flags=(self.fs2.predict_dur, self.predict_pitch, self.predict_variances)))
+        t_len = base_pitch.shape[1]
+        mix = 0.0 if spk_mix_embed is None else float(spk_mix_embed.sum()) * 1e-3
+        dur = None
+        if self.fs2.predict_dur:
+            dur = 1.5 + 0.37 * midi.float() / 60.0 + 0.21 * torch.arange(txt_tokens.shape[1])[None]
+            if ph_spk_mix_embed is not None:
+                dur = dur + ph_spk_mix_embed.sum(-1).abs() * 0.1
+        ramp = torch.arange(t_len, dtype=torch.float32)[None]
+        pitch_pred = None
+        if self.predict_pitch:
+            pitch_pred = 0.3 * torch.sin(ramp / 5.0) + mix
+            if pitch_expr is not None:
+                pitch_pred = pitch_pred * pitch_expr
+        var = {}
+        if self.predict_variances:
+            var = {n: -20.0 - 0.013 * ramp * (k + 1) + mix for k, n in enumerate(self.variance_prediction_list)}
+        return dur, pitch_pred, var
