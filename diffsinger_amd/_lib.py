@@ -27,6 +27,7 @@ EXPORTS = [
     "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode", "dsd_vocoder_create", "dsd_vocode",
     "dsd_token_encoder_create", "dsd_token_encode", "dsd_predict_dur", "dsd_cond_assemble",
 ]
+POS_ROPE, POS_REL, POS_NONE = 0, 1, 2       # DSD_POS_*
 EMBED_FLAGS = {"energy": 1, "breathiness": 2, "voicing": 4, "tension": 8, "key_shift": 16, "speed": 32}
 
 
@@ -39,7 +40,8 @@ class DsdConfig(C.Structure):
 class DsdEncoderConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("vocab_size", C.c_int32), ("hidden_size", C.c_int32),
                 ("enc_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_kernel_size", C.c_int32),
-                ("num_spk", C.c_int32), ("num_lang", C.c_int32), ("embed_flags", C.c_uint32), ("device", C.c_int32)]
+                ("num_spk", C.c_int32), ("num_lang", C.c_int32), ("embed_flags", C.c_uint32), ("pos_mode", C.c_int32),
+                ("device", C.c_int32)]
 
 
 class DsdVocoderConfig(C.Structure):
@@ -54,7 +56,7 @@ class DsdVocoderConfig(C.Structure):
 class DsdTokenEncoderConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("hidden_size", C.c_int32), ("enc_layers", C.c_int32), ("num_heads", C.c_int32),
                 ("ffn_kernel_size", C.c_int32), ("out_dims", C.c_int32), ("dur_layers", C.c_int32), ("dur_chans", C.c_int32),
-                ("dur_kernel_size", C.c_int32), ("dur_offset", C.c_float), ("device", C.c_int32)]
+                ("dur_kernel_size", C.c_int32), ("dur_offset", C.c_float), ("pos_mode", C.c_int32), ("device", C.c_int32)]
 
 
 class _AssembleGather(C.Structure):
@@ -143,7 +145,7 @@ def _load():
     lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     for name in EXPORTS:
         getattr(lib, name)
-    if lib.dsd_api_version() != 6:
+    if lib.dsd_api_version() != 7:
         raise NativeLibraryError("libdsdenoise.so API version mismatch")
     return lib
 

@@ -86,7 +86,7 @@ struct dsd_handle {
     std::vector<size_t> e_ln1g, e_ln1b, e_ln2g, e_ln2b;
     size_t e_lng = 0, e_lnb = 0, e_txt = 0, e_lang = SIZE_MAX, e_durw = 0, e_durb = 0, e_freqs = 0, e_spk = SIZE_MAX;
     size_t e_linw[7], e_linb[7];                     // pitch, energy, breathiness, voicing, tension, key shift, speed
-    int eL = 0, eLs = 0, eB = 0;
+    int eL = 0, eLs = 0, eB = 0, e_pos = 0;
     float *e_x = nullptr, *e_y = nullptr, *e_qkv = nullptr, *e_mid = nullptr, *e_nonpad = nullptr;
     int* e_dur = nullptr;
     float* e_arena = nullptr;
@@ -223,15 +223,20 @@ inline bool lin_present(const dsd_encoder_config& e, int k) {
 
 // FastSpeech2Encoder state_dict (tts_modules.py:353-383; common_layers.py:120-234)
 void expected_fs2_layers(std::vector<std::pair<std::string, std::vector<int64_t>>>& v, int64_t H, int layers, int heads,
-                         int64_t ks) {
+                         int64_t ks, int pos_mode) {
     auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
+    if (pos_mode == DSD_POS_REL) add("encoder.embed_positions.div_term", {H / 2});
     for (int l = 0; l < layers; ++l) {
         const std::string p = "encoder.layers." + std::to_string(l) + ".op.";
         add(p + "layer_norm1.weight", {H});
         add(p + "layer_norm1.bias", {H});
-        add(p + "self_attn.in_proj.weight", {3 * H, H});
+        if (pos_mode == DSD_POS_ROPE) {
+            add(p + "self_attn.in_proj.weight", {3 * H, H});
+            add(p + "self_attn.rotary_embed.freqs", {H / heads / 2});
+        } else {      // torch.nn.MultiheadAttention(bias=False)  (common_layers.py:222-226)
+            add(p + "self_attn.in_proj_weight", {3 * H, H});
+        }
         add(p + "self_attn.out_proj.weight", {H, H});
-        add(p + "self_attn.rotary_embed.freqs", {H / heads / 2});
         add(p + "layer_norm2.weight", {H});
         add(p + "layer_norm2.bias", {H});
         add(p + "ffn.ffn_1.weight", {4 * H, H, ks});
@@ -249,7 +254,7 @@ std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_tok(co
     std::vector<std::pair<std::string, std::vector<int64_t>>> v;
     const int64_t H = t.hidden_size;
     auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
-    expected_fs2_layers(v, H, t.enc_layers, t.num_heads, t.ffn_kernel_size);
+    expected_fs2_layers(v, H, t.enc_layers, t.num_heads, t.ffn_kernel_size, t.pos_mode);
     if (t.out_dims > 0) {
         add("out_proj.weight", {t.out_dims, H});
         add("out_proj.bias", {t.out_dims});
@@ -277,7 +282,7 @@ std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_enc(co
     if (e.num_lang > 0) add("lang_embed.weight", {e.num_lang + 1, H});
     add("dur_embed.weight", {H, 1});
     add("dur_embed.bias", {H});
-    expected_fs2_layers(v, H, e.enc_layers, e.num_heads, ks);
+    expected_fs2_layers(v, H, e.enc_layers, e.num_heads, ks, e.pos_mode);
     for (int k = 0; k < 7; ++k)
         if (lin_present(e, k)) {
             add(std::string(kLinNames[k]) + ".weight", {H, 1});
@@ -482,7 +487,7 @@ size_t blob_copy_vec(dsd_handle* h, const std::string& name) {
     return off;
 }
 
-void pack_fs2_layers(dsd_handle* h, int H, int L, int ks);
+void pack_fs2_layers(dsd_handle* h, int H, int L, int ks, int pos_mode);
 
 int build_packed_enc(dsd_handle* h) {
     const dsd_encoder_config& e = h->ecfg;
@@ -501,7 +506,7 @@ int build_packed_enc(dsd_handle* h) {
             h->e_linb[k] = copy_vec(std::string(kLinNames[k]) + ".bias");
         }
     }
-    pack_fs2_layers(h, H, L, ks);
+    pack_fs2_layers(h, H, L, ks, e.pos_mode);
     return DSD_OK;
 }
 
@@ -510,7 +515,7 @@ int build_packed_tok(dsd_handle* h) {
     const dsd_token_encoder_config& t = h->tcfg;
     const int H = t.hidden_size;
     h->blob_host.clear();
-    pack_fs2_layers(h, H, t.enc_layers, t.ffn_kernel_size);
+    pack_fs2_layers(h, H, t.enc_layers, t.ffn_kernel_size, t.pos_mode);
     if (t.out_dims > 0) {
         const HostTensor* w = &W(h, "out_proj.weight");
         const HostTensor* b = &W(h, "out_proj.bias");
@@ -537,9 +542,12 @@ int build_packed_tok(dsd_handle* h) {
     return DSD_OK;
 }
 
-void pack_fs2_layers(dsd_handle* h, int H, int L, int ks) {
+void pack_fs2_layers(dsd_handle* h, int H, int L, int ks, int pos_mode) {
     auto copy_vec = [&](const std::string& name) { return blob_copy_vec(h, name); };
-    h->e_freqs = copy_vec("encoder.layers.0.op.self_attn.rotary_embed.freqs");     // one shared RotaryEmbedding
+    h->e_pos = pos_mode;
+    h->e_freqs = SIZE_MAX;
+    if (pos_mode == DSD_POS_ROPE) h->e_freqs = copy_vec("encoder.layers.0.op.self_attn.rotary_embed.freqs");     // one shared RotaryEmbedding
+    if (pos_mode == DSD_POS_REL) h->e_freqs = copy_vec("encoder.embed_positions.div_term");
     h->e_lng = copy_vec("encoder.layer_norm.weight");
     h->e_lnb = copy_vec("encoder.layer_norm.bias");
     h->g_qkv.resize(L); h->g_oproj.resize(L); h->g_ffn1.resize(L); h->g_ffn2.resize(L);
@@ -555,7 +563,8 @@ void pack_fs2_layers(dsd_handle* h, int H, int L, int ks) {
             const HostTensor* t = &W(h, name);
             return WGet([t, cols](int r, int k, int) { return (double)t->data[(size_t)r * cols + k]; });
         };
-        h->g_qkv[l] = pack_gemm(h, 3 * H, H, 1, 0, lin(p + "self_attn.in_proj.weight", H), nullptr);
+        h->g_qkv[l] = pack_gemm(h, 3 * H, H, 1, 0,
+                                lin(p + (pos_mode == DSD_POS_ROPE ? "self_attn.in_proj.weight" : "self_attn.in_proj_weight"), H), nullptr);
         h->g_oproj[l] = pack_gemm(h, H, H, 1, 0, lin(p + "self_attn.out_proj.weight", H), nullptr);
         const HostTensor* w1 = &W(h, p + "ffn.ffn_1.weight");
         const HostTensor* b1 = &W(h, p + "ffn.ffn_1.bias");
@@ -1345,6 +1354,7 @@ int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out) {
     if (cfg->ffn_kernel_size < 1 || cfg->ffn_kernel_size % 2 == 0 || cfg->ffn_kernel_size > 15)
         return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: enc_ffn_kernel_size must be odd and <= 15");
     if (cfg->num_spk < 0 || cfg->num_lang < 0) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: negative table size");
+    if (cfg->pos_mode < DSD_POS_ROPE || cfg->pos_mode > DSD_POS_NONE) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: pos_mode must be DSD_POS_ROPE, _REL or _NONE");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, DSD_EHIP, "dsd_encoder_create: no HIP device is visible (this library has no CPU path)");
@@ -1414,7 +1424,7 @@ static int run_fs2_layers(dsd_handle* h, int H, int NL, int heads, int ffn_ks, i
         GemmCall q = make_gemm(h, h->g_qkv[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_ACT, 0);
         q.p.act = ACT_NONE; q.p.out = h->e_qkv; q.p.o_bstride = 3 * xs; q.p.o_rstride = Ls;
         if ((rc = run_gemm(h, q, st))) return rc;
-        ENC_OK(launch_enc_rope(h->e_qkv, blob + h->e_freqs, H, H / heads, B, L, Ls, st), "rope");
+        if (h->e_pos == DSD_POS_ROPE) ENC_OK(launch_enc_rope(h->e_qkv, blob + h->e_freqs, H, H / heads, B, L, Ls, st), "rope");
         ENC_OK(launch_enc_attention(h->e_qkv, h->e_nonpad, h->e_y, H, heads, B, L, Ls, st), "attention");
         GemmCall o = make_gemm(h, h->g_oproj[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_RES, 0);
         o.p.aux = h->e_x; o.p.aux_bstride = xs; o.p.aux_rstride = Ls;
@@ -1472,6 +1482,10 @@ int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, 
                             e.vocab_size, h->e_lang == SIZE_MAX ? nullptr : blob + h->e_lang, e.num_lang + 1,
                             blob + h->e_durw, blob + h->e_durb, sqrtf((float)H), H, B, L, Ls, h->e_x, h->e_nonpad, st),
            "embed");
+    if (e.pos_mode == DSD_POS_REL) {      // x * sqrt(H) + positions, then the padding mask again  (tts_modules.py:390-392,412)
+        ENC_OK(launch_enc_relpos(h->e_x, blob + h->e_freqs, H, B, L, Ls, st), "relpos");
+        ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
+    }
     if ((rc = run_fs2_layers(h, H, e.enc_layers, e.num_heads, e.ffn_kernel_size, B, L, st))) return rc;
     EncExpandArgs a;
     memset(&a, 0, sizeof(a));
@@ -1507,6 +1521,8 @@ int dsd_token_encoder_create(const dsd_token_encoder_config* cfg, dsd_handle** o
     if (cfg->ffn_kernel_size < 1 || cfg->ffn_kernel_size % 2 == 0 || cfg->ffn_kernel_size > 15)
         return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: enc_ffn_kernel_size must be odd and <= 15");
     if (cfg->out_dims < 0 || cfg->dur_layers < 0) return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: negative size");
+    if (cfg->out_dims > 4 * cfg->hidden_size) return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: out_dims above 4 * hidden_size is not supported");
+    if (cfg->pos_mode < DSD_POS_ROPE || cfg->pos_mode > DSD_POS_NONE) return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: pos_mode must be DSD_POS_ROPE, _REL or _NONE");
     if (cfg->dur_layers > 0 && (cfg->dur_chans < 1 || cfg->dur_kernel_size < 1 || cfg->dur_kernel_size % 2 == 0 ||
                                 cfg->dur_kernel_size > 15))
         return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: duration predictor needs channels >= 1 and an odd kernel size <= 15");
@@ -1559,6 +1575,7 @@ int dsd_token_encode(dsd_handle* h, const float* embed, const uint8_t* padding_m
     // x = (embed_scale * main + extra) * nonpadding  (tts_modules.py:401-412), [B, L, H] -> [B][H][Ls]
     ENC_OK(launch_enc_nonpad(padding_mask, B, L, Ls, h->e_nonpad, st), "nonpad");
     ENC_OK(launch_pack(embed, (long)L * H, 1, H, h->e_x, B, H, L, Ls, st), "pack(embed)");
+    if (t.pos_mode == DSD_POS_REL) ENC_OK(launch_enc_relpos(h->e_x, h->blob + h->e_freqs, H, B, L, Ls, st), "relpos");
     ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
     if ((rc = run_fs2_layers(h, H, t.enc_layers, t.num_heads, t.ffn_kernel_size, B, L, st))) return rc;
     const float* res = h->e_y;

@@ -322,7 +322,24 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AssembleArgs a, flo
     }
 }
 
+// RelPositionalEncoding.forward (espnet_positional_embedding.py:102-113) on x[b][c][l]:
+//   x = x * sqrt(H) + pe[l][c],  pe[l][2i] = sin((max_len - 1 - l) * div[i]),  pe[l][2i + 1] = cos(same)
+// (the table is built once for max_len = 5000 with reversed positions and sliced from the front).
+__global__ void enc_relpos_kernel(float* __restrict__ x, const float* __restrict__ div, int C, int L, int Ls, float xscale,
+                                  float last_pos) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (l >= L) return;
+    const float ang = (last_pos - (float)l) * div[c >> 1];
+    float* p = x + ((long)b * C + c) * Ls + l;
+    *p = *p * xscale + ((c & 1) ? cosf(ang) : sinf(ang));
+}
+
 // ------------------------------------------- launchers -------------------------------------------
+hipError_t launch_enc_relpos(float* x, const float* div, int C, int B, int L, int Ls, hipStream_t st) {
+    hipLaunchKernelGGL(enc_relpos_kernel, dim3((L + 63) / 64, C, B), dim3(64), 0, st, x, div, C, L, Ls, sqrtf((float)C), 4999.f);
+    return hipGetLastError();
+}
+
 hipError_t launch_enc_nonpad(const unsigned char* pad, int B, int L, int Ls, float* nonpad, hipStream_t st) {
     hipLaunchKernelGGL(enc_nonpad_kernel, dim3((L + 63) / 64, B), dim3(64), 0, st, pad, L, Ls, nonpad);
     return hipGetLastError();

@@ -6,11 +6,14 @@ parameters in ordinary torch modules under the reference's names - `txt_embed.we
 ffn.ffn_1, ffn.ffn_2}.*`, `encoder.layer_norm.*`, `pitch_embed.*`, ... - so the `fs2.` slice of an acoustic
 checkpoint loads with strict=True, and runs `forward(txt_tokens, mel2ph, f0, ...) -> condition [B, T, H]` ONLY on
 the HIP library (`dsd_encode`).  Supported: the reference fork's configuration (`use_pos_embed: true`,
-`use_rope: true`, `ffn_act: gelu`); other positional-embedding variants raise NotImplementedError at construction.
+`use_rope: true`, `ffn_act: gelu`) and the two pre-rotary layouts - `use_rope: false` with `rel_pos: true`
+(RelPositionalEncoding + torch.nn.MultiheadAttention parameter names) or `use_pos_embed: false`; the fairseq-style
+SinusoidalPositionalEmbedding (`rel_pos: false`) raises NotImplementedError at construction.
 """
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import torch
 import torch.nn as nn
@@ -40,6 +43,35 @@ class _SelfAttn(nn.Module):
         self.rotary_embed = rotary
 
 
+class _SelfAttnPlain(nn.Module):
+    """Parameter names of torch.nn.MultiheadAttention(h, heads, bias=False) (common_layers.py:222-226)."""
+
+    def __init__(self, h):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * h, h))
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        self.out_proj = nn.Linear(h, h, bias=False)
+
+
+def pos_mode_of(get):
+    """DSD_POS_* from `use_pos_embed` / `use_rope` / `rel_pos` as FastSpeech2Encoder.__init__ reads them
+    (tts_modules.py:362-364,378-384)."""
+    use_pos = get('use_pos_embed') if get('use_pos_embed') is not None else True
+    if use_pos and get('use_rope'):
+        return _lib.POS_ROPE
+    if not use_pos:
+        return _lib.POS_NONE
+    if get('rel_pos'):
+        return _lib.POS_REL
+    raise NotImplementedError("use_pos_embed: true with rel_pos: false and use_rope: false (SinusoidalPositionalEmbedding, "
+                              "tts_modules.py:383-385) is not implemented on the HIP path")
+
+
+def rel_pos_div_term(h):
+    """RelPositionalEncoding's frequency table, with the reference's own torch ops (espnet_positional_embedding.py:38-41)."""
+    return torch.exp(torch.arange(0, h, 2, dtype=torch.float32) * -(math.log(10000.0) / h))
+
+
 class _FFN(nn.Module):
     def __init__(self, h, ks):
         super().__init__()
@@ -51,7 +83,7 @@ class _EncSALayer(nn.Module):
     def __init__(self, h, ks, rotary):
         super().__init__()
         self.layer_norm1 = nn.LayerNorm(h)
-        self.self_attn = _SelfAttn(h, rotary)
+        self.self_attn = _SelfAttn(h, rotary) if rotary is not None else _SelfAttnPlain(h)
         self.layer_norm2 = nn.LayerNorm(h)
         self.ffn = _FFN(h, ks)
 
@@ -65,9 +97,9 @@ class _Layer(nn.Module):
 class _Encoder(nn.Module):
     """Parameter holder with the names of FastSpeech2Encoder (tts_modules.py:353-383); never called."""
 
-    def __init__(self, h, layers, heads, ks):
+    def __init__(self, h, layers, heads, ks, pos_mode=0):
         super().__init__()
-        rotary = _Rotary(h // heads)
+        rotary = _Rotary(h // heads) if pos_mode == _lib.POS_ROPE else None
         self.layers = nn.ModuleList([_Layer(h, ks, rotary) for _ in range(layers)])
         self.layer_norm = nn.LayerNorm(h)
 
@@ -76,10 +108,7 @@ class FastSpeech2Acoustic(_NativeBackbone):
     def __init__(self, vocab_size):
         super().__init__()
         hp = hparams
-        if not (hp.get('use_pos_embed', True) and hp.get('use_rope', False)):
-            raise NotImplementedError(
-                "diffsinger_amd.FastSpeech2Acoustic implements the rotary-embedding encoder (use_pos_embed: true, "
-                "use_rope: true - configs/acoustic.yaml:66); other positional embeddings stay on the reference")
+        self.pos_mode = pos_mode_of(hp.get)
         if hp.get('ffn_act', 'gelu') != 'gelu':
             raise NotImplementedError(f"ffn_act={hp.get('ffn_act')!r}: only 'gelu' (configs/base.yaml:32) runs on the HIP path")
         h = self._hidden = hp['hidden_size']
@@ -91,7 +120,7 @@ class FastSpeech2Acoustic(_NativeBackbone):
         if self.use_lang_id:
             self.lang_embed = nn.Embedding(hp['num_lang'] + 1, h, padding_idx=0)
         self.dur_embed = nn.Linear(1, h)
-        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size)
+        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size, self.pos_mode)
         self.pitch_embed = nn.Linear(1, h)
         self.variance_embed_list = [v for v in VARIANCE_ORDER if hp.get(f'use_{v}_embed', False)]
         self.use_variance_embeds = len(self.variance_embed_list) > 0
@@ -115,7 +144,10 @@ class FastSpeech2Acoustic(_NativeBackbone):
         flags |= _lib.EMBED_FLAGS["speed"] if self.use_speed_embed else 0
         return _lib.DsdEncoderConfig(C.sizeof(_lib.DsdEncoderConfig), self.vocab_size, self._hidden, self.enc_layers,
                                      self.num_heads, self.ffn_kernel_size, self.num_spk, self.num_lang, flags,
-                                     device_index)
+                                     self.pos_mode, device_index)
+
+    def _extra_weights(self):
+        return {"encoder.embed_positions.div_term": rel_pos_div_term(self._hidden)} if self.pos_mode == _lib.POS_REL else {}
 
     def prepare_cond(self, cond, layout="BHT"):
         raise RuntimeError("FastSpeech2Acoustic produces the condition; call forward(txt_tokens, mel2ph, f0, ...)")

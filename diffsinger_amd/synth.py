@@ -103,10 +103,11 @@ def convnext_param_shapes(in_dims, out_dims, num_channels=512, num_layers=6, ker
 
 
 def fs2_acoustic_param_shapes(vocab_size, hidden_size=256, enc_layers=4, num_heads=2, ffn_kernel_size=3,
-                              num_spk=0, num_lang=0, variances=(), key_shift=False, speed=False):
+                              num_spk=0, num_lang=0, variances=(), key_shift=False, speed=False, rope=True):
     """state_dict of modules/fastspeech/acoustic_encoder.py:14-63 (FastSpeech2Acoustic) in its rotary-embedding
     configuration (`use_rope: true`): tts_modules.py:353-383, common_layers.py:120-234.  The rotary frequency
-    table is an (untrained) nn.Parameter of the shared RotaryEmbedding and shows up once per layer."""
+    table is an (untrained) nn.Parameter of the shared RotaryEmbedding and shows up once per layer.  `rope=False`:
+    the pre-rotary layout, torch.nn.MultiheadAttention(bias=False) (common_layers.py:222-226)."""
     h = hidden_size
     shapes = OrderedDict()
     shapes["txt_embed.weight"] = (vocab_size, h)
@@ -118,9 +119,13 @@ def fs2_acoustic_param_shapes(vocab_size, hidden_size=256, enc_layers=4, num_hea
         p = f"encoder.layers.{l}.op."
         shapes[p + "layer_norm1.weight"] = (h,)
         shapes[p + "layer_norm1.bias"] = (h,)
-        shapes[p + "self_attn.in_proj.weight"] = (3 * h, h)
-        shapes[p + "self_attn.out_proj.weight"] = (h, h)
-        shapes[p + "self_attn.rotary_embed.freqs"] = (h // num_heads // 2,)
+        if rope:
+            shapes[p + "self_attn.in_proj.weight"] = (3 * h, h)
+            shapes[p + "self_attn.out_proj.weight"] = (h, h)
+            shapes[p + "self_attn.rotary_embed.freqs"] = (h // num_heads // 2,)
+        else:
+            shapes[p + "self_attn.in_proj_weight"] = (3 * h, h)
+            shapes[p + "self_attn.out_proj.weight"] = (h, h)
         shapes[p + "layer_norm2.weight"] = (h,)
         shapes[p + "layer_norm2.bias"] = (h,)
         shapes[p + "ffn.ffn_1.weight"] = (4 * h, h, ffn_kernel_size)

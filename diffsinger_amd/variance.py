@@ -7,7 +7,8 @@ delta_pitch_embed`, `pitch_retake_embed`, `pitch_predictor.*`, `pitch_embed`, `v
 library: the FastSpeech2Encoder stacks and the DurationPredictor (`dsd_token_encode`, `dsd_predict_dur`), every
 embedding sum (`dsd_cond_assemble`), and the pitch / multi-variance denoisers (diffusion.py).  What stays in torch is
 integer bookkeeping on [B, T_ph]-sized tensors: word onsets, the rhythm and length regulators.
-Rotary-embedding configuration only (`use_rope: true`, configs/variance.yaml:38); inference only; no CPU path.
+Encoders: the rotary configuration (`use_rope: true`, configs/variance.yaml:38) and the two pre-rotary ones (`use_rope:
+false` with `rel_pos: true`, or `use_pos_embed: false`); inference only; no CPU path.
 """
 from __future__ import annotations
 
@@ -22,7 +23,7 @@ import torch.nn.functional as F
 from . import _lib
 from .backbones import _NativeBackbone
 from .diffusion import (MultiVarianceDiffusion, MultiVarianceRectifiedFlow, PitchDiffusion, PitchRectifiedFlow)
-from .encoder import PAD_INDEX, _Encoder
+from .encoder import PAD_INDEX, _Encoder, pos_mode_of, rel_pos_div_term
 from .harness import length_regulator
 from .hparams import hparams
 from .toplevel import get_backbone_args
@@ -96,11 +97,10 @@ def _check_infer(module):
 
 
 def _check_encoder_hparams(get):
-    if not (get('use_pos_embed') and get('use_rope')):
-        raise NotImplementedError("the HIP path implements the rotary-embedding encoder (use_pos_embed: true, use_rope: true "
-                                  "- configs/variance.yaml:38); other positional embeddings stay on the reference")
+    """-> DSD_POS_*; raises for what the HIP path does not implement."""
     if (get('ffn_act') or 'gelu') != 'gelu':
         raise NotImplementedError(f"ffn_act={get('ffn_act')!r}: only 'gelu' (configs/base.yaml:32) runs on the HIP path")
+    return pos_mode_of(get)
 
 
 class _TokenEncoderBase(_NativeBackbone):
@@ -109,6 +109,9 @@ class _TokenEncoderBase(_NativeBackbone):
 
     def _native_state(self):
         return {k: v for k, v in self.state_dict().items() if k.startswith(self._native_prefixes)}
+
+    def _extra_weights(self):
+        return {"encoder.embed_positions.div_term": rel_pos_div_term(self._hidden)} if self.pos_mode == _lib.POS_REL else {}
 
     def prepare_cond(self, cond, layout="BHT"):
         raise RuntimeError(f"{type(self).__name__} is an encoder; call forward(...)")
@@ -150,7 +153,7 @@ class FastSpeech2Variance(_TokenEncoderBase):
     def __init__(self, vocab_size):
         super().__init__()
         hp = hparams
-        _check_encoder_hparams(lambda k: hp.get(k, {'use_pos_embed': True, 'use_rope': False}.get(k)))
+        self.pos_mode = _check_encoder_hparams(hp.get)
         h = self._hidden = hp['hidden_size']
         self.predict_dur = hp['predict_dur']
         self.linguistic_mode = 'word' if self.predict_dur else 'phoneme'
@@ -164,7 +167,7 @@ class FastSpeech2Variance(_TokenEncoderBase):
             self.word_dur_embed = nn.Linear(1, h)
         else:
             self.ph_dur_embed = nn.Linear(1, h)
-        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size)
+        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size, self.pos_mode)
         if self.predict_dur:
             d = hp['dur_prediction_args']
             self.midi_embed = nn.Embedding(128, h)
@@ -176,7 +179,7 @@ class FastSpeech2Variance(_TokenEncoderBase):
         d = self.dur_predictor if self.predict_dur else None
         return _lib.DsdTokenEncoderConfig(C.sizeof(_lib.DsdTokenEncoderConfig), self._hidden, self.enc_layers, self.num_heads,
                                           self.ffn_kernel_size, 0, d.n_layers if d else 0, d.n_chans if d else 0,
-                                          d.kernel_size if d else 0, float(d.offset) if d else 0.0, device_index)
+                                          d.kernel_size if d else 0, float(d.offset) if d else 0.0, self.pos_mode, device_index)
 
     def forward(self, txt_tokens, midi, ph2word, ph_dur=None, word_dur=None, spk_embed=None, languages=None, infer=True):
         """-> encoder_out [B, T_ph, H], ph_dur_pred [B, T_ph] or None (variance_encoder.py:52-99)."""
@@ -228,7 +231,7 @@ class MelodyEncoder(_TokenEncoderBase):
         def get(key):
             return enc_hparams.get(key, hparams.get(key))
 
-        _check_encoder_hparams(get)
+        self.pos_mode = _check_encoder_hparams(get)
         h = self._hidden = get('hidden_size')
         self.enc_layers, self.num_heads, self.ffn_kernel_size = get('enc_layers'), get('num_heads'), get('enc_ffn_kernel_size')
         self.note_midi_embed = nn.Linear(1, h)
@@ -237,13 +240,13 @@ class MelodyEncoder(_TokenEncoderBase):
         self.glide_embed_scale = hparams['glide_embed_scale']
         if self.use_glide_embed:
             self.note_glide_embed = nn.Embedding(len(hparams['glide_types']) + 1, h, padding_idx=0)      # 0: none, 1: up, 2: down
-        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size)
+        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size, self.pos_mode)
         self.out_dims = hparams['hidden_size']
         self.out_proj = nn.Linear(h, self.out_dims)
 
     def _config(self, device_index):
         return _lib.DsdTokenEncoderConfig(C.sizeof(_lib.DsdTokenEncoderConfig), self._hidden, self.enc_layers, self.num_heads,
-                                          self.ffn_kernel_size, self.out_dims, 0, 0, 0, 0.0, device_index)
+                                          self.ffn_kernel_size, self.out_dims, 0, 0, 0, 0.0, self.pos_mode, device_index)
 
     def forward(self, note_midi, note_rest, note_dur, glide=None):
         """note_midi float [B, T_n] (-1: padding), note_rest bool, note_dur int64, glide int64 -> [B, T_n, H]."""

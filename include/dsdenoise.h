@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSD_API_VERSION 6
+#define DSD_API_VERSION 7
 
 /* error codes */
 #define DSD_OK 0
@@ -149,6 +149,14 @@ int dsd_aux_decode(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64
 #define DSD_EMBED_KEY_SHIFT 16u
 #define DSD_EMBED_SPEED 32u
 
+/* Positional information of a FastSpeech2Encoder (tts_modules.py:362-364,378-384,390-395) */
+enum { DSD_POS_ROPE = 0,   /* use_pos_embed && use_rope: rotary embedding inside the attention (MultiheadSelfAttentionWithRoPE) */
+       DSD_POS_REL = 1,    /* use_pos_embed && !use_rope && rel_pos: x * sqrt(H) + RelPositionalEncoding table
+                              (espnet_positional_embedding.py:26-47,98-113), torch.nn.MultiheadAttention(bias=False);
+                              weights `...self_attn.in_proj_weight` instead of `in_proj.weight` + `rotary_embed.freqs`, plus
+                              `encoder.embed_positions.div_term` [H/2] = exp(arange(0, H, 2) * -(ln 10000 / H)) */
+       DSD_POS_NONE = 2 }; /* !use_pos_embed: no positions; attention and weight names as DSD_POS_REL */
+
 typedef struct dsd_encoder_config {
     int32_t struct_size;      /* sizeof(dsd_encoder_config)                                          */
     int32_t vocab_size;       /* FastSpeech2Acoustic(vocab_size)                                     */
@@ -159,6 +167,7 @@ typedef struct dsd_encoder_config {
     int32_t num_spk;          /* hparams['num_spk'] if use_spk_id else 0                             */
     int32_t num_lang;         /* hparams['num_lang'] if use_lang_id else 0 (table has num_lang + 1 rows) */
     uint32_t embed_flags;     /* DSD_EMBED_*: use_energy_embed ... use_speed_embed                   */
+    int32_t pos_mode;         /* DSD_POS_*                                                           */
     int32_t device;
 } dsd_encoder_config;
 
@@ -208,6 +217,7 @@ typedef struct dsd_token_encoder_config {
     int32_t dur_chans;        /* dur_prediction_args.hidden_size                                      */
     int32_t dur_kernel_size;  /* dur_prediction_args.kernel_size (odd)                                */
     float dur_offset;         /* dur_prediction_args.log_offset                                       */
+    int32_t pos_mode;         /* DSD_POS_*                                                            */
     int32_t device;
 } dsd_token_encoder_config;
 
@@ -215,7 +225,7 @@ int dsd_token_encoder_create(const dsd_token_encoder_config* cfg, dsd_handle** o
 /*
  * Replaces: FastSpeech2Encoder.forward(main_embed, extra_embed, padding_mask) (tts_modules.py:400-428) [+ out_proj,
  * variance_encoder.py:147].  embed [B, L, H] = embed_scale * main_embed + extra_embed (tts_modules.py:387-389; no additive
- * positions in the rotary configuration), padding_mask [B, L] bytes (non-zero = padding), enc_out [B, L, H or out_dims].
+ * positions in the rotary configuration; DSD_POS_REL adds them inside), padding_mask [B, L] bytes (non-zero = padding), enc_out [B, L, H or out_dims].
  */
 int dsd_token_encode(dsd_handle* h, const float* embed, const uint8_t* padding_mask, int32_t B, int32_t L,
                      float* enc_out, void* stream);

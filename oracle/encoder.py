@@ -46,14 +46,28 @@ def rope(t, freqs):
     return (t * np.cos(ang).astype(F32) + rot * np.sin(ang).astype(F32)).astype(F32)
 
 
+def rel_positional_encoding(seq, dim, max_len=5000):
+    """RelPositionalEncoding's table as the encoder uses it (espnet_positional_embedding.py:26-47,98-113): built once
+    for max_len with REVERSED positions (max_len-1 ... 0), sin/cos interleaved, then sliced from the front."""
+    pos = np.arange(max_len - 1, -1, -1.0, dtype=F32)[:seq, None]
+    div = np.exp(np.arange(0, dim, 2, dtype=F32) * F32(-(np.log(10000.0) / dim))).astype(F32)
+    ang = (pos * div).astype(F32)
+    return np.stack([np.sin(ang), np.cos(ang)], axis=2).reshape(seq, dim).astype(F32)
+
+
 def self_attention_rope(x, p, pre, num_heads, pad_mask, freqs=None):
+    """MultiheadSelfAttentionWithRoPE (common_layers.py:171-213); without a rotary table - `in_proj_weight` present -
+    torch.nn.MultiheadAttention(bias=False) as EncSALayer calls it (common_layers.py:222-226,247-254): the same
+    arithmetic minus the rotation."""
     bsz, seq, dim = x.shape
     hd = dim // num_heads
-    qkv = (x @ p[pre + "in_proj.weight"].T).astype(F32)
+    plain = pre + "in_proj_weight" in p
+    qkv = (x @ p[pre + ("in_proj_weight" if plain else "in_proj.weight")].T).astype(F32)
     q, k, v = (qkv[..., i * dim:(i + 1) * dim].reshape(bsz, seq, num_heads, hd).transpose(0, 2, 1, 3) for i in range(3))
-    if freqs is None:
-        freqs = p[pre + "rotary_embed.freqs"]
-    q, k = rope(q, freqs), rope(k, freqs)
+    if not plain:
+        if freqs is None:
+            freqs = p[pre + "rotary_embed.freqs"]
+        q, k = rope(q, freqs), rope(k, freqs)
     scores = (np.matmul(q, k.transpose(0, 1, 3, 2)) / F32(np.sqrt(hd))).astype(F32)
     scores = np.where(pad_mask[:, None, None, :], F32(-np.inf), scores)
     scores = scores - scores.max(axis=-1, keepdims=True)
@@ -78,10 +92,13 @@ def ffn(x, p, pre):
     return (y @ p[pre + "ffn_2.weight"].T + p[pre + "ffn_2.bias"]).astype(F32)
 
 
-def fs2_encoder(p, main_embed, extra_embed, pad_mask, num_heads, prefix="encoder."):
+def fs2_encoder(p, main_embed, extra_embed, pad_mask, num_heads, prefix="encoder.", pos="rope"):
+    """pos: 'rope' (rotation inside the attention), 'rel' (use_rope false, rel_pos true: x * sqrt(H) + table), 'none'."""
     hidden = main_embed.shape[-1]
     nonpad = (1.0 - pad_mask.astype(F32))[:, :, None]
     x = (F32(np.sqrt(hidden)) * main_embed + extra_embed).astype(F32)
+    if pos == "rel":                                     # tts_modules.py:390-392
+        x = (x * F32(np.sqrt(hidden)) + rel_positional_encoding(x.shape[1], hidden)[None]).astype(F32)
     x = (x * nonpad).astype(F32)
     l = 0
     while f"{prefix}layers.{l}.op.layer_norm1.weight" in p:
@@ -106,7 +123,7 @@ def _lin1(v, p, name):
 
 
 def fs2_acoustic_forward(p, txt_tokens, mel2ph, f0, num_heads=2, key_shift=None, speed=None, spk_embed_id=None,
-                         languages=None, spk_mix_embed=None, **variances):
+                         languages=None, spk_mix_embed=None, pos="rope", **variances):
     """-> condition [B, T, H]."""
     txt_tokens, mel2ph = np.asarray(txt_tokens), np.asarray(mel2ph)
     txt_embed = p["txt_embed.weight"][txt_tokens]
@@ -114,7 +131,7 @@ def fs2_acoustic_forward(p, txt_tokens, mel2ph, f0, num_heads=2, key_shift=None,
     extra = _lin1(dur, p, "dur_embed")
     if "lang_embed.weight" in p:
         extra = (extra + p["lang_embed.weight"][np.asarray(languages)]).astype(F32)
-    enc = fs2_encoder(p, txt_embed, extra, txt_tokens == 0, num_heads)
+    enc = fs2_encoder(p, txt_embed, extra, txt_tokens == 0, num_heads, pos=pos)
     enc = np.concatenate([np.zeros_like(enc[:, :1]), enc], axis=1)
     cond = np.take_along_axis(enc, mel2ph[:, :, None].repeat(enc.shape[-1], axis=2), axis=1).astype(F32)
     if "spk_embed.weight" in p:

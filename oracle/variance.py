@@ -21,6 +21,17 @@ from .encoder import _lin1, _ln, fs2_encoder
 VARIANCE_CHECKLIST = ("energy", "breathiness", "voicing", "tension")     # param_adaptor.py:10
 
 
+def pos_mode(get):
+    """'rope' | 'rel' | 'none' as FastSpeech2Encoder.__init__ decides (tts_modules.py:362-364,378-384)."""
+    use_pos = get("use_pos_embed") if get("use_pos_embed") is not None else True
+    if use_pos and get("use_rope"):
+        return "rope"
+    if not use_pos:
+        return "none"
+    assert get("rel_pos"), "SinusoidalPositionalEmbedding (rel_pos false) is not restated"
+    return "rel"
+
+
 def sub(p, prefix):
     """The entries of a flat state dict below `prefix`, with the prefix removed."""
     return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
@@ -71,7 +82,7 @@ def fs2_variance_forward(p, hp, txt_tokens, midi, ph2word, ph_dur=None, word_dur
         extra = _lin1(np.asarray(ph_dur).astype(F32), p, "ph_dur_embed")
     if hp.get("use_lang_id"):
         extra = (extra + p["lang_embed.weight"][np.asarray(languages)]).astype(F32)
-    enc = fs2_encoder(p, txt_embed, extra, txt_tokens == 0, hp["num_heads"])
+    enc = fs2_encoder(p, txt_embed, extra, txt_tokens == 0, hp["num_heads"], pos=pos_mode(hp.get))
     if not hp["predict_dur"]:
         return enc, None
     dur_cond = (enc + p["midi_embed.weight"][np.asarray(midi)]).astype(F32)
@@ -90,7 +101,8 @@ def melody_encoder(p, hp, note_midi, note_rest, note_dur, glide=None):
     extra = _lin1(np.asarray(note_dur).astype(F32), p, "note_dur_embed")
     if hp.get("use_glide_embed"):
         extra = (extra + p["note_glide_embed.weight"][np.asarray(glide)] * F32(hp["glide_embed_scale"])).astype(F32)
-    enc = fs2_encoder(p, midi_embed, extra, note_midi < 0, args.get("num_heads", hp["num_heads"]))
+    enc = fs2_encoder(p, midi_embed, extra, note_midi < 0, args.get("num_heads", hp["num_heads"]),
+                      pos=pos_mode(lambda k: args.get(k, hp.get(k))))
     return (enc @ p["out_proj.weight"].T + p["out_proj.bias"]).astype(F32)
 
 

@@ -500,6 +500,9 @@ ENC_CASES = {
              dict(num_spk=3, num_lang=2, variances=("energy", "breathiness"), key_shift=True, speed=True), 2, 12, 70, 82),
     "k9": (30, dict(enc_ffn_kernel_size=9, enc_layers=2, hidden_size=128), dict(ffn_kernel_size=9, enc_layers=2,
                                                                                hidden_size=128), 2, 9, 40, 83),
+    # pre-rotary checkpoints: RelPositionalEncoding + torch.nn.MultiheadAttention (use_rope false), or no positions at all
+    "relpos": (40, dict(use_rope=False, rel_pos=True, enc_layers=2), dict(enc_layers=2, rope=False), 3, 15, 64, 84),
+    "nopos": (40, dict(use_rope=False, use_pos_embed=False, enc_layers=2), dict(enc_layers=2, rope=False), 2, 11, 50, 85),
 }
 
 
@@ -565,7 +568,7 @@ def g8_encoder():
         for k in ("key_shift", "speed", "energy", "breathiness", "languages", "spk_embed_id"):
             if k in kwargs or (k in ("energy", "breathiness") and k in skw.get("variances", ())):
                 out[f"{tag}_{k}"] = ex[k]
-        out[f"{tag}_cond"] = cond[:, ::2] if tag in ("default", "padded") else cond      # every other frame: half the bytes
+        out[f"{tag}_cond"] = cond[:, ::2] if tag in ("default", "padded", "relpos", "nopos") else cond      # every other frame: half the bytes
         print(f"  enc {tag}: cond {cond.shape} absmax={np.abs(cond).max():.3f}")
     save("g8_encoder", **out)
 

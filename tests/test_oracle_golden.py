@@ -352,7 +352,9 @@ ENC_SYNTH = {
     "default": dict(), "padded": dict(),
     "full": dict(num_spk=3, num_lang=2, variances=("energy", "breathiness"), key_shift=True, speed=True),
     "k9": dict(),
+    "relpos": dict(rope=False), "nopos": dict(rope=False),
 }
+ENC_POS = {"relpos": "rel", "nopos": "none"}
 
 
 def enc_case(g, tag):
@@ -371,9 +373,9 @@ def test_g8_fs2_acoustic_encoder(tag):
     (4 transformer layers: LayerNorm, RoPE attention, k-tap FFN; padded batches; every optional embedding)."""
     g = load("g8_encoder")
     params, heads, tokens, mel2ph, f0, extra = enc_case(g, tag)
-    cond = oe.fs2_acoustic_forward(params, tokens, mel2ph, f0, num_heads=heads, **extra)
+    cond = oe.fs2_acoustic_forward(params, tokens, mel2ph, f0, num_heads=heads, pos=ENC_POS.get(tag, "rope"), **extra)
     want = g[f"{tag}_cond"]
-    if tag in ("default", "padded"):
+    if tag in ("default", "padded", "relpos", "nopos"):
         cond = cond[:, ::2]
     assert cond.shape == want.shape
     assert rel_err(cond, want) < 2e-5

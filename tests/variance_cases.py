@@ -42,6 +42,10 @@ CASES = OrderedDict(
                           dur_prediction_args=dict(arch="fs2", hidden_size=512, dropout=0.1, num_layers=5, kernel_size=3,
                                                    log_offset=1.0, loss_type="mse")),
                   vocab=40, bsz=3, n_ph=17, n_word=6, t_len=0, seed=1230),
+    # a pre-rotary checkpoint layout (use_rope false): RelPositionalEncoding + torch.nn.MultiheadAttention, melody encoder too
+    relpos_pitch=dict(hp=dict(predict_dur=True, predict_pitch=True, use_melody_encoder=True, use_rope=False,
+                              diffusion_type="reflow", sampling_algorithm="euler", sampling_steps=4),
+                      vocab=20, bsz=2, n_ph=10, n_word=4, t_len=37, seed=1240),
 )
 
 
