@@ -27,7 +27,7 @@ EXPORTS = [
     "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode", "dsd_vocoder_create", "dsd_vocode",
     "dsd_token_encoder_create", "dsd_token_encode", "dsd_predict_dur", "dsd_cond_assemble",
 ]
-POS_ROPE, POS_REL, POS_NONE = 0, 1, 2       # DSD_POS_*
+POS_ROPE, POS_REL, POS_NONE, POS_SIN = 0, 1, 2, 3       # DSD_POS_*
 EMBED_FLAGS = {"energy": 1, "breathiness": 2, "voicing": 4, "tension": 8, "key_shift": 16, "speed": 32}
 
 

@@ -226,6 +226,7 @@ void expected_fs2_layers(std::vector<std::pair<std::string, std::vector<int64_t>
                          int64_t ks, int pos_mode) {
     auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
     if (pos_mode == DSD_POS_REL) add("encoder.embed_positions.div_term", {H / 2});
+    if (pos_mode == DSD_POS_SIN) add("encoder.embed_positions.freqs", {H / 2});
     for (int l = 0; l < layers; ++l) {
         const std::string p = "encoder.layers." + std::to_string(l) + ".op.";
         add(p + "layer_norm1.weight", {H});
@@ -548,6 +549,7 @@ void pack_fs2_layers(dsd_handle* h, int H, int L, int ks, int pos_mode) {
     h->e_freqs = SIZE_MAX;
     if (pos_mode == DSD_POS_ROPE) h->e_freqs = copy_vec("encoder.layers.0.op.self_attn.rotary_embed.freqs");     // one shared RotaryEmbedding
     if (pos_mode == DSD_POS_REL) h->e_freqs = copy_vec("encoder.embed_positions.div_term");
+    if (pos_mode == DSD_POS_SIN) h->e_freqs = copy_vec("encoder.embed_positions.freqs");
     h->e_lng = copy_vec("encoder.layer_norm.weight");
     h->e_lnb = copy_vec("encoder.layer_norm.bias");
     h->g_qkv.resize(L); h->g_oproj.resize(L); h->g_ffn1.resize(L); h->g_ffn2.resize(L);
@@ -1258,6 +1260,8 @@ int dsd_load_weight(dsd_handle* h, const char* name, const float* data, const in
     const std::string n(name);
     std::vector<int64_t> shp(shape, shape + ndim);
     bool found = false;
+    if ((is_enc(h) || is_tok(h)) && n == "encoder.embed_positions._float_tensor")
+        return DSD_OK;       // SinusoidalPositionalEmbedding's device/dtype marker buffer (common_layers.py:59): carries no value
     if (n == "diffusion_embedding.freqs" && !is_enc(h) && !is_voc(h) && !is_tok(h)) {
         if (ndim != 1 || shp[0] != h->cfg.num_channels / 2)
             return fail(h, DSD_EINVAL, "diffusion_embedding.freqs must have shape [%d]", h->cfg.num_channels / 2);
@@ -1354,7 +1358,7 @@ int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out) {
     if (cfg->ffn_kernel_size < 1 || cfg->ffn_kernel_size % 2 == 0 || cfg->ffn_kernel_size > 15)
         return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: enc_ffn_kernel_size must be odd and <= 15");
     if (cfg->num_spk < 0 || cfg->num_lang < 0) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: negative table size");
-    if (cfg->pos_mode < DSD_POS_ROPE || cfg->pos_mode > DSD_POS_NONE) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: pos_mode must be DSD_POS_ROPE, _REL or _NONE");
+    if (cfg->pos_mode < DSD_POS_ROPE || cfg->pos_mode > DSD_POS_SIN) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: pos_mode must be one of DSD_POS_*");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, DSD_EHIP, "dsd_encoder_create: no HIP device is visible (this library has no CPU path)");
@@ -1486,6 +1490,8 @@ int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, 
         ENC_OK(launch_enc_relpos(h->e_x, blob + h->e_freqs, H, B, L, Ls, st), "relpos");
         ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
     }
+    if (e.pos_mode == DSD_POS_SIN)        // x + positions (zero at padding)  (tts_modules.py:393-395)
+        ENC_OK(launch_enc_sinpos(h->e_x, h->e_nonpad, blob + h->e_freqs, H, B, L, Ls, st), "sinpos");
     if ((rc = run_fs2_layers(h, H, e.enc_layers, e.num_heads, e.ffn_kernel_size, B, L, st))) return rc;
     EncExpandArgs a;
     memset(&a, 0, sizeof(a));
@@ -1522,7 +1528,7 @@ int dsd_token_encoder_create(const dsd_token_encoder_config* cfg, dsd_handle** o
         return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: enc_ffn_kernel_size must be odd and <= 15");
     if (cfg->out_dims < 0 || cfg->dur_layers < 0) return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: negative size");
     if (cfg->out_dims > 4 * cfg->hidden_size) return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: out_dims above 4 * hidden_size is not supported");
-    if (cfg->pos_mode < DSD_POS_ROPE || cfg->pos_mode > DSD_POS_NONE) return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: pos_mode must be DSD_POS_ROPE, _REL or _NONE");
+    if (cfg->pos_mode < DSD_POS_ROPE || cfg->pos_mode > DSD_POS_SIN) return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: pos_mode must be one of DSD_POS_*");
     if (cfg->dur_layers > 0 && (cfg->dur_chans < 1 || cfg->dur_kernel_size < 1 || cfg->dur_kernel_size % 2 == 0 ||
                                 cfg->dur_kernel_size > 15))
         return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: duration predictor needs channels >= 1 and an odd kernel size <= 15");
@@ -1576,6 +1582,7 @@ int dsd_token_encode(dsd_handle* h, const float* embed, const uint8_t* padding_m
     ENC_OK(launch_enc_nonpad(padding_mask, B, L, Ls, h->e_nonpad, st), "nonpad");
     ENC_OK(launch_pack(embed, (long)L * H, 1, H, h->e_x, B, H, L, Ls, st), "pack(embed)");
     if (t.pos_mode == DSD_POS_REL) ENC_OK(launch_enc_relpos(h->e_x, h->blob + h->e_freqs, H, B, L, Ls, st), "relpos");
+    if (t.pos_mode == DSD_POS_SIN) ENC_OK(launch_enc_sinpos(h->e_x, h->e_nonpad, h->blob + h->e_freqs, H, B, L, Ls, st), "sinpos");
     ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
     if ((rc = run_fs2_layers(h, H, t.enc_layers, t.num_heads, t.ffn_kernel_size, B, L, st))) return rc;
     const float* res = h->e_y;

@@ -169,6 +169,7 @@ struct AssembleArgs {             // dsd_cond_assemble, device view
     const float* t_s[16];
     const float* t_v[16];
 };
+hipError_t launch_enc_sinpos(float* x, const float* nonpad, const float* freqs, int C, int B, int L, int Ls, hipStream_t st);
 hipError_t launch_enc_relpos(float* x, const float* div, int C, int B, int L, int Ls, hipStream_t st);
 hipError_t launch_enc_nonpad(const unsigned char* pad, int B, int L, int Ls, float* nonpad, hipStream_t st);
 hipError_t launch_enc_dur_head(const float* x, const float* w, const float* bias, const float* nonpad, int C, int B, int L,

@@ -334,7 +334,39 @@ __global__ void enc_relpos_kernel(float* __restrict__ x, const float* __restrict
     *p = *p * xscale + ((c & 1) ? cosf(ang) : sinf(ang));
 }
 
+// SinusoidalPositionalEmbedding (common_layers.py:44-99) through make_positions (utils/__init__.py:118-128):
+//   pos[b][l] = nonpad[b][l] * #{l' <= l : nonpad[b][l']};   x[b][c][l] += pos ? (c < H/2 ? sin(pos f_c) : cos(pos f_{c-H/2})) : 0
+// One workgroup per batch row scans the (<= 2048) tokens, then every lane adds its channels.
+__global__ __launch_bounds__(256) void enc_sinpos_kernel(float* __restrict__ x, const float* __restrict__ nonpad,
+                                                         const float* __restrict__ freqs, int C, int L, int Ls) {
+    __shared__ int pos[2048];
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int l = 0; l < L; ++l) {
+            const bool keep = nonpad[(long)b * Ls + l] != 0.f;
+            run += keep;
+            pos[l] = keep ? run : 0;
+        }
+    }
+    __syncthreads();
+    const int half = C >> 1;
+    for (long i = threadIdx.x; i < (long)C * L; i += blockDim.x) {
+        const int c = (int)(i / L), l = (int)(i - (long)c * L);
+        const int p = pos[l];
+        if (p == 0 || c >= 2 * half) continue;
+        const float ang = (float)p * freqs[c < half ? c : c - half];
+        x[((long)b * C + c) * Ls + l] += c < half ? sinf(ang) : cosf(ang);
+    }
+}
+
 // ------------------------------------------- launchers -------------------------------------------
+hipError_t launch_enc_sinpos(float* x, const float* nonpad, const float* freqs, int C, int B, int L, int Ls, hipStream_t st) {
+    if (L > 2048) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(enc_sinpos_kernel, dim3(B), dim3(256), 0, st, x, nonpad, freqs, C, L, Ls);
+    return hipGetLastError();
+}
+
 hipError_t launch_enc_relpos(float* x, const float* div, int C, int B, int L, int Ls, hipStream_t st) {
     hipLaunchKernelGGL(enc_relpos_kernel, dim3((L + 63) / 64, C, B), dim3(64), 0, st, x, div, C, L, Ls, sqrtf((float)C), 4999.f);
     return hipGetLastError();

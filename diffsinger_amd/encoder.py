@@ -7,8 +7,8 @@ ffn.ffn_1, ffn.ffn_2}.*`, `encoder.layer_norm.*`, `pitch_embed.*`, ... - so the 
 checkpoint loads with strict=True, and runs `forward(txt_tokens, mel2ph, f0, ...) -> condition [B, T, H]` ONLY on
 the HIP library (`dsd_encode`).  Supported: the reference fork's configuration (`use_pos_embed: true`,
 `use_rope: true`, `ffn_act: gelu`) and the two pre-rotary layouts - `use_rope: false` with `rel_pos: true`
-(RelPositionalEncoding + torch.nn.MultiheadAttention parameter names) or `use_pos_embed: false`; the fairseq-style
-SinusoidalPositionalEmbedding (`rel_pos: false`) raises NotImplementedError at construction.
+(RelPositionalEncoding + torch.nn.MultiheadAttention parameter names), `rel_pos: false` (SinusoidalPositionalEmbedding
+over the non-padding positions) or `use_pos_embed: false`.
 """
 from __future__ import annotations
 
@@ -61,15 +61,34 @@ def pos_mode_of(get):
         return _lib.POS_ROPE
     if not use_pos:
         return _lib.POS_NONE
-    if get('rel_pos'):
-        return _lib.POS_REL
-    raise NotImplementedError("use_pos_embed: true with rel_pos: false and use_rope: false (SinusoidalPositionalEmbedding, "
-                              "tts_modules.py:383-385) is not implemented on the HIP path")
+    return _lib.POS_REL if get('rel_pos') else _lib.POS_SIN
 
 
 def rel_pos_div_term(h):
     """RelPositionalEncoding's frequency table, with the reference's own torch ops (espnet_positional_embedding.py:38-41)."""
     return torch.exp(torch.arange(0, h, 2, dtype=torch.float32) * -(math.log(10000.0) / h))
+
+
+def sin_pos_freqs(h):
+    """SinusoidalPositionalEmbedding.get_embedding's frequency table, with its torch ops (common_layers.py:69-71)."""
+    half = h // 2
+    return torch.exp(torch.arange(half, dtype=torch.float) * -(math.log(10000) / (half - 1)))
+
+
+def positional_extra_weights(pos_mode, h):
+    if pos_mode == _lib.POS_REL:
+        return {"encoder.embed_positions.div_term": rel_pos_div_term(h)}
+    if pos_mode == _lib.POS_SIN:
+        return {"encoder.embed_positions.freqs": sin_pos_freqs(h)}
+    return {}
+
+
+class _SinPos(nn.Module):
+    """SinusoidalPositionalEmbedding's only state-dict entry: the `_float_tensor` marker buffer (common_layers.py:59)."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer('_float_tensor', torch.zeros(1))
 
 
 class _FFN(nn.Module):
@@ -102,6 +121,8 @@ class _Encoder(nn.Module):
         rotary = _Rotary(h // heads) if pos_mode == _lib.POS_ROPE else None
         self.layers = nn.ModuleList([_Layer(h, ks, rotary) for _ in range(layers)])
         self.layer_norm = nn.LayerNorm(h)
+        if pos_mode == _lib.POS_SIN:
+            self.embed_positions = _SinPos()
 
 
 class FastSpeech2Acoustic(_NativeBackbone):
@@ -147,7 +168,7 @@ class FastSpeech2Acoustic(_NativeBackbone):
                                      self.pos_mode, device_index)
 
     def _extra_weights(self):
-        return {"encoder.embed_positions.div_term": rel_pos_div_term(self._hidden)} if self.pos_mode == _lib.POS_REL else {}
+        return positional_extra_weights(self.pos_mode, self._hidden)
 
     def prepare_cond(self, cond, layout="BHT"):
         raise RuntimeError("FastSpeech2Acoustic produces the condition; call forward(txt_tokens, mel2ph, f0, ...)")

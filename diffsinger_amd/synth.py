@@ -103,7 +103,7 @@ def convnext_param_shapes(in_dims, out_dims, num_channels=512, num_layers=6, ker
 
 
 def fs2_acoustic_param_shapes(vocab_size, hidden_size=256, enc_layers=4, num_heads=2, ffn_kernel_size=3,
-                              num_spk=0, num_lang=0, variances=(), key_shift=False, speed=False, rope=True):
+                              num_spk=0, num_lang=0, variances=(), key_shift=False, speed=False, rope=True, sinpos=False):
     """state_dict of modules/fastspeech/acoustic_encoder.py:14-63 (FastSpeech2Acoustic) in its rotary-embedding
     configuration (`use_rope: true`): tts_modules.py:353-383, common_layers.py:120-234.  The rotary frequency
     table is an (untrained) nn.Parameter of the shared RotaryEmbedding and shows up once per layer.  `rope=False`:
@@ -134,6 +134,8 @@ def fs2_acoustic_param_shapes(vocab_size, hidden_size=256, enc_layers=4, num_hea
         shapes[p + "ffn.ffn_2.bias"] = (h,)
     shapes["encoder.layer_norm.weight"] = (h,)
     shapes["encoder.layer_norm.bias"] = (h,)
+    if sinpos:       # SinusoidalPositionalEmbedding's marker buffer (common_layers.py:59): a value nobody reads
+        shapes["encoder.embed_positions._float_tensor"] = (1,)
     shapes["pitch_embed.weight"] = (h, 1)
     shapes["pitch_embed.bias"] = (h,)
     for v in variances:

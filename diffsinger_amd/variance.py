@@ -7,8 +7,8 @@ delta_pitch_embed`, `pitch_retake_embed`, `pitch_predictor.*`, `pitch_embed`, `v
 library: the FastSpeech2Encoder stacks and the DurationPredictor (`dsd_token_encode`, `dsd_predict_dur`), every
 embedding sum (`dsd_cond_assemble`), and the pitch / multi-variance denoisers (diffusion.py).  What stays in torch is
 integer bookkeeping on [B, T_ph]-sized tensors: word onsets, the rhythm and length regulators.
-Encoders: the rotary configuration (`use_rope: true`, configs/variance.yaml:38) and the two pre-rotary ones (`use_rope:
-false` with `rel_pos: true`, or `use_pos_embed: false`); inference only; no CPU path.
+Encoders: the rotary configuration (`use_rope: true`, configs/variance.yaml:38) and the pre-rotary ones (`use_rope:
+false` with `rel_pos: true` or `false`, or `use_pos_embed: false`); inference only; no CPU path.
 """
 from __future__ import annotations
 
@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import _lib
 from .backbones import _NativeBackbone
 from .diffusion import (MultiVarianceDiffusion, MultiVarianceRectifiedFlow, PitchDiffusion, PitchRectifiedFlow)
-from .encoder import PAD_INDEX, _Encoder, pos_mode_of, rel_pos_div_term
+from .encoder import PAD_INDEX, _Encoder, pos_mode_of, positional_extra_weights
 from .harness import length_regulator
 from .hparams import hparams
 from .toplevel import get_backbone_args
@@ -111,7 +111,7 @@ class _TokenEncoderBase(_NativeBackbone):
         return {k: v for k, v in self.state_dict().items() if k.startswith(self._native_prefixes)}
 
     def _extra_weights(self):
-        return {"encoder.embed_positions.div_term": rel_pos_div_term(self._hidden)} if self.pos_mode == _lib.POS_REL else {}
+        return positional_extra_weights(self.pos_mode, self._hidden)
 
     def prepare_cond(self, cond, layout="BHT"):
         raise RuntimeError(f"{type(self).__name__} is an encoder; call forward(...)")

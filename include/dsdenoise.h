@@ -155,7 +155,12 @@ enum { DSD_POS_ROPE = 0,   /* use_pos_embed && use_rope: rotary embedding inside
                               (espnet_positional_embedding.py:26-47,98-113), torch.nn.MultiheadAttention(bias=False);
                               weights `...self_attn.in_proj_weight` instead of `in_proj.weight` + `rotary_embed.freqs`, plus
                               `encoder.embed_positions.div_term` [H/2] = exp(arange(0, H, 2) * -(ln 10000 / H)) */
-       DSD_POS_NONE = 2 }; /* !use_pos_embed: no positions; attention and weight names as DSD_POS_REL */
+       DSD_POS_NONE = 2,   /* !use_pos_embed: no positions; attention and weight names as DSD_POS_REL */
+       DSD_POS_SIN = 3 };  /* use_pos_embed && !use_rope && !rel_pos: x + SinusoidalPositionalEmbedding(positions)
+                              (common_layers.py:44-99; positions count the non-padding tokens from 1, utils/__init__.py:118-128);
+                              attention and weight names as DSD_POS_REL, plus `encoder.embed_positions.freqs` [H/2] =
+                              exp(arange(H/2) * -(ln 10000 / (H/2 - 1))); the checkpoint's `encoder.embed_positions._float_tensor`
+                              buffer is accepted and ignored */
 
 typedef struct dsd_encoder_config {
     int32_t struct_size;      /* sizeof(dsd_encoder_config)                                          */

@@ -55,6 +55,18 @@ def rel_positional_encoding(seq, dim, max_len=5000):
     return np.stack([np.sin(ang), np.cos(ang)], axis=2).reshape(seq, dim).astype(F32)
 
 
+def sinusoidal_positions(pad_mask, dim):
+    """SinusoidalPositionalEmbedding(~padding_mask): positions count the non-padding tokens from 1 (utils/__init__.py:118-128),
+    row p = [sin(p f_0..), cos(p f_0..)], f_i = exp(-i ln(10000) / (dim/2 - 1)); padding -> zeros."""
+    nonpad = ~np.asarray(pad_mask, dtype=bool)
+    pos = np.cumsum(nonpad, axis=1) * nonpad
+    half = dim // 2
+    freqs = np.exp(np.arange(half, dtype=F32) * F32(-(np.log(10000.0) / (half - 1)))).astype(F32)
+    ang = (pos[..., None].astype(F32) * freqs).astype(F32)
+    emb = np.concatenate([np.sin(ang), np.cos(ang)], axis=-1).astype(F32)
+    return (emb * nonpad[..., None]).astype(F32)
+
+
 def self_attention_rope(x, p, pre, num_heads, pad_mask, freqs=None):
     """MultiheadSelfAttentionWithRoPE (common_layers.py:171-213); without a rotary table - `in_proj_weight` present -
     torch.nn.MultiheadAttention(bias=False) as EncSALayer calls it (common_layers.py:222-226,247-254): the same
@@ -93,12 +105,15 @@ def ffn(x, p, pre):
 
 
 def fs2_encoder(p, main_embed, extra_embed, pad_mask, num_heads, prefix="encoder.", pos="rope"):
-    """pos: 'rope' (rotation inside the attention), 'rel' (use_rope false, rel_pos true: x * sqrt(H) + table), 'none'."""
+    """pos: 'rope' (rotation inside the attention), 'rel' (use_rope false, rel_pos true: x * sqrt(H) + table), 'sin'
+    (rel_pos false: x + sinusoidal table of the non-padding positions), 'none'."""
     hidden = main_embed.shape[-1]
     nonpad = (1.0 - pad_mask.astype(F32))[:, :, None]
     x = (F32(np.sqrt(hidden)) * main_embed + extra_embed).astype(F32)
     if pos == "rel":                                     # tts_modules.py:390-392
         x = (x * F32(np.sqrt(hidden)) + rel_positional_encoding(x.shape[1], hidden)[None]).astype(F32)
+    elif pos == "sin":                                   # tts_modules.py:393-395, common_layers.py:61-99
+        x = (x + sinusoidal_positions(pad_mask, hidden)).astype(F32)
     x = (x * nonpad).astype(F32)
     l = 0
     while f"{prefix}layers.{l}.op.layer_norm1.weight" in p:

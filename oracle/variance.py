@@ -22,14 +22,13 @@ VARIANCE_CHECKLIST = ("energy", "breathiness", "voicing", "tension")     # param
 
 
 def pos_mode(get):
-    """'rope' | 'rel' | 'none' as FastSpeech2Encoder.__init__ decides (tts_modules.py:362-364,378-384)."""
+    """'rope' | 'rel' | 'sin' | 'none' as FastSpeech2Encoder.__init__ decides (tts_modules.py:362-364,378-384)."""
     use_pos = get("use_pos_embed") if get("use_pos_embed") is not None else True
     if use_pos and get("use_rope"):
         return "rope"
     if not use_pos:
         return "none"
-    assert get("rel_pos"), "SinusoidalPositionalEmbedding (rel_pos false) is not restated"
-    return "rel"
+    return "rel" if get("rel_pos") else "sin"
 
 
 def sub(p, prefix):

@@ -503,6 +503,7 @@ ENC_CASES = {
     # pre-rotary checkpoints: RelPositionalEncoding + torch.nn.MultiheadAttention (use_rope false), or no positions at all
     "relpos": (40, dict(use_rope=False, rel_pos=True, enc_layers=2), dict(enc_layers=2, rope=False), 3, 15, 64, 84),
     "nopos": (40, dict(use_rope=False, use_pos_embed=False, enc_layers=2), dict(enc_layers=2, rope=False), 2, 11, 50, 85),
+    "sinpos": (40, dict(use_rope=False, rel_pos=False, enc_layers=2), dict(enc_layers=2, rope=False, sinpos=True), 3, 13, 56, 86),
 }
 
 
@@ -568,7 +569,7 @@ def g8_encoder():
         for k in ("key_shift", "speed", "energy", "breathiness", "languages", "spk_embed_id"):
             if k in kwargs or (k in ("energy", "breathiness") and k in skw.get("variances", ())):
                 out[f"{tag}_{k}"] = ex[k]
-        out[f"{tag}_cond"] = cond[:, ::2] if tag in ("default", "padded", "relpos", "nopos") else cond      # every other frame: half the bytes
+        out[f"{tag}_cond"] = cond[:, ::2] if tag in ("default", "padded", "relpos", "nopos", "sinpos") else cond      # every other frame: half the bytes
         print(f"  enc {tag}: cond {cond.shape} absmax={np.abs(cond).max():.3f}")
     save("g8_encoder", **out)
 

@@ -27,6 +27,7 @@ CASES = {
     # pre-rotary checkpoints (use_rope false): RelPositionalEncoding / no positions, torch.nn.MultiheadAttention names
     "relpos": (dict(use_rope=False, rel_pos=True, enc_layers=2), dict(rope=False)),
     "nopos": (dict(use_rope=False, use_pos_embed=False, enc_layers=2), dict(rope=False)),
+    "sinpos": (dict(use_rope=False, rel_pos=False, enc_layers=2), dict(rope=False, sinpos=True)),
 }
 
 
@@ -62,7 +63,7 @@ def test_encoder_vs_golden(tag):
     with torch.no_grad():
         cond = m(dev(g[f"{tag}_tokens"]), dev(g[f"{tag}_mel2ph"]), dev(g[f"{tag}_f0"]), **kwargs)
     want = g[f"{tag}_cond"]
-    if tag in ("default", "padded", "relpos", "nopos"):
+    if tag in ("default", "padded", "relpos", "nopos", "sinpos"):
         cond = cond[:, ::2]
     assert rel_err(cond, want) < TOL
     m.release_native()
@@ -118,7 +119,7 @@ def test_encoder_spk_mix_and_errors():
         m(tokens, mel2ph, f0, spk_embed_id=dev(g["full_spk_embed_id"]), **base)
     m.release_native()
     from diffsinger_amd.encoder import FastSpeech2Acoustic
-    set_hp(**dict(ENC_HP, use_rope=False, rel_pos=False))          # fairseq-style SinusoidalPositionalEmbedding
+    set_hp(**dict(ENC_HP, ffn_act="swiglu"))
     with pytest.raises(NotImplementedError):
         FastSpeech2Acoustic(10)
 

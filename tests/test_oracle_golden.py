@@ -352,9 +352,9 @@ ENC_SYNTH = {
     "default": dict(), "padded": dict(),
     "full": dict(num_spk=3, num_lang=2, variances=("energy", "breathiness"), key_shift=True, speed=True),
     "k9": dict(),
-    "relpos": dict(rope=False), "nopos": dict(rope=False),
+    "relpos": dict(rope=False), "nopos": dict(rope=False), "sinpos": dict(rope=False, sinpos=True),
 }
-ENC_POS = {"relpos": "rel", "nopos": "none"}
+ENC_POS = {"relpos": "rel", "nopos": "none", "sinpos": "sin"}
 
 
 def enc_case(g, tag):
@@ -375,7 +375,7 @@ def test_g8_fs2_acoustic_encoder(tag):
     params, heads, tokens, mel2ph, f0, extra = enc_case(g, tag)
     cond = oe.fs2_acoustic_forward(params, tokens, mel2ph, f0, num_heads=heads, pos=ENC_POS.get(tag, "rope"), **extra)
     want = g[f"{tag}_cond"]
-    if tag in ("default", "padded", "relpos", "nopos"):
+    if tag in ("default", "padded", "relpos", "nopos", "sinpos"):
         cond = cond[:, ::2]
     assert cond.shape == want.shape
     assert rel_err(cond, want) < 2e-5

@@ -41,10 +41,10 @@ def test_unsupported_configurations_raise():
     from diffsinger_amd.variance import DiffSingerVariance
     hparams.clear()
     hparams.update(vc.case_hparams("dur_only"), infer=True)
-    hparams["use_rope"], hparams["rel_pos"] = False, False          # fairseq-style SinusoidalPositionalEmbedding
-    with pytest.raises(NotImplementedError, match="SinusoidalPositionalEmbedding"):
+    hparams["ffn_act"] = "swiglu"
+    with pytest.raises(NotImplementedError, match="ffn_act"):
         DiffSingerVariance(10)
-    hparams["use_rope"], hparams["rel_pos"] = True, True
+    hparams["ffn_act"] = "gelu"
     hparams["diffusion_type"] = "flow"
     with pytest.raises(ValueError, match="Invalid diffusion type"):
         DiffSingerVariance(10)

@@ -46,6 +46,9 @@ CASES = OrderedDict(
     relpos_pitch=dict(hp=dict(predict_dur=True, predict_pitch=True, use_melody_encoder=True, use_rope=False,
                               diffusion_type="reflow", sampling_algorithm="euler", sampling_steps=4),
                       vocab=20, bsz=2, n_ph=10, n_word=4, t_len=37, seed=1240),
+    # the oldest layout: fairseq-style sinusoidal positions over the non-padding tokens (rel_pos false), a padded batch
+    sinpos_dur=dict(hp=dict(predict_dur=True, use_rope=False, rel_pos=False, diffusion_type="reflow"),
+                    vocab=25, bsz=3, n_ph=13, n_word=4, t_len=0, seed=1250),
 )
 
 
