@@ -682,6 +682,20 @@ def g10_vocoder():
     save("g10_vocoder", **out)
 
 
+def g5_config1_pndm50():
+    """BASELINE configs[0] (the reference's own CPU-runnable case): the 20-layer WaveNet, one utterance, PNDM 1000 -> 50
+    steps (ddpm.py:149-204,323-347), at full width; T = 48 keeps the fixture small."""
+    set_hp(diff_accelerator="pndm", diff_speedup=20, K_step_infer=1000)
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    d = _build_gd(128, 1, args, 42)
+    cond = synth.synth_normal((1, 48, 256), 3700)
+    with InjectRandn(3200) as inj, torch.no_grad():
+        y = d(to_t(cond), infer=True).numpy()
+    print(f"  config 1 (PNDM 50): randn calls={len(inj.seeds)} out={y.shape} absmax={np.abs(y).max():.3f}")
+    save("g5_config1_pndm50", out=y, meta=np.array([1, 48, 3200, len(inj.seeds), 3700], dtype=np.int64))
+
+
+
 # --------------------------------------------------------------------------- G12: DiffSingerVariance, tokens -> dur / pitch / variances
 def g12_variance_model():
     """The reference's own top-level variance model (modules/toplevel.py:125-309), infer branch, small nets; configurations
@@ -881,7 +895,7 @@ def g11_harness():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g5c1"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -900,6 +914,8 @@ if __name__ == "__main__":
         g9_acoustic_model()
     if "g10" in which:
         g10_vocoder()
+    if "g5c1" in which:
+        g5_config1_pndm50()
     if "g12" in which:
         g12_variance_model()
     if "g13" in which:

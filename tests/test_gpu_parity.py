@@ -469,3 +469,17 @@ def test_config5_variance_full_size_vs_oracle():
     for a, w in zip(outs, want2):
         assert np.abs(a.cpu().numpy() - w).max() < 2e-4 * max(1.0, np.abs(w).max())
     m.velocity_fn.release_native()
+
+
+def test_config1_full_size_wavenet_pndm50_vs_golden():
+    """BASELINE configs[0] (the reference's own CPU-runnable case): 20x256 WaveNet, one utterance, PNDM 1000 -> 50
+    (ddpm.py:149-204,323-347), against the fixture generated from the reference."""
+    g = load("g5_config1_pndm50")
+    bsz, t_len, nseed, _, cseed = (int(v) for v in g["meta"])
+    set_hp(diff_accelerator="pndm", diff_speedup=20, K_step_infer=1000)
+    d = _gd(1000, in_dims=128, args=dict(num_layers=20, num_channels=256, dilation_cycle_length=4), wseed=42)
+    out = d(dev(synth.synth_normal((bsz, t_len, 256), cseed)), infer=True,
+            noise=dev(synth.synth_normal((bsz, 1, 128, t_len), nseed)))
+    err = rel_err(out, g["out"])
+    assert err < TOL_SAMPLER, err
+    d.denoise_fn.release_native()

@@ -521,3 +521,16 @@ def test_g12_variance_model(tag):
     for n in names:
         want = g[f"{tag}_{n}"]
         assert np.abs(var[n] - want).max() < 1e-4 * np.abs(want).max()
+
+
+def test_g5_config1_full_size_wavenet_pndm50():
+    """BASELINE configs[0]: 20x256 WaveNet, one utterance, PNDM 1000 -> 50 (the reference's CPU-runnable case)."""
+    g = load("g5_config1_pndm50")
+    bsz, t_len, nseed, _, cseed = (int(v) for v in g["meta"])
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    params = synth_params("wavenet", 128, 1, args, 42)
+    fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=4)
+    d = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
+    out = d.forward(synth.synth_normal((bsz, t_len, 256), cseed), synth.synth_normal((bsz, 1, 128, t_len), nseed),
+                    diff_accelerator="pndm", diff_speedup=20, K_step_infer=1000)
+    assert rel_err(out, g["out"]) < 2e-4
