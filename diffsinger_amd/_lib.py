@@ -25,7 +25,7 @@ EXPORTS = [
     "dsd_api_version", "dsd_create", "dsd_destroy", "dsd_last_error", "dsd_load_weight",
     "dsd_finalize_weights", "dsd_prepare_cond", "dsd_denoise", "dsd_sample", "dsd_get_stats",
     "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode", "dsd_vocoder_create", "dsd_vocode",
-    "dsd_token_encoder_create", "dsd_token_encode", "dsd_predict_dur", "dsd_cond_assemble",
+    "dsd_token_encoder_create", "dsd_token_encode", "dsd_predict_dur", "dsd_cond_assemble", "dsd_set_lengths",
 ]
 POS_ROPE, POS_REL, POS_NONE, POS_SIN = 0, 1, 2, 3       # DSD_POS_*
 EMBED_FLAGS = {"energy": 1, "breathiness": 2, "voicing": 4, "tension": 8, "key_shift": 16, "speed": 32}
@@ -139,13 +139,14 @@ def _load():
     lib.dsd_token_encode.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.dsd_predict_dur.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.dsd_cond_assemble.argtypes = [C.POINTER(DsdAssembleArgs), vp, vp]
+    lib.dsd_set_lengths.argtypes = [vp, C.POINTER(C.c_int32), i32, vp]
     lib.dsd_encode.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.POINTER(DsdEncodeExtras), vp, vp]
     lib.dsd_get_stats.argtypes = [vp, C.POINTER(DsdStats)]
     lib.dsd_kernel_timing.argtypes = [vp, i32]
     lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     for name in EXPORTS:
         getattr(lib, name)
-    if lib.dsd_api_version() != 7:
+    if lib.dsd_api_version() != 8:
         raise NativeLibraryError("libdsdenoise.so API version mismatch")
     return lib
 

@@ -51,9 +51,15 @@ class ConvNeXtDecoder(_NativeBackbone):
         raise RuntimeError("ConvNeXtDecoder has no hoisted conditioner; call forward(condition)")
 
     # noinspection PyUnusedLocal
-    def forward(self, x, infer=False, *, out_scale=None, out_shift=None):
+    def forward(self, x, infer=False, *, out_scale=None, out_shift=None, lengths=None):
         """x: [B, T, in_dims] -> [B, T, out_dims] (convnext.py:78-85); `out_scale/out_shift` ([out_dims]) fuse
-        AuxDecoderAdaptor.denorm_spec into the output transpose."""
+        AuxDecoderAdaptor.denorm_spec into the output transpose; `lengths` [B]: ragged batch (dsd_set_lengths)."""
+        if lengths is not None:
+            self.set_lengths(lengths, x.device)
+            try:
+                return self.forward(x, infer, out_scale=out_scale, out_shift=out_shift)
+            finally:
+                self.set_lengths(None, x.device)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError(
                 "diffsinger_amd.ConvNeXtDecoder is inference-only (no backward kernels): call it under "
@@ -131,12 +137,12 @@ class AuxDecoderAdaptor(nn.Module):
         k, b = self._affine()
         return x * k + b
 
-    def forward(self, condition, infer=False):
+    def forward(self, condition, infer=False, lengths=None):
         fuse = infer and self.n_feats == 1 and self.spec_min.numel() in (1, self.out_dims)
         if fuse:        # x * k + b rides on the decoder's output transpose
             k, b = (v.reshape(-1).expand(self.out_dims) for v in self._affine())
-            return self.decoder(condition, infer=True, out_scale=k, out_shift=b)
-        x = self.decoder(condition, infer=infer)  # [B, T, F x C]
+            return self.decoder(condition, infer=True, out_scale=k, out_shift=b, lengths=lengths)
+        x = self.decoder(condition, infer=infer, lengths=lengths)  # [B, T, F x C]
         if self.n_feats > 1:
             x = x.reshape(-1, x.shape[1], self.n_feats, self.out_dims)  # [B, T, F, C]
             x = x.transpose(1, 2)  # [B, F, T, C]

@@ -108,6 +108,18 @@ class _NativeBackbone(nn.Module):
             self._cond_key = None
         return self._handle
 
+    def set_lengths(self, lengths, device):
+        """Ragged batch (dsd_set_lengths): item b of the following calls is valid on [0, lengths[b]) and treated as zero
+        padding beyond - it comes out as if it were run alone at its own length.  None: dense batches again."""
+        handle = self.native_handle(device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        if lengths is None:
+            _lib.check(handle, _lib.lib().dsd_set_lengths(handle, None, 0, C.c_void_p(stream)), "dsd_set_lengths")
+            return
+        vals = [int(v) for v in (lengths.tolist() if torch.is_tensor(lengths) else lengths)]
+        arr = (C.c_int32 * len(vals))(*vals)
+        _lib.check(handle, _lib.lib().dsd_set_lengths(handle, arr, len(vals), C.c_void_p(stream)), "dsd_set_lengths")
+
     def release_native(self):
         if self._handle is not None:
             _lib.lib().dsd_destroy(self._handle)

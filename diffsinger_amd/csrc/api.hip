@@ -109,6 +109,10 @@ struct dsd_handle {
     float *xin = nullptr, *ubuf = nullptr, *vbuf = nullptr, *stats = nullptr, *lnpart = nullptr;
     float *io_in = nullptr, *io_out = nullptr;
     bool cond_ready = false;
+    // ragged batches (dsd_set_lengths): per-item valid lengths on the device, nullptr = dense
+    int* lens_dev = nullptr;
+    int lens_cap = 0;
+    std::vector<int> lens_host;
     // sampler state buffers
     float* state = nullptr;
     int state_nbufs = 0;
@@ -149,6 +153,16 @@ int fail(dsd_handle* h, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                  \
         if (e_ != hipSuccess) return fail(h, DSD_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// ragged batch bookkeeping: the lengths given by dsd_set_lengths must describe this call's batch
+inline int check_lens(dsd_handle* h, const char* who, int B, int T) {
+    if (h->lens_host.empty()) return DSD_OK;
+    if ((int)h->lens_host.size() != B)
+        return fail(h, DSD_ESTATE, "%s: dsd_set_lengths gave %zu lengths but this call runs a batch of %d", who, h->lens_host.size(), B);
+    for (int v : h->lens_host)
+        if (v > T) return fail(h, DSD_EINVAL, "%s: a length (%d) exceeds T = %d", who, v, T);
+    return DSD_OK;
+}
 
 inline int C_of(const dsd_handle* h) { return h->cfg.num_channels; }
 inline int FM_of(const dsd_handle* h) { return h->cfg.in_dims * h->cfg.n_feats; }
@@ -973,6 +987,9 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     p.taps = g.taps;
     p.HL = g.taps > 1 ? round_up((g.taps / 2) * dil, 4) : 0;
     p.in_scale = 1.f;
+    // ragged batches: only a convolution along time can carry an item's padded frames into its valid ones, so only the
+    // k-tap GEMMs over the utterances' (B, T) frames mask their input (not the 1x1s, not the step-embedding MLPs)
+    p.lens = (!h->lens_host.empty() && g.taps > 1 && batch == h->B && T == h->T) ? h->lens_dev : nullptr;
     c.stage = stage;
     c.taps = g.taps;
     c.epi = epi;
@@ -1021,6 +1038,7 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
 }
 
 int run_gemm(dsd_handle* h, const GemmCall& c, hipStream_t st) {
+
     if (c.p.lds_bytes > 160 * 1024)
         return fail(h, DSD_EINVAL, "GEMM tile needs %d bytes of LDS (> 160 KiB): %d input channels x k=%d at dilation %d "
                     "is outside the supported shapes", c.p.lds_bytes, c.p.K, c.taps, c.p.dil);
@@ -1156,7 +1174,8 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
         rc = run_gemm(h, g, st);
         timed_end();
         if (rc) return rc;
-        e = launch_dwconv(h->ubuf, h->vbuf, us, Ts, inner, B, T, h->blob + h->dw_w[l], h->blob + h->dw_b[l],
+        e = launch_dwconv(h->ubuf, h->vbuf, us, Ts, inner, B, T, h->lens_host.empty() ? nullptr : h->lens_dev,
+                          h->blob + h->dw_w[l], h->blob + h->dw_b[l],
                           h->cfg.kernel_size, h->cfg.activation,
                           h->dw_prelu[l] == SIZE_MAX ? nullptr : h->blob + h->dw_prelu[l], st);
         if (e != hipSuccess) return fail(h, DSD_EHIP, "dwconv launch failed: %s", hipGetErrorString(e));
@@ -1249,6 +1268,7 @@ void dsd_destroy(dsd_handle* h) {
     if (h->arena) (void)hipFree(h->arena);
     if (h->state) (void)hipFree(h->state);
     if (h->emb_arena) (void)hipFree(h->emb_arena);
+    if (h->lens_dev) (void)hipFree(h->lens_dev);
     if (h->e_arena) (void)hipFree(h->e_arena);
     if (h->v_arena) (void)hipFree(h->v_arena);
     delete h;
@@ -1912,6 +1932,7 @@ int dsd_aux_decode(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64
     HIP_OK(h, hipSetDevice(h->cfg.device));
     int rc = ensure_workspace(h, B, T);
     if (rc) return rc;
+    if ((rc = check_lens(h, "dsd_aux_decode", B, T))) return rc;
     const int H = h->cfg.hidden_size, Ts = h->Ts, L = L_of(h), C = C_of(h), M = FM_of(h);
     const long xs = (long)C * Ts, us = (long)4 * C * Ts;
     hipError_t e = launch_pack(cond, stride_b, stride_h, stride_t, h->cond_i, B, H, T, Ts, st);
@@ -1922,7 +1943,8 @@ int dsd_aux_decode(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64
         if ((rc = run_gemm(h, g, st))) return rc;
     }
     for (int l = 0; l < L; ++l) {      // ConvNeXtBlock.forward   convnext.py:40-56
-        e = launch_dwconv(h->xh, h->xin, xs, Ts, C, B, T, h->blob + h->dw_w[l], h->blob + h->dw_b[l], 7, 3, nullptr, st);
+        e = launch_dwconv(h->xh, h->xin, xs, Ts, C, B, T, h->lens_host.empty() ? nullptr : h->lens_dev,
+                          h->blob + h->dw_w[l], h->blob + h->dw_b[l], 7, 3, nullptr, st);
         if (e != hipSuccess) return fail(h, DSD_EHIP, "dwconv launch failed: %s", hipGetErrorString(e));
         e = launch_lynx_pre(h->xin, nullptr, nullptr, 0, nullptr, 0, 0, 0, xs, Ts, C, B, T, 0, h->stats, Ts, 1e-6f, st);
         if (e != hipSuccess) return fail(h, DSD_EHIP, "LayerNorm stats launch failed: %s", hipGetErrorString(e));
@@ -1954,8 +1976,9 @@ int dsd_denoise(dsd_handle* h, const float* x, const float* t, int32_t t_len, fl
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int B = h->B, T = h->T, Ts = h->Ts, FM = FM_of(h);
-    int rc = ensure_emb(h, t_len);
+    int rc = check_lens(h, "dsd_denoise", B, T);
     if (rc) return rc;
+    if ((rc = ensure_emb(h, t_len))) return rc;
     HIP_OK(h, hipMemcpyAsync(h->t_dev, t, sizeof(float) * t_len, hipMemcpyDeviceToDevice, st));
     if ((rc = run_step_tables(h, t_len, st))) return rc;
     hipError_t e = launch_pack(x, (long)FM * T, T, 1, h->io_in, B, FM, T, Ts, st);
@@ -2001,8 +2024,9 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
             }
         }
     }
-    int rc = ensure_state(h, prog->n_bufs);
+    int rc = check_lens(h, "dsd_sample", B, T);
     if (rc) return rc;
+    if ((rc = ensure_state(h, prog->n_bufs))) return rc;
     if (prog->n_evals > 0 && (rc = ensure_emb(h, prog->n_evals))) return rc;
 
     // x_T (or the shallow-diffusion start) -> state buffer 0
@@ -2057,6 +2081,7 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
         std::string key((const char*)prog->evals, sizeof(dsd_eval) * prog->n_evals);
         key.append((const char*)&prog->n_bufs, sizeof(int32_t));
         key.append((const char*)&noise, sizeof(noise));
+        key.push_back(h->lens_host.empty() ? 'd' : 'r');       // dense / ragged: the kernels' length pointer differs
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
             hipStream_t cs = nullptr;
@@ -2089,6 +2114,33 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
                       (flags & DSD_SAMPLE_TRANSPOSE) ? 1 : 0, (flags & DSD_SAMPLE_TRANSPOSE) ? out_scale : nullptr,
                       (flags & DSD_SAMPLE_TRANSPOSE) ? out_shift : nullptr, st);
     if (e != hipSuccess) return fail(h, DSD_EHIP, "unpack launch failed: %s", hipGetErrorString(e));
+    return DSD_OK;
+}
+
+int dsd_set_lengths(dsd_handle* h, const int32_t* lengths, int32_t B, void* stream) {
+    if (!h) return DSD_EINVAL;
+    if (is_enc(h) || is_tok(h) || is_voc(h))
+        return fail(h, DSD_ESTATE, "dsd_set_lengths: only denoiser and aux-decoder handles take ragged batches");
+    if (!lengths) {             // back to dense batches
+        h->lens_host.clear();
+        return DSD_OK;
+    }
+    if (B < 1) return fail(h, DSD_EINVAL, "dsd_set_lengths: B must be positive (%d)", B);
+    for (int b = 0; b < B; ++b)
+        if (lengths[b] < 0) return fail(h, DSD_EINVAL, "dsd_set_lengths: lengths[%d] = %d is negative", b, lengths[b]);
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    if (h->lens_cap < B) {
+        if (h->lens_dev) (void)hipFree(h->lens_dev);
+        h->lens_dev = nullptr;
+        h->lens_cap = 0;
+        if (hipMalloc(&h->lens_dev, sizeof(int) * (size_t)B) != hipSuccess)
+            return fail(h, DSD_ENOMEM, "hipMalloc of %d lengths failed", B);
+        h->lens_cap = B;
+        destroy_graphs(h);      // cached graphs captured the old pointer
+    }
+    h->lens_host.assign(lengths, lengths + B);
+    // stream-ordered behind earlier launches that still read the old values
+    HIP_OK(h, hipMemcpyAsync(h->lens_dev, h->lens_host.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, (hipStream_t)stream));
     return DSD_OK;
 }
 

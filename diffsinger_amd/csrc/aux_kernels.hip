@@ -267,13 +267,14 @@ constexpr int DW_MAXK = 63;
 // of 124); KS == 0: any odd k <= 63, taps read from LDS one by one.
 template <int KS>
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                     long bstride, int rstride, int C, int T,
+                                                     long bstride, int rstride, int C, int T, const int* __restrict__ lens,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      int ksz_rt, int act, const float* __restrict__ prelu) {
     __shared__ __attribute__((aligned(16))) float row[4][DW_TT + 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
+    const int Tb = lens ? lens[b] : T;                   // ragged batch: zero padding starts at this item's own length
     const int c = blockIdx.y * 4 + wave;                 // wave-uniform: weights and bias are scalar loads
     const int t0 = blockIdx.x * DW_TT;
     const int ksz = KS > 0 ? KS : ksz_rt;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ s
         const float* s = src + (long)b * bstride + (long)c * rstride;
         for (int i = lane; i < DW_TT + 64; i += 64) {
             const int t = t0 - pad + i;
-            row[wave][i] = (t >= 0 && t < T && i < DW_TT + ksz - 1) ? s[t] : 0.f;
+            row[wave][i] = (t >= 0 && t < Tb && i < DW_TT + ksz - 1) ? s[t] : 0.f;
         }
     }
     __syncthreads();
@@ -329,19 +330,19 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ s
     if (t0 + lane * 4 < rstride - 3) *reinterpret_cast<f32x4*>(d) = o;
 }
 
-hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T,
+hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T, const int* lens,
                          const float* w, const float* bias, int ksz, int act, const float* prelu,
                          hipStream_t stream) {
     if (ksz > DW_MAXK || ksz < 1 || ksz % 2 == 0) return hipErrorInvalidValue;
     dim3 grid((T + DW_TT - 1) / DW_TT, (C + 3) / 4, B);
     if (ksz == 31)
-        hipLaunchKernelGGL(dwconv_kernel<31>, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, w, bias, ksz,
+        hipLaunchKernelGGL(dwconv_kernel<31>, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, lens, w, bias, ksz,
                            act, prelu);
     else if (ksz == 7)
-        hipLaunchKernelGGL(dwconv_kernel<7>, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, w, bias, ksz,
+        hipLaunchKernelGGL(dwconv_kernel<7>, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, lens, w, bias, ksz,
                            act, prelu);
     else
-        hipLaunchKernelGGL(dwconv_kernel<0>, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, w, bias, ksz,
+        hipLaunchKernelGGL(dwconv_kernel<0>, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, lens, w, bias, ksz,
                            act, prelu);
     return hipGetLastError();
 }

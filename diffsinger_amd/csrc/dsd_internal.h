@@ -85,6 +85,9 @@ struct GemmP {
     // projection cpn and step projection (film fields):  strong: x = v + cpn, xin = x + d;  else: x = v, xin = v + cpn + d;
     // cpn == nullptr (after the last layer): x = xin = v.  out = x, out2 = xin (may be nullptr), and per 64-row tile the
     // LayerNorm partials of xin over its rows: lnpart[b][mtile][0][t] = mean, [1][t] = sum of squared deviations.
+    // ragged batches: item b is valid on [0, lens[b]) and zero-padded beyond, as if it were run alone at T = lens[b]
+    // (nullptr: every item is valid on [0, T))
+    const int* lens;
     float* out2;
     const float* cpn;
     long cpn_bstride;
@@ -189,7 +192,7 @@ hipError_t launch_enc_expand(const float* enc, const long long* mel2ph, const En
                              int T, float* cond, hipStream_t st);
 hipError_t launch_ln_merge(const float* lnpart, int mtiles, int C, int B, int T, int ts, float eps, float* stats,
                            hipStream_t stream);
-hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T,
+hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T, const int* lens,
                          const float* w, const float* bias, int ksz, int act, const float* prelu, hipStream_t stream);
 
 }  // namespace dsd

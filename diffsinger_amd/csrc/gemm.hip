@@ -149,6 +149,8 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
     const int mtile = work - rest * p.mtiles;
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;
+    // zero padding of the convolution input ends at this item's own length (scalar load: off the vmcnt ledger)
+    const int Tb = p.lens ? p.lens[__builtin_amdgcn_readfirstlane(b)] : p.T;
     const int K16 = p.K >> 4;
     const int S = SW > 0 ? SW : p.S;
     const int HL = p.HL;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int t = t0 - HL + s_c4[u] * 4 + e;
-                m |= (t >= 0 && t < p.T) ? (1u << e) : 0u;
+                m |= (t >= 0 && t < Tb) ? (1u << e) : 0u;
             }
             s_mask[u] = m;
         }
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
                             else if (STAGE == ST_LN) y = (y - mean[e]) * rstd[e];
                             else if (STAGE == ST_SCALE) y = y / p.in_scale;   // skip sum DIVIDED by sqrt(L) (wavenet.py:96)
                             else if (STAGE == ST_LRELU) y = y >= 0.f ? y : y * p.in_scale;   // F.leaky_relu on the input
-                            const bool ok = (t >= 0) && (t < p.T) && row_ok;
+                            const bool ok = (t >= 0) && (t < Tb) && row_ok;
                             o[e] = ok ? y : 0.f;       // zero padding applies AFTER the FiLM add (wavenet.py:36-38)
                         }
                         if (col_ok && r < kcn) *reinterpret_cast<f32x4*>(&lds[r * S + c4 * 4]) = o;

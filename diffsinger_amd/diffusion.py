@@ -207,9 +207,11 @@ class GaussianDiffusion(nn.Module, _SamplerMixin):
             return v.expand(m).contiguous() if v.numel() == 1 else v.contiguous()
         return v.reshape(f, 1).expand(f, m).reshape(-1).contiguous()
 
-    def forward(self, condition, gt_spec=None, src_spec=None, infer=True, *, noise=None, step_noise=None):
+    def forward(self, condition, gt_spec=None, src_spec=None, infer=True, *, noise=None, step_noise=None, lengths=None):
         """
             conditioning diffusion, use fastspeech2 encoder output as the condition
+            `lengths` [B]: ragged batch - item b is run as if alone at T = lengths[b] (dsd_set_lengths); frames beyond
+            an item's length are unspecified in the result.
         """
         cond = condition.transpose(1, 2)
         b, device = condition.shape[0], condition.device
@@ -222,7 +224,13 @@ class GaussianDiffusion(nn.Module, _SamplerMixin):
                 spec = spec[:, None, :, :]
         else:
             spec = None
-        x = self.inference(cond, b=b, x_start=spec, device=device, noise=noise, step_noise=step_noise, _denorm=True)
+        if lengths is not None:
+            self.denoise_fn.set_lengths(lengths, device)
+        try:
+            x = self.inference(cond, b=b, x_start=spec, device=device, noise=noise, step_noise=step_noise, _denorm=True)
+        finally:
+            if lengths is not None:
+                self.denoise_fn.set_lengths(None, device)
         return self._finish_denorm(x)
 
     def norm_spec(self, x):
@@ -401,7 +409,8 @@ class RectifiedFlow(nn.Module, _SamplerMixin):
             entry = self._cached_program(('noop',), lambda: schedule.Program(1, 0, []))
         return self._run_program(entry, cond, x, scale=scale, shift=shift)
 
-    def forward(self, condition, gt_spec=None, src_spec=None, infer=True, *, noise=None):
+    def forward(self, condition, gt_spec=None, src_spec=None, infer=True, *, noise=None, lengths=None):
+        """`lengths` [B]: ragged batch - item b is run as if alone at T = lengths[b] (dsd_set_lengths)."""
         cond = condition.transpose(1, 2)
         b, device = condition.shape[0], condition.device
         if not infer:
@@ -413,7 +422,13 @@ class RectifiedFlow(nn.Module, _SamplerMixin):
                 spec = spec[:, None, :, :]
         else:
             spec = None
-        x = self.inference(cond, b=b, x_end=spec, device=device, noise=noise, _denorm=True)
+        if lengths is not None:
+            self.velocity_fn.set_lengths(lengths, device)
+        try:
+            x = self.inference(cond, b=b, x_end=spec, device=device, noise=noise, _denorm=True)
+        finally:
+            if lengths is not None:
+                self.velocity_fn.set_lengths(None, device)
         return self._finish_denorm(x)
 
     def norm_spec(self, x):

@@ -75,13 +75,16 @@ class AcousticDecoder(nn.Module):
         else:
             raise NotImplementedError(self.diffusion_type)
 
-    def forward(self, condition, mel2ph, gt_mel=None, infer=True, **diffusion_kwargs) -> ShallowDiffusionOutput:
-        """toplevel.py:90-105 with `condition = self.fs2(...)` already evaluated."""
+    def forward(self, condition, mel2ph, gt_mel=None, infer=True, lengths=None, **diffusion_kwargs) -> ShallowDiffusionOutput:
+        """toplevel.py:90-105 with `condition = self.fs2(...)` already evaluated.  `lengths` [B] (ragged batch): every
+        utterance comes out as if it had been run alone at its own length (dsd_set_lengths)."""
         if not infer:
             raise NotImplementedError("training (toplevel.py:106-120) stays on the reference modules")
         mask = (mel2ph > 0).float()[:, :, None]
+        if lengths is not None:
+            diffusion_kwargs["lengths"] = lengths
         if self.use_shallow_diffusion:
-            aux_mel_pred = self.aux_decoder(condition, infer=True)
+            aux_mel_pred = self.aux_decoder(condition, infer=True, lengths=lengths)
             aux_mel_pred *= mask
             if gt_mel is not None and self.shallow_args['val_gt_start']:
                 src_mel = gt_mel
@@ -103,7 +106,7 @@ class DiffSingerAcoustic(AcousticDecoder):
         self._init_decoder(out_dims)
 
     def forward(self, txt_tokens, mel2ph, f0, key_shift=None, speed=None, spk_embed_id=None, languages=None,
-                gt_mel=None, infer=True, noise=None, step_noise=None, **kwargs) -> ShallowDiffusionOutput:
+                gt_mel=None, infer=True, noise=None, step_noise=None, lengths=None, **kwargs) -> ShallowDiffusionOutput:
         condition = self.fs2(txt_tokens, mel2ph, f0, key_shift=key_shift, speed=speed, spk_embed_id=spk_embed_id,
                              languages=languages, **kwargs)
         extra = {}
@@ -111,4 +114,4 @@ class DiffSingerAcoustic(AcousticDecoder):
             extra["noise"] = noise
         if step_noise is not None:
             extra["step_noise"] = step_noise
-        return AcousticDecoder.forward(self, condition, mel2ph, gt_mel=gt_mel, infer=infer, **extra)
+        return AcousticDecoder.forward(self, condition, mel2ph, gt_mel=gt_mel, infer=infer, lengths=lengths, **extra)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSD_API_VERSION 7
+#define DSD_API_VERSION 8
 
 /* error codes */
 #define DSD_OK 0
@@ -323,6 +323,18 @@ int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out);
 int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_m,
                int64_t stride_t, const float* f0, const float* rand_ini, const float* noise, const float* pre_noise,
                float* wav_out, void* stream);
+
+/*
+ * Ragged batches.  The reference runs one utterance per call (inference/ds_acoustic.py:214-271), because padding a batch
+ * changes results near the end of the shorter items: frames beyond an item's end are not zero after the first layer and
+ * leak into valid frames through every convolution along time.  With per-item lengths the library treats frames
+ * t >= lengths[b] of item b as the convolutions' zero padding - in the dilated convolutions of the WaveNet, the depthwise
+ * convolution of LYNXNet and the ConvNeXt aux decoder - so item b of a padded batch comes out as if it had been run alone
+ * at T = lengths[b] (outputs at its padded frames are unspecified), and several segments of a project can share one
+ * launch.  lengths: HOST array of B values (copied, stream-ordered); applies to the following dsd_prepare_cond / dsd_denoise
+ * / dsd_sample / dsd_aux_decode calls at batch size B until changed; NULL restores dense batches.
+ */
+int dsd_set_lengths(dsd_handle* h, const int32_t* lengths, int32_t B, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sampling programs.  Every sampler of the reference (ddpm.py:149-204,221-351 p_sample /
