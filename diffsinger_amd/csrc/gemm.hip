@@ -122,7 +122,10 @@ __device__ __forceinline__ void ring_load_s(f32x4& dst, unsigned voff, unsigned 
 // 17.4 -> 12.8 ms per 50-NFE utterance at T = 256).  WN = 1, NB = 2 - the same 64 x 32 tile with no weight block
 // streamed by two waves - was measured too: halving the weight traffic does not pay for doubling each wave's LDS
 // fragment reads (17.5 -> 18.8 ms at B = 1), so 32- and 64-frame tiles keep the 2 x 2 layout.
-template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2>
+// RAG = 1: ragged batch - the zero padding of a k-tap convolution's input starts at the item's own length p.lens[b].
+// A separate instantiation so that the dense kernels carry no trace of it (an always-present scalar load of the
+// length cost 1.3 % of the B = 1 loop, 4 % when placed in the staging loads' shadow).
+template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2, int RAG = 0>
 __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(WN == 2 || (WN == 1 && SW > 0 && EPI != EP_SWIGLU && STAGE != ST_LN), "4x1 wave layout: fast path only");
@@ -149,8 +152,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
     const int mtile = work - rest * p.mtiles;
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;
-    // zero padding of the convolution input ends at this item's own length (scalar load: off the vmcnt ledger)
-    const int Tb = p.lens ? p.lens[__builtin_amdgcn_readfirstlane(b)] : p.T;
+    const int Tb = RAG ? p.lens[__builtin_amdgcn_readfirstlane(b)] : p.T;      // scalar load: off the vmcnt ledger
     const int K16 = p.K >> 4;
     const int S = SW > 0 ? SW : p.S;
     const int HL = p.HL;
@@ -872,9 +874,9 @@ int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb, int resident)
     return ((resident ? 4 : 2) * gemm_fast_chunk_rows(taps, nb) * S + (stage == ST_LN ? 2 * 32 * (nb ? nb : 1) : 0)) * 4;
 }
 
-template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2>
+template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2, int RAG = 0>
 static hipError_t set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN, RAG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -887,15 +889,15 @@ void gemm_set_timing_events(hipEvent_t start, hipEvent_t stop) {
     g_ev_stop = stop;
 }
 
-template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2>
+template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2, int RAG = 0>
 static hipError_t launch_one(const GemmP& p, int batch, hipStream_t st) {
     const int lds = p.lds_bytes;
     dim3 grid(batch * p.tiles_per_b * p.mtiles, 1, 1);
     if (g_ev_start && g_ev_stop)
-        hipExtLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN>), grid, dim3(256), lds, st, g_ev_start,
+        hipExtLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN, RAG>), grid, dim3(256), lds, st, g_ev_start,
                               g_ev_stop, 0, p);
     else
-        hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN>), grid, dim3(256), lds, st, p);
+        hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN, RAG>), grid, dim3(256), lds, st, p);
     return hipGetLastError();
 }
 
@@ -932,6 +934,20 @@ static hipError_t dispatch(const GemmP& p, int nb, int fast, int batch, hipStrea
     if constexpr (TAPS == 3)
         if (fast && p.S == 112) return launch_one<STAGE, TAPS, EPI, 2, 112>(p, batch, st);
     return launch_one<STAGE, TAPS, EPI, 2, 0>(p, batch, st);
+}
+
+// the WaveNet's dilated convolution on a ragged batch: the same tile choices with the RAG = 1 instantiations
+static hipError_t dispatch_ragged_conv3(const GemmP& p, int nb, int fast, int batch, hipStream_t st) {
+    constexpr int S_ = ST_FILM, E_ = EP_GATE;
+    if (nb == 0) return (fast && p.S == 48) ? launch_one<S_, 3, E_, 1, 48, 0, 1, 1>(p, batch, st) : hipErrorInvalidValue;
+    if (nb == 1) {
+        if (fast && p.S == 48) return launch_one<S_, 3, E_, 1, 48, 0, 2, 1>(p, batch, st);
+        if (fast && p.S == 80) return launch_one<S_, 3, E_, 1, 80, 0, 2, 1>(p, batch, st);
+        return launch_one<S_, 3, E_, 1, 0, 0, 2, 1>(p, batch, st);
+    }
+    if (fast && p.S == 80) return launch_one<S_, 3, E_, 2, 80, 0, 2, 1>(p, batch, st);
+    if (fast && p.S == 112) return launch_one<S_, 3, E_, 2, 112, 0, 2, 1>(p, batch, st);
+    return launch_one<S_, 3, E_, 2, 0, 0, 2, 1>(p, batch, st);
 }
 
 template <int STAGE, int TAPS, int EPI>
@@ -976,6 +992,16 @@ hipError_t gemm_init_all() {
     if ((e = set_attr<ST_PLAIN, 1, EP_LYNX_NEXT, 2, 80>()) != hipSuccess) return e;
     if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0>()) != hipSuccess) return e;
     if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0>()) != hipSuccess) return e;
+    // ragged batches: the k-tap convolutions of the denoisers and the aux decoder
+    if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0, 0, 2, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0, 0, 2, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_FILM, 3, EP_GATE, 1, 48, 0, 1, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_FILM, 3, EP_GATE, 1, 48, 0, 2, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_FILM, 3, EP_GATE, 1, 80, 0, 2, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_FILM, 3, EP_GATE, 1, 0, 0, 2, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_FILM, 3, EP_GATE, 2, 80, 0, 2, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_FILM, 3, EP_GATE, 2, 112, 0, 2, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_FILM, 3, EP_GATE, 2, 0, 0, 2, 1>()) != hipSuccess) return e;
     // NSF-HiFiGAN: leaky-ReLU staged k-tap convs, residual epilogue, transposed-conv scatter (generic path only)
     if ((e = set_attr<ST_LRELU, 0, EP_BIAS_ACT, 1, 0>()) != hipSuccess) return e;
     if ((e = set_attr<ST_LRELU, 0, EP_BIAS_ACT, 2, 0>()) != hipSuccess) return e;
@@ -992,6 +1018,13 @@ hipError_t gemm_init_all() {
     if (stage == ST && taps == TP && epi == EP) return dispatch<ST, TP, EP>(p, nb, fast, batch, st);
 
 hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int fast, int batch, hipStream_t st) {
+    if (p.lens) {       // ragged batch: only the k-tap convolutions of the denoisers / aux decoder are asked for it
+        if (stage == ST_FILM && taps == 3 && epi == EP_GATE) return dispatch_ragged_conv3(p, nb, fast, batch, st);
+        if (stage == ST_PLAIN && epi == EP_BIAS_ACT && taps == p.taps && !fast && nb >= 1)
+            return nb == 1 ? launch_one<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0, 0, 2, 1>(p, batch, st)
+                           : launch_one<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0, 0, 2, 1>(p, batch, st);
+        return hipErrorInvalidValue;
+    }
     DSD_CASE(ST_PLAIN, 1, EP_BIAS_ACT)
     DSD_CASE(ST_SCALE, 1, EP_BIAS_ACT)
     DSD_CASE(ST_FILM, 3, EP_GATE)
