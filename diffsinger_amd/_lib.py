@@ -17,6 +17,7 @@ DSD_SRC_MODEL = -1
 DSD_SRC_NOISE_BASE = -1000
 DSD_SAMPLE_GRAPH = 1
 DSD_SAMPLE_TRANSPOSE = 2
+DSD_SAMPLE_GRAPH_LAZY = 4
 BACKBONE_IDS = {"wavenet": 0, "lynxnet": 1}
 AUX_CONVNEXT = 2
 ACT_IDS = {"PReLU": 0, "SiLU": 1, "ReLU": 2}

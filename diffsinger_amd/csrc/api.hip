@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <functional>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -104,7 +105,7 @@ struct dsd_handle {
     // workspace for (B, T)
     int B = 0, T = 0, Ts = 0;
     float* arena = nullptr;
-    size_t arena_floats = 0;
+    size_t arena_floats = 0, arena_cap = 0, state_cap = 0;
     float *cond_i = nullptr, *cp = nullptr, *xh = nullptr, *z = nullptr, *skip = nullptr, *hbuf = nullptr;
     float *xin = nullptr, *ubuf = nullptr, *vbuf = nullptr, *stats = nullptr, *lnpart = nullptr;
     float *io_in = nullptr, *io_out = nullptr;
@@ -124,6 +125,7 @@ struct dsd_handle {
     std::vector<float> t_host;
 
     std::map<std::string, GraphEntry> graphs;
+    std::set<std::string> graph_seen;      // programs run once eagerly: a graph is captured when one comes back
 
     // timing of the dominant kernel
     bool timing = false;
@@ -850,7 +852,7 @@ int build_packed(dsd_handle* h) {
 // ------------------------------------------------------------------------------------------
 constexpr size_t kGuard = 256;
 
-int ensure_workspace(dsd_handle* h, int B, int T) {
+int ensure_workspace(dsd_handle* h, int B, int T, hipStream_t st) {
     if (h->arena && h->B == B && h->T == T) return DSD_OK;
     // shape change: drop everything that depends on it
     for (auto& kv : h->graphs) {
@@ -858,11 +860,8 @@ int ensure_workspace(dsd_handle* h, int B, int T) {
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     h->graphs.clear();
-    if (h->arena) (void)hipFree(h->arena);
-    if (h->state) (void)hipFree(h->state);
-    h->arena = nullptr;
-    h->state = nullptr;
-    h->state_nbufs = 0;
+    h->graph_seen.clear();
+    h->state_nbufs = 0;          // the state buffers are re-carved for the new shape (ensure_state)
     h->cond_ready = false;
     const int Ts = padded_ts(T);
     const size_t C = C_of(h), FM = FM_of(h), H = h->cfg.hidden_size, L = L_of(h);
@@ -892,11 +891,19 @@ int ensure_workspace(dsd_handle* h, int B, int T) {
         o_lp = take(per * 2 * ((C + 63) / 64));
     }
     off += kGuard;
-    float* a = nullptr;
-    if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
-        return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the (B=%d, T=%d) workspace failed", off * 4, B, T);
+    // A project's segments all differ in length: keep the allocation while the new shape fits (hipFree + hipMalloc per
+    // segment is a device-wide synchronisation each), re-carve it, and clear it on the caller's stream.
+    float* a = h->arena;
+    if (!a || off > h->arena_cap) {
+        if (h->arena) (void)hipFree(h->arena);
+        h->arena = a = nullptr;
+        h->arena_cap = 0;
+        if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
+            return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the (B=%d, T=%d) workspace failed", off * 4, B, T);
+        h->arena_cap = off;
+    }
     // padding frames and guards are masked by every consumer, but start from finite values
-    if (hipMemset(a, 0, off * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(workspace) failed");
+    if (hipMemsetAsync(a, 0, off * sizeof(float), st) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(workspace) failed");
     h->arena = a;
     h->arena_floats = off;
     h->B = B; h->T = T; h->Ts = Ts;
@@ -906,16 +913,20 @@ int ensure_workspace(dsd_handle* h, int B, int T) {
     return DSD_OK;
 }
 
-int ensure_state(dsd_handle* h, int nbufs) {
+int ensure_state(dsd_handle* h, int nbufs, hipStream_t st) {
     if (h->state && h->state_nbufs >= nbufs) return DSD_OK;
-    if (h->state) (void)hipFree(h->state);
-    h->state = nullptr;
     const size_t per = ((size_t)h->B * FM_of(h) * h->Ts + 63) / 64 * 64 + 64;
     const size_t total = kGuard * 2 + per * nbufs;
-    float* s = nullptr;
-    if (hipMalloc(&s, total * sizeof(float)) != hipSuccess)
-        return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for %d sampler state buffers failed", total * 4, nbufs);
-    if (hipMemset(s, 0, total * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(state) failed");
+    float* s = h->state;
+    if (!s || total > h->state_cap) {
+        if (h->state) (void)hipFree(h->state);
+        h->state = s = nullptr;
+        h->state_cap = 0;
+        if (hipMalloc(&s, total * sizeof(float)) != hipSuccess)
+            return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for %d sampler state buffers failed", total * 4, nbufs);
+        h->state_cap = total;
+    }
+    if (hipMemsetAsync(s, 0, total * sizeof(float), st) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(state) failed");
     h->state = s;
     h->state_nbufs = nbufs;
     h->state_buf_floats = per;
@@ -925,6 +936,7 @@ int ensure_state(dsd_handle* h, int nbufs) {
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     h->graphs.clear();
+    h->graph_seen.clear();
     return DSD_OK;
 }
 inline float* state_buf(dsd_handle* h, int i) { return h->state + kGuard + h->state_buf_floats * i; }
@@ -938,6 +950,7 @@ int ensure_emb(dsd_handle* h, int ncols) {
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     h->graphs.clear();
+    h->graph_seen.clear();
     const int cap = round_up(ncols, 64);
     const int Ns = padded_ts(cap);
     const size_t C = C_of(h), L = L_of(h);
@@ -1199,6 +1212,7 @@ void destroy_graphs(dsd_handle* h) {
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
     h->graphs.clear();
+    h->graph_seen.clear();
 }
 
 }  // namespace
@@ -1351,7 +1365,7 @@ int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int
         return fail(h, DSD_EINVAL, "dsd_prepare_cond: cond must be contiguous along T ([B,H,T]) or along H ([B,T,H])");
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(h, hipSetDevice(h->cfg.device));
-    int rc = ensure_workspace(h, B, T);
+    int rc = ensure_workspace(h, B, T, st);
     if (rc) return rc;
     const int H = h->cfg.hidden_size, Ts = h->Ts, L = L_of(h), R = cp_rows(h);
     hipError_t e = launch_pack(cond, stride_b, stride_h, stride_t, h->cond_i, B, H, T, Ts, st);
@@ -1930,7 +1944,7 @@ int dsd_aux_decode(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64
         return fail(h, DSD_EINVAL, "dsd_aux_decode: cond must be contiguous along T ([B,H,T]) or along H ([B,T,H])");
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(h, hipSetDevice(h->cfg.device));
-    int rc = ensure_workspace(h, B, T);
+    int rc = ensure_workspace(h, B, T, st);
     if (rc) return rc;
     if ((rc = check_lens(h, "dsd_aux_decode", B, T))) return rc;
     const int H = h->cfg.hidden_size, Ts = h->Ts, L = L_of(h), C = C_of(h), M = FM_of(h);
@@ -2026,7 +2040,7 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
     }
     int rc = check_lens(h, "dsd_sample", B, T);
     if (rc) return rc;
-    if ((rc = ensure_state(h, prog->n_bufs))) return rc;
+    if ((rc = ensure_state(h, prog->n_bufs, st))) return rc;
     if (prog->n_evals > 0 && (rc = ensure_emb(h, prog->n_evals))) return rc;
 
     // x_T (or the shallow-diffusion start) -> state buffer 0
@@ -2083,6 +2097,13 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
         key.append((const char*)&noise, sizeof(noise));
         key.push_back(h->lens_host.empty() ? 'd' : 'r');       // dense / ragged: the kernels' length pointer differs
         auto it = h->graphs.find(key);
+        if (it == h->graphs.end() && (flags & DSD_SAMPLE_GRAPH_LAZY) && !h->graph_seen.count(key)) {
+            // DSD_SAMPLE_GRAPH_LAZY, first sight of this (program, batch shape): run it eagerly; the graph is built when the
+            // same key comes back
+            if (h->graph_seen.size() >= 64) h->graph_seen.clear();
+            h->graph_seen.insert(key);
+            if ((rc = body(st))) return rc;
+        } else {
         if (it == h->graphs.end()) {
             hipStream_t cs = nullptr;
             HIP_OK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -2109,6 +2130,7 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
             it = h->graphs.emplace(key, ge).first;
         }
         HIP_OK(h, hipGraphLaunch(it->second.exec, st));
+        }
     }
     e = launch_unpack(state_buf(h, prog->result_buf), Ts, out, B, h->cfg.n_feats, h->cfg.in_dims, T,
                       (flags & DSD_SAMPLE_TRANSPOSE) ? 1 : 0, (flags & DSD_SAMPLE_TRANSPOSE) ? out_scale : nullptr,

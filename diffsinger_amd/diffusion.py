@@ -33,7 +33,10 @@ def _spec_buffer(spec, out_dims):
 class _SamplerMixin:
     """Runs a schedule.Program on the backbone's native handle."""
 
-    use_graph = True            # replay the whole loop from a cached hipGraph
+    # hipGraph policy of the loop: "lazy" (default) = a (program, batch shape) runs eagerly the first time and is captured
+    # when it comes back (a project's segments all differ in length, and a capture costs about one loop); True = capture
+    # at first use (fixed shapes: benchmarks, servers with bucketed lengths); False = never
+    use_graph = "lazy"
     _ANCESTRAL_CHUNK = 50       # ancestral DDPM: steps per dsd_sample call (bounds the injected-noise tensor)
 
     def _backbone(self):
@@ -74,6 +77,8 @@ class _SamplerMixin:
             else:
                 out = torch.empty_like(x_init)
         flags = (_lib.DSD_SAMPLE_GRAPH if self.use_graph else 0) | (_lib.DSD_SAMPLE_TRANSPOSE if transpose else 0)
+        if self.use_graph == "lazy":
+            flags |= _lib.DSD_SAMPLE_GRAPH_LAZY
         nptr = None
         if prog.n_noise:
             noise = noise.to(torch.float32).contiguous()

@@ -279,18 +279,83 @@ class AcousticHarness:
         torch.manual_seed(value & 0xffff_ffff)
         torch.cuda.manual_seed_all(value & 0xffff_ffff)
 
-    def run_inference(self, params: List[dict], out_path=None, seed: int = -1, save_mel: bool = False):
+    # -- several segments in one launch (ragged batch) --------------------------------------------------------------
+    def _draw_noise(self, param, seed, t_len):
+        """x_T of one segment, drawn exactly as the model would draw it when run alone (same seeding, same call)."""
+        if 'seed' in param:
+            self._seed(param['seed'])
+        elif seed >= 0:
+            self._seed(seed)
+        d = self.model.diffusion
+        return torch.randn(1, d.num_feats, d.out_dims, t_len, device=self.device)
+
+    @torch.no_grad()
+    def forward_model_batch(self, samples, noises):
+        """`forward_model` for several segments at once: inputs zero-padded to the longest, per-segment lengths handed to
+        the library (dsd_set_lengths), so every mel equals the one the segment gives alone.  -> list of [1, T_i, M]."""
+        lens = [int(s['mel2ph'].size(1)) for s in samples]
+        t_max, n = max(lens), len(samples)
+
+        def pad_t(v, t_len):                         # [1, T_i or 1, ...] -> [1, t_max, ...]
+            if v.size(1) == 1 and t_len > 1:
+                v = v.expand(-1, t_len, *v.shape[2:])
+            return torch.nn.functional.pad(v, [0, 0] * (v.dim() - 2) + [0, t_max - v.size(1)])
+
+        l_max = max(int(s['tokens'].size(1)) for s in samples)
+        cat = lambda key, width: torch.cat([torch.nn.functional.pad(s[key], [0, width - s[key].size(1)]) for s in samples])  # noqa: E731
+        kwargs = {v: torch.cat([pad_t(s[v], t) for s, t in zip(samples, lens)]) for v in self.variances_to_embed}
+        if hparams['use_spk_id']:
+            mixes = []
+            for s, t in zip(samples, lens):
+                table = self.model.fs2.spk_embed(s['spk_mix_id'])
+                mixes.append(pad_t(torch.sum(table * s['spk_mix_value'].unsqueeze(3), dim=2, keepdim=False), t))
+            kwargs['spk_mix_embed'] = torch.cat(mixes)
+        else:
+            kwargs['spk_mix_embed'] = None
+        for key in ('key_shift', 'speed'):
+            kwargs[key] = torch.cat([pad_t(s[key], t) for s, t in zip(samples, lens)]) if samples[0].get(key) is not None else None
+        languages = cat('languages', l_max) if samples[0].get('languages') is not None else None
+        noise = torch.cat([torch.nn.functional.pad(z, [0, t_max - z.size(-1)]) for z in noises])
+        out = self.model(cat('tokens', l_max), languages=languages, mel2ph=cat('mel2ph', t_max), f0=cat('f0', t_max),
+                         infer=True, noise=noise, lengths=lens, **kwargs).diff_out
+        return [out[i:i + 1, :lens[i]] for i in range(n)]
+
+    def _batchable(self):
+        """A ragged batch reproduces the one-by-one results when x_T is the sampler's only random draw."""
+        d = getattr(self.model, 'diffusion', None)
+        if d is None or not hasattr(self.model, 'fs2'):
+            return False
+        if hasattr(d, 'velocity_fn'):
+            return True
+        return hparams.get('diff_accelerator') in ('ddim', 'pndm', 'dpm-solver', 'unipc') and hparams.get('diff_speedup', 1) > 1
+
+    def run_inference(self, params: List[dict], out_path=None, seed: int = -1, save_mel: bool = False, batch_size: int = 1):
         """One pass over the segments of a project: returns the assembled waveform (or the list of mels) and, when
         `out_path` is given, writes it.  Each segment is placed at its `offset`; where it overlaps what is already
-        there the two are cross-faded."""
+        there the two are cross-faded.  `batch_size` > 1 runs that many segments per launch of the acoustic model as
+        a ragged batch (same mels as one by one - the reference's order of operations, `ds_acoustic.py:214-271`,
+        `batch_size` = 1, is the default); the vocoder still takes them one at a time."""
         batches = [self.preprocess_input(param, idx=i) for i, param in enumerate(params)]
+        ready = {}
+        if batch_size > 1 and self._batchable():
+            noises = [self._draw_noise(p, seed, int(b['mel2ph'].size(1))) for p, b in zip(params, batches)]
+            order = sorted(range(len(params)), key=lambda i: -int(batches[i]['mel2ph'].size(1)))     # similar lengths together
+            for k in range(0, len(order), batch_size):
+                group = order[k:k + batch_size]
+                mels_g = self.forward_model_batch([batches[i] for i in group], [noises[i] for i in group])
+                ready.update(zip(group, mels_g))
         mels, track, cursor = [], np.zeros(0), 0
-        for param, batch in zip(params, batches):
-            if 'seed' in param:
-                self._seed(param['seed'])
-            elif seed >= 0:
-                self._seed(seed)
-            mel = self.forward_model(batch)
+        for i, (param, batch) in enumerate(zip(params, batches)):
+            if i in ready:
+                mel = ready[i]
+                if not save_mel:        # leave the generator where a lone run of this segment leaves it for the vocoder's draws
+                    self._draw_noise(param, seed, int(batch['mel2ph'].size(1)))
+            else:
+                if 'seed' in param:
+                    self._seed(param['seed'])
+                elif seed >= 0:
+                    self._seed(seed)
+                mel = self.forward_model(batch)
             if save_mel:
                 mels.append({'offset': param.get('offset', 0.), 'mel': mel.cpu(), 'f0': batch['f0'].cpu()})
                 continue

@@ -378,7 +378,11 @@ typedef struct dsd_program {
     const dsd_eval* evals;
 } dsd_program;
 
-#define DSD_SAMPLE_GRAPH 1u      /* replay the whole loop from a cached hipGraph */
+#define DSD_SAMPLE_GRAPH 1u      /* replay the whole loop from a cached hipGraph (captured at first use) */
+#define DSD_SAMPLE_GRAPH_LAZY 4u /* with DSD_SAMPLE_GRAPH: run a (program, batch shape) eagerly the first time and capture
+                                    its graph when it comes back - capture costs about one loop, and the segments of a
+                                    project all differ in length (8 segments of 480-1000 frames: 250 ms capturing each,
+                                    136 ms lazily) */
 #define DSD_SAMPLE_TRANSPOSE 2u  /* out is [B,T,M] (F == 1) or [B,F,T,M] and
                                     out = sample * out_scale[f*M+m] + out_shift[f*M+m]
                                     (x.transpose(2,3).squeeze(1) + denorm_spec, ddpm.py:350,382-383) */

@@ -124,3 +124,32 @@ def test_acoustic_decoder_ragged_equals_alone():
             assert close(out.aux_out[b:b + 1, :n], alone.aux_out), b
             assert close(out.diff_out[b:b + 1, :n], alone.diff_out), b
             assert float(out.diff_out[b, n:].abs().max() if n < t_max else 0.0) == 0.0      # the padding mask still applies
+
+
+def test_lazy_graph_policy_captures_on_second_use():
+    """The default hipGraph policy: a (program, shape) runs eagerly the first time and is captured when it comes back;
+    eager, captured and replayed runs give the same bits, and a new length does not pay for a capture."""
+    from diffsinger_amd.diffusion import GaussianDiffusion
+    args = dict(num_layers=4, num_channels=64, dilation_cycle_length=2)
+    set_hp(diff_accelerator="dpm-solver", diff_speedup=100, K_step_infer=1000)
+    d = GaussianDiffusion(32, 1, timesteps=1000, k_step=1000, backbone_type="wavenet", backbone_args=args,
+                          spec_min=[-8.0], spec_max=[0.0])
+    load_synth(d.denoise_fn, synth_params("wavenet", 32, 1, args, 60))
+    d = d.cuda().eval()
+    assert d.use_graph == "lazy"
+    cond = dev(synth.synth_normal((2, 90, 256), 3))
+    noise = dev(synth.synth_normal((2, 1, 32, 90), 4))
+    cached = lambda: d.denoise_fn.stats()["graphs_cached"]  # noqa: E731
+    with torch.no_grad():
+        first = d(cond, infer=True, noise=noise).clone()
+        assert cached() == 0
+        second = d(cond, infer=True, noise=noise).clone()
+        assert cached() == 1
+        third = d(cond, infer=True, noise=noise)
+        assert cached() == 1 and torch.equal(first, second) and torch.equal(first, third)
+        other = d(cond[:, :70].contiguous(), infer=True, noise=noise[..., :70].contiguous())     # a new length: eager again
+        assert cached() == 0 and tuple(other.shape) == (2, 70, 32)
+        d.use_graph = True
+        d(cond, infer=True, noise=noise)
+        assert cached() == 1                                # immediate capture when asked for
+    d.denoise_fn.release_native()

@@ -191,6 +191,15 @@ def test_ds_harness_segments_to_waveform(tmp_path):
         assert [tuple(m["mel"].shape) for m in mels] == [(1, f, 128) for f in frames]
         different = h.run_inference([dict(s, seed=s["seed"] + 1) for s in segs])
         assert not np.array_equal(track, different)
+        # all segments in ONE ragged batch of the acoustic model (dsd_set_lengths): the same mels, the same waveform
+        batched_mels = h.run_inference(segs, save_mel=True, batch_size=len(segs))
+        for a, b in zip(mels, batched_mels):
+            # not bit-equal: the padded batch takes other tile shapes through the encoder's GEMMs (fp32 rounding, 1e-6),
+            # which this random-weight model amplifies; a leak of padded frames would be an O(1) difference
+            assert float((a["mel"] - b["mel"]).abs().max()) <= 3e-4 * float(a["mel"].abs().max())
+        batched = h.run_inference(segs, batch_size=2)
+        assert batched.shape == track.shape and np.abs(batched - track).max() < 2e-2 and \
+            np.abs(batched - track).mean() < 1e-3
     finally:
         hparams.clear()
         hparams.update(saved)
