@@ -75,18 +75,35 @@ def gather_mels(mel_local: torch.Tensor, n_utt: int, dst: int = 0) -> Optional[t
     return None
 
 
-def sharded_sample(sample_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], cond_all, n_utt: int, t_len: int,
-                   hidden: int, noise_shape_per_utt, seed: int, device) -> Optional[torch.Tensor]:
+def sharded_sample(sample_fn: Callable[..., torch.Tensor], cond_all, n_utt: int, t_len: int,
+                   hidden: int, noise_shape_per_utt, seed: int, device, lengths=None) -> Optional[torch.Tensor]:
     """scatter cond -> per-rank sampling of its utterances -> gather mels on rank 0.
 
     sample_fn(cond [n, T, H], x_T [n, F, M, T]) -> mel [n, T, M] is the single-GPU path
-    (e.g. `lambda c, z: diffusion(c, infer=True, noise=z)`)."""
+    (e.g. `lambda c, z: diffusion(c, infer=True, noise=z)`).
+    `lengths` (rank 0: one frame count per utterance, padded to `t_len`): a ragged batch - the per-rank slice is handed on
+    as `sample_fn(cond, x_T, lengths=[...])` (`diffusion(..., lengths=...)`, dsd_set_lengths), so every utterance comes out
+    as if run alone at its own length whatever the number of ranks."""
     rank, world = dist.get_rank(), dist.get_world_size()
     mine = shard_ranges(n_utt, world)[rank]
+    kwargs = {}
+    if _any_rank_has(lengths is not None, device):       # every rank takes part in this broadcast
+        lens = torch.zeros(n_utt, dtype=torch.int64, device=device)
+        if rank == 0:
+            lens.copy_(torch.as_tensor(lengths, dtype=torch.int64))
+        dist.broadcast(lens, src=0)
+        kwargs["lengths"] = [int(v) for v in lens[mine.start:mine.stop].tolist()]
     cond = scatter_condition(cond_all, n_utt, t_len, hidden, device)
     noise = utterance_noise(noise_shape_per_utt, mine, seed, device)
     if len(mine):
-        mel = sample_fn(cond, noise)
+        mel = sample_fn(cond, noise, **kwargs)
     else:
         mel = torch.empty((0, t_len, noise_shape_per_utt[-2]), device=device)
     return gather_mels(mel, n_utt)
+
+
+def _any_rank_has(flag: bool, device) -> bool:
+    """True on every rank if `flag` is set on rank 0 (which is the one that holds the project's metadata)."""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=0)
+    return bool(int(t.item()))

@@ -83,3 +83,47 @@ def test_utterance_noise_independent_of_partition():
     a = sharding.utterance_noise((1, M, T), range(6), 5, torch.device("cpu"))
     b = torch.cat([sharding.utterance_noise((1, M, T), r, 5, torch.device("cpu")) for r in sharding.shard_ranges(6, 4)])
     assert torch.equal(a, b)
+
+
+def ragged_sampler(cond, noise, lengths):
+    out = fake_sampler(cond, noise)
+    for b, n in enumerate(lengths):         # what a ragged batch leaves meaningful: the item's own frames
+        out[b, n:] = -1.0
+    return out
+
+
+def _worker_ragged(rank, world, port, n_utt, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cond_all, _ = reference(n_utt, seed)
+        lens = [T - (3 * u) % T for u in range(n_utt)]
+        noise = sharding.utterance_noise((1, M, T), range(n_utt), seed, torch.device("cpu"))
+        want = ragged_sampler(cond_all, noise, lens)
+        out = sharding.sharded_sample(ragged_sampler, cond_all if rank == 0 else None, n_utt, T, H, (1, M, T), seed,
+                                      torch.device("cpu"), lengths=lens if rank == 0 else None)
+        if rank == 0:
+            q.put(("ok", bool(torch.equal(out, want)), tuple(out.shape)))
+    except Exception as e:  # pragma: no cover
+        if rank == 0:
+            q.put(("err", repr(e), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_utt", [(2, 5), (3, 4)])
+def test_sharded_ragged_lengths_reach_their_rank(world, n_utt):
+    """Ragged utterances: rank 0 alone knows the lengths; every rank must get the slice that belongs to its shard."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, n_utt, 78, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    status, same, shape = q.get()
+    assert status == "ok" and same and shape == (n_utt, T, M)
