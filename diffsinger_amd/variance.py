@@ -366,10 +366,12 @@ class DiffSingerVariance(ParameterAdaptorModule):
     def forward(self, txt_tokens, midi, ph2word, ph_dur=None, word_dur=None, mel2ph=None,
                 note_midi=None, note_rest=None, note_dur=None, note_glide=None, mel2note=None,
                 base_pitch=None, pitch=None, pitch_expr=None, pitch_retake=None,
-                variance_retake: Dict[str, torch.Tensor] = None, spk_id=None, languages=None, infer=True, **kwargs):
+                variance_retake: Dict[str, torch.Tensor] = None, spk_id=None, languages=None, infer=True, lengths=None,
+                **kwargs):
         """-> dur_pred [B, T_ph] | None, pitch_pred [B, T] | None, {name: [B, T]}.  Extra keywords: the current variance
         curves by name (`energy=...`), `ph_spk_mix_embed` / `spk_mix_embed`, and - for reproducible runs - the x_T of the
-        two denoisers, `pitch_noise` [B, 1, R, T] and `variance_noise` [B, F, R, T]."""
+        two denoisers, `pitch_noise` [B, 1, R, T] and `variance_noise` [B, F, R, T]; `lengths` [B] runs a zero-padded batch
+        of segments as a ragged batch (each comes out as if alone at its own frame count, dsd_set_lengths)."""
         _check_infer(self)
         if not infer:
             raise NotImplementedError("training (infer=False) stays on the reference DiffSingerVariance")
@@ -418,7 +420,7 @@ class DiffSingerVariance(ParameterAdaptorModule):
                     base_pitch = base_pitch * pitch_retake + pitch * ~pitch_retake
                 terms += lin1(self.base_pitch_embed, base_pitch)
             pitch_cond = assemble(bsz, t_len, h, gathers, terms, dev)
-            pitch_pred_out = self.pitch_predictor(pitch_cond, infer=True, noise=kwargs.get('pitch_noise'))
+            pitch_pred_out = self.pitch_predictor(pitch_cond, infer=True, noise=kwargs.get('pitch_noise'), lengths=lengths)
         if not self.predict_variances:
             return dur_pred_out, pitch_pred_out, {}
 
@@ -432,5 +434,5 @@ class DiffSingerVariance(ParameterAdaptorModule):
                 layer = self.variance_embeds[name]
                 terms += [(v_in * keep, layer.weight.reshape(-1)), (keep, layer.bias)]
         var_cond = assemble(bsz, t_len, h, cond_g, terms, dev)
-        outs = self.variance_predictor(var_cond, infer=True, noise=kwargs.get('variance_noise'))
+        outs = self.variance_predictor(var_cond, infer=True, noise=kwargs.get('variance_noise'), lengths=lengths)
         return dur_pred_out, pitch_pred_out, self.collect_variance_outputs(outs)

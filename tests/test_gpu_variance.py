@@ -195,3 +195,27 @@ def test_ds_project_completed_on_gpu(tmp_path):
     for m in model.modules():
         if hasattr(m, "release_native"):
             m.release_native()
+
+
+def test_variance_model_ragged_batch_equals_alone():
+    """Two segments of different length in one zero-padded batch with `lengths` (dsd_set_lengths) against the shorter one
+    run alone: phoneme mode, melody encoder, pitch loop (DDIM) - padded tokens, notes and frames all present."""
+    tag = "melody_ddim"
+    model, hp, _ = build(tag)
+    c = vc.CASES[tag]
+    inp = vc.case_inputs(tag)
+    n_short = 30
+    lens = [c["t_len"], n_short]
+    for key in ("mel2ph", "mel2note"):
+        inp[key][1, n_short:] = 0
+    nz, _ = noises(hp, c)
+    with torch.no_grad():
+        _, pitch, _ = model(infer=True, lengths=lens, **to_dev(inp), pitch_noise=dev(nz["pitch_noise"]))
+        alone = {k: (v[1:2, :n_short] if v.shape[-1] == c["t_len"] and k not in ("txt_tokens", "midi", "ph2word", "ph_dur", "languages")
+                     else v[1:2]) for k, v in inp.items()}
+        _, pitch1, _ = model(infer=True, **to_dev(alone), pitch_noise=dev(nz["pitch_noise"][1:2, :, :, :n_short]))
+    a, b = pitch[1:2, :n_short].cpu().numpy(), pitch1.cpu().numpy()
+    assert a.shape == b.shape and np.abs(a - b).max() < 5e-5 * max(1.0, np.abs(b).max())
+    for m in model.modules():
+        if hasattr(m, "release_native"):
+            m.release_native()
