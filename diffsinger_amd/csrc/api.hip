@@ -105,7 +105,7 @@ struct dsd_handle {
     // workspace for (B, T)
     int B = 0, T = 0, Ts = 0;
     float* arena = nullptr;
-    size_t arena_floats = 0, arena_cap = 0, state_cap = 0;
+    size_t arena_floats = 0, arena_cap = 0, state_cap = 0, e_cap = 0, v_cap = 0;
     float *cond_i = nullptr, *cp = nullptr, *xh = nullptr, *z = nullptr, *skip = nullptr, *hbuf = nullptr;
     float *xin = nullptr, *ubuf = nullptr, *vbuf = nullptr, *stats = nullptr, *lnpart = nullptr;
     float *io_in = nullptr, *io_out = nullptr;
@@ -1419,11 +1419,9 @@ int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out) {
 
 // workspace of an encoder pass over (B, L): x, y [H], qkv [3H], mid [4H], nonpad, dur (+ two [Cd] buffers and one [H]
 // input buffer for the duration predictor)
-static int enc_workspace(dsd_handle* h, int B, int L, int H, int Cd) {
+static int enc_workspace(dsd_handle* h, int B, int L, int H, int Cd, hipStream_t st) {
     const int Ls = padded_ts(L);
     if (h->e_arena && h->eB == B && h->eL == L && h->dC == Cd) return DSD_OK;
-    if (h->e_arena) (void)hipFree(h->e_arena);
-    h->e_arena = nullptr;
     const size_t per = (size_t)B * Ls;
     size_t off = kGuard;
     auto take = [&](size_t n) {
@@ -1435,10 +1433,16 @@ static int enc_workspace(dsd_handle* h, int B, int L, int H, int Cd) {
     const size_t o_np = take(per), o_dur = take((size_t)B * L);
     const size_t o_da = take(per * Cd), o_db = take(per * Cd), o_di = take(Cd > 0 ? per * H : 0);
     off += kGuard;
-    float* a = nullptr;
-    if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
-        return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the encoder workspace failed", off * 4);
-    if (hipMemset(a, 0, off * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(encoder workspace) failed");
+    float* a = h->e_arena;      // kept while the new shape fits (every segment of a project has its own token count)
+    if (!a || off > h->e_cap) {
+        if (h->e_arena) (void)hipFree(h->e_arena);
+        h->e_arena = a = nullptr;
+        h->e_cap = 0;
+        if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
+            return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the encoder workspace failed", off * 4);
+        h->e_cap = off;
+    }
+    if (hipMemsetAsync(a, 0, off * sizeof(float), st) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(encoder workspace) failed");
     h->e_arena = a;
     h->eB = B; h->eL = L; h->eLs = Ls; h->dC = Cd;
     h->e_x = a + o_x; h->e_y = a + o_y; h->e_qkv = a + o_qkv; h->e_mid = a + o_mid; h->e_nonpad = a + o_np;
@@ -1508,7 +1512,7 @@ int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, 
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(h, hipSetDevice(e.device));
     const int H = e.hidden_size, Ls = padded_ts(L);
-    int rc = enc_workspace(h, B, L, H, 0);
+    int rc = enc_workspace(h, B, L, H, 0, st);
     if (rc) return rc;
     const float* blob = h->blob;
     hipError_t er;
@@ -1607,7 +1611,7 @@ int dsd_token_encode(dsd_handle* h, const float* embed, const uint8_t* padding_m
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(h, hipSetDevice(t.device));
     const int H = t.hidden_size;
-    if ((rc = enc_workspace(h, B, L, H, t.dur_layers > 0 ? t.dur_chans : 0))) return rc;
+    if ((rc = enc_workspace(h, B, L, H, t.dur_layers > 0 ? t.dur_chans : 0, st))) return rc;
     const int Ls = h->eLs;
     hipError_t er;
 #define ENC_OK(expr, what)                                                                        \
@@ -1642,7 +1646,7 @@ int dsd_predict_dur(dsd_handle* h, const float* dur_cond, const uint8_t* padding
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(h, hipSetDevice(t.device));
     const int H = t.hidden_size, Cd = t.dur_chans;
-    if ((rc = enc_workspace(h, B, L, H, Cd))) return rc;
+    if ((rc = enc_workspace(h, B, L, H, Cd, st))) return rc;
     const int Ls = h->eLs;
     const float* blob = h->blob;
     hipError_t er;
@@ -1795,8 +1799,6 @@ int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t st
     for (int i = 0; i < NU; ++i) len[i + 1] = len[i] * v.upsample_rates[i];
     for (int i = 0; i <= NU; ++i) lts[i] = padded_ts((int)len[i]);
     if (!h->v_arena || h->vB != B || h->vT != T) {
-        if (h->v_arena) (void)hipFree(h->v_arena);
-        h->v_arena = nullptr;
         size_t off = kGuard;
         auto take = [&](size_t n) {
             size_t o = off;
@@ -1811,10 +1813,16 @@ int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t st
             for (int k = 0; k < 4; ++k) ob.push_back(take(n));
         }
         off += kGuard;
-        float* a = nullptr;
-        if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
-            return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the vocoder workspace failed", off * 4);
-        if (hipMemset(a, 0, off * sizeof(float)) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(vocoder workspace) failed");
+        float* a = h->v_arena;      // kept while the new shape fits: half a gigabyte per 1000 frames is not re-made per segment
+        if (!a || off > h->v_cap) {
+            if (h->v_arena) (void)hipFree(h->v_arena);
+            h->v_arena = a = nullptr;
+            h->v_cap = 0;
+            if (hipMalloc(&a, off * sizeof(float)) != hipSuccess)
+                return fail(h, DSD_ENOMEM, "hipMalloc of %zu bytes for the vocoder workspace failed", off * 4);
+            h->v_cap = off;
+        }
+        if (hipMemsetAsync(a, 0, off * sizeof(float), st) != hipSuccess) return fail(h, DSD_EHIP, "hipMemset(vocoder workspace) failed");
         h->v_arena = a;
         h->vB = B; h->vT = T;
         h->v_mel = a + o_mel; h->v_pre_out = a + o_pre; h->v_har = a + o_har; h->v_phase = a + o_ph; h->v_wav = a + o_wav;
