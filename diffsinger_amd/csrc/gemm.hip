@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int Tb = RAG ? p.lens[__builtin_amdgcn_readfirstlane(b)] : p.T;      // scalar load: off the vmcnt ledger
+    if (RAG && t0 >= Tb) return;       // a tile of nothing but this item's padding: its outputs are never read
     const int K16 = p.K >> 4;
     const int S = SW > 0 ? SW : p.S;
     const int HL = p.HL;
