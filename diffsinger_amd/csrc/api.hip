@@ -1,5 +1,18 @@
 // libdsdenoise C-ABI (include/dsdenoise.h): handle, weight re-layout, workspace, backbone launch
 // sequences (WaveNet / LYNXNet), sampling-program executor and hipGraph cache.  gfx950 only.
+//
+// Map of this file (one translation unit: every entry point shares the handle, the packed-weight blob and make_gemm):
+//   handle + host tensors ............ struct dsd_handle, expected_params*(): the state-dict layouts the library accepts
+//   weight re-layout ................. pack_gemm (MFMA fragment order), build_packed{,_aux,_enc,_tok,_voc}
+//   workspaces ....................... ensure_workspace / ensure_state / ensure_emb (kept across shape changes)
+//   GEMM launch decisions ............ make_gemm (tile width, fast / generic path, ragged lengths), run_gemm
+//   denoiser ......................... run_step_tables, run_backbone (WaveNet 43 kernels, LYNXNet), dsd_create ...
+//                                      dsd_prepare_cond, dsd_denoise, dsd_sample (+ hipGraph cache), dsd_set_lengths
+//   acoustic encoder ................. dsd_encoder_create, enc_workspace, run_fs2_layers, dsd_encode
+//   variance-model encoders .......... dsd_token_encoder_create, dsd_token_encode, dsd_predict_dur, dsd_cond_assemble
+//   vocoder .......................... run_tconv, dsd_vocoder_create, dsd_vocode
+//   aux decoder ...................... dsd_aux_decode
+//   diagnostics ...................... dsd_get_stats, dsd_kernel_timing*
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
