@@ -127,6 +127,12 @@ struct dsd_handle {
     int* lens_dev = nullptr;
     int lens_cap = 0;
     std::vector<int> lens_host;
+    // ... and, per tile width (16 / 32 / 64 frames), the list of column groups (item, frame tile) with valid frames
+    int* cg_dev[3] = {nullptr, nullptr, nullptr};
+    int cg_cap[3] = {0, 0, 0}, cg_n[3] = {0, 0, 0};
+    std::vector<int> cg_host[3];
+    int cg_T = -1;                  // the T the lists were built for (-1: stale)
+    bool use_cg = false;            // set around the launch sequences that may skip padded tiles
     // sampler state buffers
     float* state = nullptr;
     int state_nbufs = 0;
@@ -169,13 +175,45 @@ int fail(dsd_handle* h, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(h, DSD_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-// ragged batch bookkeeping: the lengths given by dsd_set_lengths must describe this call's batch
-inline int check_lens(dsd_handle* h, const char* who, int B, int T) {
+void destroy_graphs(dsd_handle* h);
+
+// the launch sequences that may skip padded tiles (denoiser evaluations, aux decoder) run inside one of these
+struct RaggedScope {
+    dsd_handle* h;
+    explicit RaggedScope(dsd_handle* hh) : h(hh) { h->use_cg = true; }
+    ~RaggedScope() { h->use_cg = false; }
+};
+
+// ragged batch bookkeeping: the lengths given by dsd_set_lengths must describe this call's batch; the lists of valid
+// column groups are (re)built here, on the caller's stream and outside any graph capture
+inline int check_lens(dsd_handle* h, const char* who, int B, int T, hipStream_t st) {
     if (h->lens_host.empty()) return DSD_OK;
     if ((int)h->lens_host.size() != B)
         return fail(h, DSD_ESTATE, "%s: dsd_set_lengths gave %zu lengths but this call runs a batch of %d", who, h->lens_host.size(), B);
     for (int v : h->lens_host)
         if (v > T) return fail(h, DSD_EINVAL, "%s: a length (%d) exceeds T = %d", who, v, T);
+    if (h->cg_T == T) return DSD_OK;
+    for (int k = 0; k < 3; ++k) {
+        const int BN = k == 0 ? 16 : 32 * k, tiles = (T + BN - 1) / BN;
+        std::vector<int>& v = h->cg_host[k];
+        v.clear();
+        for (int b = 0; b < B; ++b)
+            for (int ft = 0; ft * BN < h->lens_host[b]; ++ft) v.push_back(b * tiles + ft);
+        h->cg_n[k] = (int)v.size();
+        if ((int)v.size() > h->cg_cap[k]) {
+            if (h->cg_dev[k]) (void)hipFree(h->cg_dev[k]);
+            h->cg_dev[k] = nullptr;
+            h->cg_cap[k] = 0;
+            const size_t cap = (size_t)B * tiles;
+            if (hipMalloc(&h->cg_dev[k], sizeof(int) * cap) != hipSuccess)
+                return fail(h, DSD_ENOMEM, "%s: hipMalloc of %zu tile indices failed", who, cap);
+            h->cg_cap[k] = (int)cap;
+            destroy_graphs(h);      // cached graphs captured the old pointer
+        }
+        if (!v.empty() && hipMemcpyAsync(h->cg_dev[k], v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice, st) != hipSuccess)
+            return fail(h, DSD_EHIP, "%s: upload of the valid-tile list failed", who);
+    }
+    h->cg_T = T;
     return DSD_OK;
 }
 
@@ -1015,7 +1053,8 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     p.in_scale = 1.f;
     // ragged batches: only a convolution along time can carry an item's padded frames into its valid ones, so only the
     // k-tap GEMMs over the utterances' (B, T) frames mask their input (not the 1x1s, not the step-embedding MLPs)
-    p.lens = (!h->lens_host.empty() && g.taps > 1 && batch == h->B && T == h->T) ? h->lens_dev : nullptr;
+    const bool ragged = h->use_cg && !h->lens_host.empty() && batch == h->B && T == h->T;
+    p.lens = (ragged && g.taps > 1) ? h->lens_dev : nullptr;
     c.stage = stage;
     c.taps = g.taps;
     c.epi = epi;
@@ -1041,6 +1080,10 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     }
     const int BN = c.nb == 0 ? 16 : 32 * c.nb;
     p.tiles_per_b = (T + BN - 1) / BN;
+    if (ragged) {       // the launch covers only the tiles that hold valid frames (lists built by prepare_ragged)
+        p.cgmap = h->cg_dev[c.nb];
+        p.ncg = h->cg_n[c.nb];
+    }
     int S = BN + 2 * p.HL;
     while (S % 32 != 16) S += 4;
     p.S = S;
@@ -1101,6 +1144,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
     const int B = h->B, T = h->T, Ts = h->Ts, C = C_of(h), FM = FM_of(h), L = L_of(h), Ns = h->Ns;
     const long xs = (long)C * Ts;
     int rc;
+    RaggedScope ragged_scope(h);
     // only every timing_stride-th launch of the dominant kernel carries events (a dispatch with profiling events
     // costs the command processor more than a plain one; sampling keeps the pass close to the untimed pace)
     bool timed_now = false;
@@ -1296,6 +1340,8 @@ void dsd_destroy(dsd_handle* h) {
     if (h->state) (void)hipFree(h->state);
     if (h->emb_arena) (void)hipFree(h->emb_arena);
     if (h->lens_dev) (void)hipFree(h->lens_dev);
+    for (int k = 0; k < 3; ++k)
+        if (h->cg_dev[k]) (void)hipFree(h->cg_dev[k]);
     if (h->e_arena) (void)hipFree(h->e_arena);
     if (h->v_arena) (void)hipFree(h->v_arena);
     delete h;
@@ -1967,7 +2013,8 @@ int dsd_aux_decode(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64
     HIP_OK(h, hipSetDevice(h->cfg.device));
     int rc = ensure_workspace(h, B, T, st);
     if (rc) return rc;
-    if ((rc = check_lens(h, "dsd_aux_decode", B, T))) return rc;
+    if ((rc = check_lens(h, "dsd_aux_decode", B, T, st))) return rc;
+    RaggedScope ragged_scope(h);
     const int H = h->cfg.hidden_size, Ts = h->Ts, L = L_of(h), C = C_of(h), M = FM_of(h);
     const long xs = (long)C * Ts, us = (long)4 * C * Ts;
     hipError_t e = launch_pack(cond, stride_b, stride_h, stride_t, h->cond_i, B, H, T, Ts, st);
@@ -2011,7 +2058,7 @@ int dsd_denoise(dsd_handle* h, const float* x, const float* t, int32_t t_len, fl
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int B = h->B, T = h->T, Ts = h->Ts, FM = FM_of(h);
-    int rc = check_lens(h, "dsd_denoise", B, T);
+    int rc = check_lens(h, "dsd_denoise", B, T, st);
     if (rc) return rc;
     if ((rc = ensure_emb(h, t_len))) return rc;
     HIP_OK(h, hipMemcpyAsync(h->t_dev, t, sizeof(float) * t_len, hipMemcpyDeviceToDevice, st));
@@ -2059,7 +2106,7 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
             }
         }
     }
-    int rc = check_lens(h, "dsd_sample", B, T);
+    int rc = check_lens(h, "dsd_sample", B, T, st);
     if (rc) return rc;
     if ((rc = ensure_state(h, prog->n_bufs, st))) return rc;
     if (prog->n_evals > 0 && (rc = ensure_emb(h, prog->n_evals))) return rc;
@@ -2116,7 +2163,8 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
         std::string key((const char*)prog->evals, sizeof(dsd_eval) * prog->n_evals);
         key.append((const char*)&prog->n_bufs, sizeof(int32_t));
         key.append((const char*)&noise, sizeof(noise));
-        key.push_back(h->lens_host.empty() ? 'd' : 'r');       // dense / ragged: the kernels' length pointer differs
+        key.push_back(h->lens_host.empty() ? 'd' : 'r');       // dense / ragged: other kernels, and grids that follow
+        for (int v : h->lens_host) key.append((const char*)&v, sizeof(v));      // the lengths (baked into the launches)
         auto it = h->graphs.find(key);
         if (it == h->graphs.end() && (flags & DSD_SAMPLE_GRAPH_LAZY) && !h->graph_seen.count(key)) {
             // DSD_SAMPLE_GRAPH_LAZY, first sight of this (program, batch shape): run it eagerly; the graph is built when the
@@ -2182,6 +2230,7 @@ int dsd_set_lengths(dsd_handle* h, const int32_t* lengths, int32_t B, void* stre
         destroy_graphs(h);      // cached graphs captured the old pointer
     }
     h->lens_host.assign(lengths, lengths + B);
+    h->cg_T = -1;               // the valid-tile lists follow the lengths
     // stream-ordered behind earlier launches that still read the old values
     HIP_OK(h, hipMemcpyAsync(h->lens_dev, h->lens_host.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, (hipStream_t)stream));
     return DSD_OK;

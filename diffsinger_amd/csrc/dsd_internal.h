@@ -88,6 +88,10 @@ struct GemmP {
     // ragged batches: item b is valid on [0, lens[b]) and zero-padded beyond, as if it were run alone at T = lens[b]
     // (nullptr: every item is valid on [0, T))
     const int* lens;
+    // ragged batches, continued: the launch covers only the column groups (item b, frame tile ft) that hold valid frames;
+    // cgmap[i] = b * tiles_per_b + ft of the i-th of them, ncg their number (nullptr: all batch * tiles_per_b of them)
+    const int* cgmap;
+    int ncg;
     float* out2;
     const float* cpn;
     long cpn_bstride;

@@ -122,9 +122,10 @@ __device__ __forceinline__ void ring_load_s(f32x4& dst, unsigned voff, unsigned 
 // 17.4 -> 12.8 ms per 50-NFE utterance at T = 256).  WN = 1, NB = 2 - the same 64 x 32 tile with no weight block
 // streamed by two waves - was measured too: halving the weight traffic does not pay for doubling each wave's LDS
 // fragment reads (17.5 -> 18.8 ms at B = 1), so 32- and 64-frame tiles keep the 2 x 2 layout.
-// RAG = 1: ragged batch - the zero padding of a k-tap convolution's input starts at the item's own length p.lens[b].
-// A separate instantiation so that the dense kernels carry no trace of it (an always-present scalar load of the
-// length cost 1.3 % of the B = 1 loop, 4 % when placed in the staging loads' shadow).
+// RAG = 1: ragged batch.  The grid covers only the column groups (item, frame tile) that hold valid frames - p.cgmap
+// lists them, p.ncg of them - and the zero padding of a k-tap convolution's input starts at the item's own length
+// p.lens[b].  Separate instantiations so that the dense kernels carry no trace of it (an always-present scalar load of
+// the length cost 1.3 % of the B = 1 loop, 4 % when placed in the staging loads' shadow).
 template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2, int RAG = 0>
 __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -148,12 +149,12 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int rest = fdiv_floor(work, p.inv_mtiles);
-    const int mtile = work - rest * p.mtiles;
+    const int rest0 = fdiv_floor(work, p.inv_mtiles);
+    const int mtile = work - rest0 * p.mtiles;
+    const int rest = RAG ? p.cgmap[__builtin_amdgcn_readfirstlane(rest0)] : rest0;     // scalar loads: off the vmcnt ledger
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;
-    const int Tb = RAG ? p.lens[__builtin_amdgcn_readfirstlane(b)] : p.T;      // scalar load: off the vmcnt ledger
-    if (RAG && t0 >= Tb) return;       // a tile of nothing but this item's padding: its outputs are never read
+    const int Tb = (RAG && p.lens) ? p.lens[__builtin_amdgcn_readfirstlane(b)] : p.T;
     const int K16 = p.K >> 4;
     const int S = SW > 0 ? SW : p.S;
     const int HL = p.HL;
@@ -893,7 +894,8 @@ void gemm_set_timing_events(hipEvent_t start, hipEvent_t stop) {
 template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2, int RAG = 0>
 static hipError_t launch_one(const GemmP& p, int batch, hipStream_t st) {
     const int lds = p.lds_bytes;
-    dim3 grid(batch * p.tiles_per_b * p.mtiles, 1, 1);
+    dim3 grid((RAG ? p.ncg : batch * p.tiles_per_b) * p.mtiles, 1, 1);
+    if (grid.x == 0) return hipSuccess;          // a ragged batch of empty items
     if (g_ev_start && g_ev_stop)
         hipExtLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN, RAG>), grid, dim3(256), lds, st, g_ev_start,
                               g_ev_stop, 0, p);
@@ -910,67 +912,53 @@ bool gemm_has_fast(int taps, int nb, int S) {
     return S == 80 || (taps == 3 && S == 112);
 }
 
-template <int STAGE, int TAPS, int EPI>
+template <int STAGE, int TAPS, int EPI, int RAG = 0>
 static hipError_t dispatch(const GemmP& p, int nb, int fast, int batch, hipStream_t st) {
     if constexpr (STAGE != ST_LN && EPI != EP_SWIGLU) {
         if (nb == 0) {      // narrow tiles: fast path only (the host never asks for them otherwise)
             if constexpr (TAPS == 1) {
-                if (fast == 2 && p.S == 16) return launch_one<STAGE, TAPS, EPI, 1, 16, 1, 1>(p, batch, st);
-                if (fast && p.S == 16) return launch_one<STAGE, TAPS, EPI, 1, 16, 0, 1>(p, batch, st);
+                if (fast == 2 && p.S == 16) return launch_one<STAGE, TAPS, EPI, 1, 16, 1, 1, RAG>(p, batch, st);
+                if (fast && p.S == 16) return launch_one<STAGE, TAPS, EPI, 1, 16, 0, 1, RAG>(p, batch, st);
             } else {
-                if (fast && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48, 0, 1>(p, batch, st);
+                if (fast && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48, 0, 1, RAG>(p, batch, st);
             }
             return hipErrorInvalidValue;
         }
     }
     if (nb == 1) {
         if constexpr (TAPS == 1)        // resident variant: 1x1 GEMMs only (measured: no gain for the k=3 conv)
-            if (fast == 2 && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48, 1>(p, batch, st);
-        if (fast && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48>(p, batch, st);
+            if (fast == 2 && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48, 1, 2, RAG>(p, batch, st);
+        if (fast && p.S == 48) return launch_one<STAGE, TAPS, EPI, 1, 48, 0, 2, RAG>(p, batch, st);
         if constexpr (TAPS == 3)
-            if (fast && p.S == 80) return launch_one<STAGE, TAPS, EPI, 1, 80>(p, batch, st);
-        return launch_one<STAGE, TAPS, EPI, 1, 0>(p, batch, st);
+            if (fast && p.S == 80) return launch_one<STAGE, TAPS, EPI, 1, 80, 0, 2, RAG>(p, batch, st);
+        return launch_one<STAGE, TAPS, EPI, 1, 0, 0, 2, RAG>(p, batch, st);
     }
-    if (fast && p.S == 80) return launch_one<STAGE, TAPS, EPI, 2, 80>(p, batch, st);
+    if (fast && p.S == 80) return launch_one<STAGE, TAPS, EPI, 2, 80, 0, 2, RAG>(p, batch, st);
     if constexpr (TAPS == 3)
-        if (fast && p.S == 112) return launch_one<STAGE, TAPS, EPI, 2, 112>(p, batch, st);
-    return launch_one<STAGE, TAPS, EPI, 2, 0>(p, batch, st);
+        if (fast && p.S == 112) return launch_one<STAGE, TAPS, EPI, 2, 112, 0, 2, RAG>(p, batch, st);
+    return launch_one<STAGE, TAPS, EPI, 2, 0, 0, 2, RAG>(p, batch, st);
 }
 
-// the WaveNet's dilated convolution on a ragged batch: the same tile choices with the RAG = 1 instantiations
-static hipError_t dispatch_ragged_conv3(const GemmP& p, int nb, int fast, int batch, hipStream_t st) {
-    constexpr int S_ = ST_FILM, E_ = EP_GATE;
-    if (nb == 0) return (fast && p.S == 48) ? launch_one<S_, 3, E_, 1, 48, 0, 1, 1>(p, batch, st) : hipErrorInvalidValue;
-    if (nb == 1) {
-        if (fast && p.S == 48) return launch_one<S_, 3, E_, 1, 48, 0, 2, 1>(p, batch, st);
-        if (fast && p.S == 80) return launch_one<S_, 3, E_, 1, 80, 0, 2, 1>(p, batch, st);
-        return launch_one<S_, 3, E_, 1, 0, 0, 2, 1>(p, batch, st);
-    }
-    if (fast && p.S == 80) return launch_one<S_, 3, E_, 2, 80, 0, 2, 1>(p, batch, st);
-    if (fast && p.S == 112) return launch_one<S_, 3, E_, 2, 112, 0, 2, 1>(p, batch, st);
-    return launch_one<S_, 3, E_, 2, 0, 0, 2, 1>(p, batch, st);
-}
-
-template <int STAGE, int TAPS, int EPI>
+template <int STAGE, int TAPS, int EPI, int RAG = 0>
 static hipError_t attr_all() {
     hipError_t e;
     if constexpr (STAGE != ST_LN && EPI != EP_SWIGLU) {
         if constexpr (TAPS == 1) {
-            if ((e = set_attr<STAGE, TAPS, EPI, 1, 16, 1, 1>()) != hipSuccess) return e;
-            if ((e = set_attr<STAGE, TAPS, EPI, 1, 16, 0, 1>()) != hipSuccess) return e;
+            if ((e = set_attr<STAGE, TAPS, EPI, 1, 16, 1, 1, RAG>()) != hipSuccess) return e;
+            if ((e = set_attr<STAGE, TAPS, EPI, 1, 16, 0, 1, RAG>()) != hipSuccess) return e;
         } else {
-            if ((e = set_attr<STAGE, TAPS, EPI, 1, 48, 0, 1>()) != hipSuccess) return e;
+            if ((e = set_attr<STAGE, TAPS, EPI, 1, 48, 0, 1, RAG>()) != hipSuccess) return e;
         }
     }
-    if ((e = set_attr<STAGE, TAPS, EPI, 1, 0>()) != hipSuccess) return e;
-    if ((e = set_attr<STAGE, TAPS, EPI, 2, 0>()) != hipSuccess) return e;
-    if ((e = set_attr<STAGE, TAPS, EPI, 1, 48>()) != hipSuccess) return e;
+    if ((e = set_attr<STAGE, TAPS, EPI, 1, 0, 0, 2, RAG>()) != hipSuccess) return e;
+    if ((e = set_attr<STAGE, TAPS, EPI, 2, 0, 0, 2, RAG>()) != hipSuccess) return e;
+    if ((e = set_attr<STAGE, TAPS, EPI, 1, 48, 0, 2, RAG>()) != hipSuccess) return e;
     if constexpr (TAPS == 1)
-        if ((e = set_attr<STAGE, TAPS, EPI, 1, 48, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<STAGE, TAPS, EPI, 2, 80>()) != hipSuccess) return e;
+        if ((e = set_attr<STAGE, TAPS, EPI, 1, 48, 1, 2, RAG>()) != hipSuccess) return e;
+    if ((e = set_attr<STAGE, TAPS, EPI, 2, 80, 0, 2, RAG>()) != hipSuccess) return e;
     if constexpr (TAPS == 3) {
-        if ((e = set_attr<STAGE, TAPS, EPI, 1, 80>()) != hipSuccess) return e;
-        if ((e = set_attr<STAGE, TAPS, EPI, 2, 112>()) != hipSuccess) return e;
+        if ((e = set_attr<STAGE, TAPS, EPI, 1, 80, 0, 2, RAG>()) != hipSuccess) return e;
+        if ((e = set_attr<STAGE, TAPS, EPI, 2, 112, 0, 2, RAG>()) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -993,16 +981,22 @@ hipError_t gemm_init_all() {
     if ((e = set_attr<ST_PLAIN, 1, EP_LYNX_NEXT, 2, 80>()) != hipSuccess) return e;
     if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0>()) != hipSuccess) return e;
     if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0>()) != hipSuccess) return e;
-    // ragged batches: the k-tap convolutions of the denoisers and the aux decoder
+    // ragged batches (RAG = 1): every GEMM of the denoisers and of the aux decoder
+    if ((e = attr_all<ST_PLAIN, 1, EP_BIAS_ACT, 1>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_SCALE, 1, EP_BIAS_ACT, 1>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_FILM, 3, EP_GATE, 1>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_PLAIN, 1, EP_RESSKIP, 1>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_PLAIN, 1, EP_LINCOMB, 1>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_LN, 1, EP_SWIGLU, 1>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_PLAIN, 1, EP_BIAS_RES, 1>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_LN, 1, EP_LINCOMB, 1>()) != hipSuccess) return e;
+    if ((e = attr_all<ST_LN, 1, EP_BIAS_ACT, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 1, EP_LYNX_NEXT, 1, 0, 0, 2, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 1, EP_LYNX_NEXT, 2, 0, 0, 2, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 1, EP_LYNX_NEXT, 1, 48, 0, 2, 1>()) != hipSuccess) return e;
+    if ((e = set_attr<ST_PLAIN, 1, EP_LYNX_NEXT, 2, 80, 0, 2, 1>()) != hipSuccess) return e;
     if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0, 0, 2, 1>()) != hipSuccess) return e;
     if ((e = set_attr<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0, 0, 2, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<ST_FILM, 3, EP_GATE, 1, 48, 0, 1, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<ST_FILM, 3, EP_GATE, 1, 48, 0, 2, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<ST_FILM, 3, EP_GATE, 1, 80, 0, 2, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<ST_FILM, 3, EP_GATE, 1, 0, 0, 2, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<ST_FILM, 3, EP_GATE, 2, 80, 0, 2, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<ST_FILM, 3, EP_GATE, 2, 112, 0, 2, 1>()) != hipSuccess) return e;
-    if ((e = set_attr<ST_FILM, 3, EP_GATE, 2, 0, 0, 2, 1>()) != hipSuccess) return e;
     // NSF-HiFiGAN: leaky-ReLU staged k-tap convs, residual epilogue, transposed-conv scatter (generic path only)
     if ((e = set_attr<ST_LRELU, 0, EP_BIAS_ACT, 1, 0>()) != hipSuccess) return e;
     if ((e = set_attr<ST_LRELU, 0, EP_BIAS_ACT, 2, 0>()) != hipSuccess) return e;
@@ -1019,9 +1013,26 @@ hipError_t gemm_init_all() {
     if (stage == ST && taps == TP && epi == EP) return dispatch<ST, TP, EP>(p, nb, fast, batch, st);
 
 hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int fast, int batch, hipStream_t st) {
-    if (p.lens) {       // ragged batch: only the k-tap convolutions of the denoisers / aux decoder are asked for it
-        if (stage == ST_FILM && taps == 3 && epi == EP_GATE) return dispatch_ragged_conv3(p, nb, fast, batch, st);
-        if (stage == ST_PLAIN && epi == EP_BIAS_ACT && taps == p.taps && !fast && nb >= 1)
+    if (p.cgmap) {      // ragged batch: the same choices with the RAG = 1 instantiations
+#define DSD_CASE_R(ST, TP, EP) \
+        if (stage == ST && taps == TP && epi == EP) return dispatch<ST, TP, EP, 1>(p, nb, fast, batch, st);
+        DSD_CASE_R(ST_PLAIN, 1, EP_BIAS_ACT)
+        DSD_CASE_R(ST_SCALE, 1, EP_BIAS_ACT)
+        DSD_CASE_R(ST_FILM, 3, EP_GATE)
+        DSD_CASE_R(ST_PLAIN, 1, EP_RESSKIP)
+        DSD_CASE_R(ST_PLAIN, 1, EP_LINCOMB)
+        DSD_CASE_R(ST_LN, 1, EP_SWIGLU)
+        DSD_CASE_R(ST_PLAIN, 1, EP_BIAS_RES)
+        DSD_CASE_R(ST_LN, 1, EP_LINCOMB)
+        DSD_CASE_R(ST_LN, 1, EP_BIAS_ACT)
+#undef DSD_CASE_R
+        if (stage == ST_PLAIN && taps == 1 && epi == EP_LYNX_NEXT && nb >= 1) {
+            if (nb == 1) return (fast && p.S == 48) ? launch_one<ST_PLAIN, 1, EP_LYNX_NEXT, 1, 48, 0, 2, 1>(p, batch, st)
+                                                    : launch_one<ST_PLAIN, 1, EP_LYNX_NEXT, 1, 0, 0, 2, 1>(p, batch, st);
+            return (fast && p.S == 80) ? launch_one<ST_PLAIN, 1, EP_LYNX_NEXT, 2, 80, 0, 2, 1>(p, batch, st)
+                                       : launch_one<ST_PLAIN, 1, EP_LYNX_NEXT, 2, 0, 0, 2, 1>(p, batch, st);
+        }
+        if (stage == ST_PLAIN && epi == EP_BIAS_ACT && taps == p.taps && !fast && nb >= 1)       // aux decoder's k-tap convs
             return nb == 1 ? launch_one<ST_PLAIN, 0, EP_BIAS_ACT, 1, 0, 0, 2, 1>(p, batch, st)
                            : launch_one<ST_PLAIN, 0, EP_BIAS_ACT, 2, 0, 0, 2, 1>(p, batch, st);
         return hipErrorInvalidValue;
