@@ -696,6 +696,27 @@ def g5_config1_pndm50():
 
 
 
+def time_reference_cpu():
+    """Not a fixture: the reference's own PyTorch modules timed on THIS container's CPU cores at the headline
+    configuration (WaveNet 20x256, DPM-Solver++ 1000 -> 50, B = 1, T = 1000) - the number DESIGN.md quotes beside the numpy
+    port that bench.py times on the GPU box (the reference itself cannot travel there)."""
+    import time
+    set_hp(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    d = _build_gd(128, 1, args, 42)
+    cond = to_t(synth.synth_normal((1, 1000, 256), 0))
+    with torch.no_grad():
+        d(cond, infer=True)
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            d(cond, infer=True)
+        dt = (time.perf_counter() - t0) / n
+    print(f"reference (PyTorch {torch.__version__}, {torch.get_num_threads()} threads): {dt:.2f} s per utterance, "
+          f"{1000 * 50 / dt / 1e3:.1f} k mel-frames/s per denoise step")
+
+
+
 # --------------------------------------------------------------------------- G12: DiffSingerVariance, tokens -> dur / pitch / variances
 def g12_variance_model():
     """The reference's own top-level variance model (modules/toplevel.py:125-309), infer branch, small nets; configurations
@@ -914,6 +935,8 @@ if __name__ == "__main__":
         g9_acoustic_model()
     if "g10" in which:
         g10_vocoder()
+    if "time" in which:
+        time_reference_cpu()
     if "g5c1" in which:
         g5_config1_pndm50()
     if "g12" in which:
