@@ -216,6 +216,71 @@ class VarianceHarness(AcousticHarness):
             pitch = sample['base_pitch'] + pitch
         return dur, pitch, variances
 
+    # -- several segments in one launch (ragged batch) --------------------------------------------------------------
+    def _draw_noises(self, param, seed, flag, t_len):
+        """x_T of the two loops for one segment, drawn as the model draws them when the segment runs alone."""
+        if 'seed' in param:
+            self._seed(param['seed'])
+        elif seed >= 0:
+            self._seed(seed)
+        out = {}
+        if flag[1]:
+            d = self.model.pitch_predictor
+            out['pitch_noise'] = torch.randn(1, d.num_feats, d.out_dims, t_len, device=self.device)
+        if flag[2]:
+            d = self.model.variance_predictor
+            out['variance_noise'] = torch.randn(1, d.num_feats, d.out_dims, t_len, device=self.device)
+        return out
+
+    @staticmethod
+    def _signature(flag, batch):
+        """Segments can share a launch when the same predictors run on the same kinds of inputs."""
+        return flag, tuple(sorted(k for k, v in batch.items() if v is not None))
+
+    @torch.no_grad()
+    def forward_model_batch(self, samples, noises):
+        """`forward_model` for several segments with one signature: inputs padded to the longest (notes with the padding
+        marker -1), frame counts handed on as `lengths` (dsd_set_lengths) -> per segment what `forward_model` returns."""
+        pad = torch.nn.functional.pad
+        lens = [int(s['base_pitch'].size(1)) for s in samples]
+        t_max = max(lens)
+
+        def cat(key, value=0, t_axis=False):
+            if samples[0].get(key) is None:
+                return None
+            rows = []
+            for s, t in zip(samples, lens):
+                v = s[key]
+                if t_axis and v.size(1) == 1 and t > 1:            # a constant given as [1, 1]
+                    v = v.expand(-1, t, *v.shape[2:])
+                rows.append(v)
+            width = max(int(r.size(1)) for r in rows)
+            return torch.cat([pad(r, [0, 0] * (r.dim() - 2) + [0, width - r.size(1)], value=value) for r in rows])
+
+        kwargs = dict(ph_spk_mix_embed=None, spk_mix_embed=None)
+        if hparams['use_spk_id']:
+            for key, n_of in (('ph_spk_mix', lambda s: int(s['tokens'].size(1))), ('spk_mix', lambda s: int(s['base_pitch'].size(1)))):
+                rows = []
+                for s in samples:
+                    table = self.model.spk_embed(s[key + '_id'])
+                    e = torch.sum(table * s[key + '_value'].unsqueeze(3), dim=2, keepdim=False)
+                    rows.append(e.expand(-1, n_of(s), -1) if e.size(1) == 1 else e)
+                width = max(int(r.size(1)) for r in rows)
+                kwargs[key + '_embed'] = torch.cat([pad(r, [0, 0, 0, width - r.size(1)]) for r in rows])
+        noise = {k: torch.cat([pad(z[k], [0, t_max - z[k].size(-1)]) for z in noises]) for k in noises[0]}
+        dur, pitch, variances = self.model(
+            cat('tokens'), languages=cat('languages'), midi=cat('midi'), ph2word=cat('ph2word'), ph_dur=cat('ph_dur'),
+            mel2ph=cat('mel2ph'), word_dur=cat('word_dur'), note_midi=cat('note_midi', value=-1.), note_rest=cat('note_rest'),
+            note_dur=cat('note_dur'), note_glide=cat('note_glide'), mel2note=cat('mel2note'), base_pitch=cat('base_pitch'),
+            pitch=cat('pitch'), pitch_expr=cat('expr', t_axis=True), infer=True, lengths=lens, **kwargs, **noise)
+        out = []
+        for i, (s, t) in enumerate(zip(samples, lens)):
+            n_ph = int(s['tokens'].size(1))
+            d = None if dur is None else self.rr(dur[i:i + 1, :n_ph], s['ph2word'], s['word_dur'])
+            p = None if pitch is None else s['base_pitch'] + pitch[i:i + 1, :t]
+            out.append((d, p, {k: v[i:i + 1, :t] for k, v in variances.items()}))
+        return out
+
     def infer_once(self, param):
         dur, pitch, variances = self.forward_model(self.preprocess_input(param))
         dur = None if dur is None else dur[0].cpu().numpy()
@@ -235,26 +300,50 @@ class VarianceHarness(AcousticHarness):
         dur = m.predict_dur and (self.global_predict_dur or (param.get('ph_dur') is None and (pitch or variances)))
         return dur, pitch, variances
 
-    def run_inference(self, params: List[dict], out_dir=None, title: str = None, num_runs: int = 1, seed: int = -1):
-        """-> the completed projects (one list of segments per run); written to `out_dir/title[-NNN].ds` when given."""
+    def _with_flags(self, flag, fn):
+        m = self.model
+        saved = (m.fs2.predict_dur, m.predict_pitch, m.predict_variances)
+        m.fs2.predict_dur, m.predict_pitch, m.predict_variances = flag
+        try:
+            return fn()
+        finally:
+            m.fs2.predict_dur, m.predict_pitch, m.predict_variances = saved
+
+    def run_inference(self, params: List[dict], out_dir=None, title: str = None, num_runs: int = 1, seed: int = -1,
+                      batch_size: int = 1):
+        """-> the completed projects (one list of segments per run); written to `out_dir/title[-NNN].ds` when given.
+        `batch_size` > 1: segments on which the same predictors run on the same kinds of inputs share a launch as a ragged
+        batch (same predictions as one by one, which is the reference's order and the default)."""
         flags = [self._flags(p) for p in params]
         batches = [self.preprocess_input(p, idx=i, load_dur=not f[0] and (f[1] or f[2]), load_pitch=not f[1] and f[2])
                    for i, (p, f) in enumerate(zip(params, flags))]
-        m, runs = self.model, []
+        runs = []
         for run in range(num_runs):
+            ready = {}
+            if batch_size > 1 and hasattr(self.model, 'fs2') and hasattr(self.model.fs2, 'native_handle'):
+                groups = {}
+                for i, (f, b) in enumerate(zip(flags, batches)):
+                    groups.setdefault(self._signature(f, b), []).append(i)
+                for (flag, _), members in groups.items():
+                    members.sort(key=lambda i: -int(batches[i]['base_pitch'].size(1)))       # similar lengths together
+                    for k in range(0, len(members), batch_size):
+                        part = members[k:k + batch_size]
+                        if len(part) < 2:
+                            continue
+                        noises = [self._draw_noises(params[i], seed, flag, int(batches[i]['base_pitch'].size(1))) for i in part]
+                        got = self._with_flags(flag, lambda: self.forward_model_batch([batches[i] for i in part], noises))
+                        ready.update(zip(part, got))
             results = []
-            for param, flag, batch in zip(params, flags, batches):
-                if 'seed' in param:
-                    self._seed(param['seed'])
-                elif seed >= 0:
-                    self._seed(seed)
+            for i, (param, flag, batch) in enumerate(zip(params, flags, batches)):
                 done = copy.deepcopy(param)
-                saved = (m.fs2.predict_dur, m.predict_pitch, m.predict_variances)
-                m.fs2.predict_dur, m.predict_pitch, m.predict_variances = flag
-                try:
-                    dur, pitch, variances = self.forward_model(batch)
-                finally:
-                    m.fs2.predict_dur, m.predict_pitch, m.predict_variances = saved
+                if i in ready:
+                    dur, pitch, variances = ready[i]
+                else:
+                    if 'seed' in param:
+                        self._seed(param['seed'])
+                    elif seed >= 0:
+                        self._seed(seed)
+                    dur, pitch, variances = self._with_flags(flag, lambda: self.forward_model(batch))
                 if dur is not None and (self.auto_completion_mode or self.global_predict_dur):
                     seconds = (dur[0].cpu().numpy() * self.timestep).tolist()
                     done['ph_dur'] = ' '.join(str(round(d, 6)) for d in seconds)

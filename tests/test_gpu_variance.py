@@ -192,6 +192,20 @@ def test_ds_project_completed_on_gpu(tmp_path):
         if "f0_seq" not in src:
             f0 = np.array(done["f0_seq"].split(), float)
             assert len(f0) == frames and np.isfinite(f0).all() and (f0 > 20).all() and (f0 < 5000).all()
+    # segments with the same predictors and kinds of inputs (here the first and the last) share a launch as a ragged batch
+    seen = []
+    fmb = h.forward_model_batch
+    h.forward_model_batch = lambda samples, noises: (seen.append(len(samples)), fmb(samples, noises))[1]
+    c = h.run_inference(copy.deepcopy(segs), seed=5, batch_size=4)[0]
+    assert seen == [2]
+    for one, bat in zip(a, c):
+        assert one.keys() == bat.keys()
+        for key in one:
+            if key in ("ph_dur", "f0_seq", "energy", "breathiness") and isinstance(one[key], str):
+                x, y = np.array(one[key].split(), float), np.array(bat[key].split(), float)
+                assert x.shape == y.shape and np.abs(x - y).max() <= 2e-3 * max(1.0, np.abs(x).max()), key
+            else:
+                assert one[key] == bat[key], key
     for m in model.modules():
         if hasattr(m, "release_native"):
             m.release_native()
