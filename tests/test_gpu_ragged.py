@@ -153,3 +153,27 @@ def test_lazy_graph_policy_captures_on_second_use():
         d(cond, infer=True, noise=noise)
         assert cached() == 1                                # immediate capture when asked for
     d.denoise_fn.release_native()
+
+
+@pytest.mark.parametrize("bsz,t_max", [(2, 90), (6, 200), (32, 300)])
+def test_ragged_in_every_tile_regime(bsz, t_max):
+    """16-, 32- and 64-frame tiles each have their own list of valid tiles (the tile width follows the size of the launch):
+    small, medium and large batches, lengths on, just below and just above tile boundaries, one single-frame item."""
+    set_hp()
+    args = dict(num_layers=6, num_channels=128, dilation_cycle_length=3)
+    net, _ = make_backbone("wavenet", 64, 1, args, 51)
+    rng = np.random.Generator(np.random.PCG64(bsz))
+    special = [t_max, 64, 63, 65, 1, 128, 127, 129, 32, 33, 16, 17]
+    lens = [min(v, t_max) for v in special[:bsz]] + [int(v) for v in rng.integers(1, t_max + 1, max(0, bsz - len(special)))]
+    x = dev(synth.synth_normal((bsz, 1, 64, t_max), 7))
+    cond = dev(synth.synth_normal((bsz, 256, t_max), 8))
+    t = dev(np.linspace(5.0, 995.0, bsz).astype(np.float32))
+    with torch.no_grad():
+        net.set_lengths(lens, x.device)
+        ragged = net(x, t, cond).clone()
+        net.set_lengths(None, x.device)
+        for b in (range(bsz) if bsz <= 6 else list(range(12)) + [bsz - 1]):
+            n = lens[b]
+            alone = net(x[b:b + 1, :, :, :n].contiguous(), t[b:b + 1], cond[b:b + 1, :, :n].contiguous())
+            assert close(ragged[b:b + 1, :, :, :n], alone), (bsz, b, n)
+    net.release_native()
