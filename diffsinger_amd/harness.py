@@ -95,6 +95,55 @@ def length_regulator(dur: torch.Tensor, dur_padding: Optional[torch.Tensor] = No
     return torch.where(frames < ends[:, -1:], owner, torch.zeros_like(owner))
 
 
+# --------------------------------------------------------------------------------------------------- checkpoints
+def load_ckpt(model, ckpt_base_dir, ckpt_steps: Optional[int] = None, prefix_in_ckpt: Optional[str] = 'model',
+              ignored_prefixes: Optional[Sequence[str]] = None, key_in_ckpt: Optional[str] = 'state_dict', strict: bool = True,
+              device='cpu') -> pathlib.Path:
+    """The reference's checkpoint convention (`utils/__init__.py:165-222`): a `.ckpt` file, or a work directory whose
+    `model_ckpt_steps_<N>.ckpt` with the highest N (or N = `ckpt_steps`) is taken; the weights sit under `state_dict`
+    with a `model.` prefix.  Read with `torch.load(weights_only=True)`: nothing from the file is executed.  -> the path."""
+    import re
+    from collections import OrderedDict
+    base = pathlib.Path(ckpt_base_dir)
+    ignored = ['model.fs2.encoder.embed_tokens'] if ignored_prefixes is None else list(ignored_prefixes)   # old duplicates
+    if base.is_file():
+        path = base
+    elif ckpt_steps is not None:
+        path = base / f'model_ckpt_steps_{int(ckpt_steps)}.ckpt'
+    else:
+        found = sorted((f for f in base.iterdir() if f.is_file() and re.fullmatch(r'model_ckpt_steps_\d+\.ckpt', f.name)),
+                       key=lambda f: int(re.search(r'\d+', f.name).group(0)))
+        assert len(found) > 0, f'| ckpt not found in {base}.'
+        path = found[-1]
+    loaded = torch.load(path, map_location=device, weights_only=True)
+    category = getattr(model, 'category', None)
+    if category is not None and isinstance(loaded, dict) and loaded.get('category') not in (None, category):
+        raise RuntimeError(f"Category mismatches! The checkpoint is of the category '{loaded.get('category')}', "
+                           f"but a checkpoint of category '{category}' is required.")
+    state = loaded if key_in_ckpt is None else loaded[key_in_ckpt]
+    if prefix_in_ckpt is not None:
+        state = OrderedDict((k[len(prefix_in_ckpt) + 1:], v) for k, v in state.items()
+                            if k.startswith(f'{prefix_in_ckpt}.') and not any(k.startswith(p) for p in ignored))
+    if not strict:
+        own = model.state_dict()
+        for key in [k for k, v in state.items() if k in own and own[k].shape != v.shape]:
+            del state[key]
+    model.load_state_dict(state, strict=strict)
+    return path
+
+
+def load_vocoder(model_path, device='cuda'):
+    """`modules/nsf_hifigan/models.py:18-33` + `modules/vocoders/nsf_hifigan.py:18-37`: `config.json` next to the generator
+    checkpoint, weights under 'generator' (weight norm folded on load) -> vocoder.NsfHifiGAN."""
+    from .vocoder import Generator, NsfHifiGAN
+    model_path = pathlib.Path(model_path)
+    with open(model_path.with_name('config.json')) as f:
+        h = json.load(f)
+    gen = Generator(h)
+    gen.load_state_dict(torch.load(model_path, map_location='cpu', weights_only=True)['generator'], strict=True)
+    return NsfHifiGAN(gen.to(device).eval(), mel_base=hparams.get('mel_base', '10'))
+
+
 class SimplePhonemeTable:
     """Single-dictionary phoneme table: ids 1..N over the sorted phoneme set (AP and SP always present), 0 = padding."""
 

@@ -100,3 +100,62 @@ def test_save_wav_roundtrip(tmp_path):
     assert sr == 44100 and data.dtype == np.int16 and np.array_equal(data, (wav * 32767).astype(np.int16))
     table = harness.SimplePhonemeTable(["x", "y"])
     assert len(table) == 5 and table.encode("SP x zh/y AP") == [2, 3, 4, 1]
+
+
+def test_load_ckpt_follows_the_reference_convention(tmp_path):
+    """work_dir/model_ckpt_steps_<N>.ckpt, weights under state_dict with a `model.` prefix, highest N unless asked for
+    another, old duplicate embeddings ignored, category checked, non-strict loading drops shape mismatches."""
+    import torch.nn as nn
+    from diffsinger_amd import harness
+
+    class Net(nn.Module):
+        category = 'acoustic'
+
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(3, 2)
+
+    def ckpt(step, scale, category='acoustic', extra=None):
+        sd = {'model.a.weight': torch.full((2, 3), float(scale)), 'model.a.bias': torch.zeros(2),
+              'model.fs2.encoder.embed_tokens.weight': torch.ones(4, 4), 'other.x': torch.ones(1)}
+        sd.update(extra or {})
+        torch.save({'state_dict': sd, 'category': category, 'global_step': step}, tmp_path / f'model_ckpt_steps_{step}.ckpt')
+
+    ckpt(100, 1.0)
+    ckpt(2000, 2.0)
+    net = Net()
+    assert harness.load_ckpt(net, tmp_path).name == 'model_ckpt_steps_2000.ckpt' and float(net.a.weight.detach()[0, 0]) == 2.0
+    assert harness.load_ckpt(net, tmp_path, ckpt_steps=100).name == 'model_ckpt_steps_100.ckpt' and float(net.a.weight.detach()[0, 0]) == 1.0
+    harness.load_ckpt(net, tmp_path / 'model_ckpt_steps_2000.ckpt')
+    assert float(net.a.weight.detach()[0, 0]) == 2.0
+    ckpt(3000, 3.0, category='variance')
+    with pytest.raises(RuntimeError, match="Category mismatches"):
+        harness.load_ckpt(net, tmp_path)
+    ckpt(4000, 4.0, extra={'model.a.bias': torch.zeros(5)})
+    with pytest.raises(RuntimeError):
+        harness.load_ckpt(net, tmp_path)
+    harness.load_ckpt(net, tmp_path, strict=False)
+    assert float(net.a.weight.detach()[0, 0]) == 4.0
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    with pytest.raises(AssertionError, match="ckpt not found"):
+        harness.load_ckpt(net, empty)
+
+
+def test_load_vocoder_reads_config_and_generator_weights(tmp_path):
+    """`config.json` beside the generator checkpoint, weights under 'generator' (models.py:18-33) - the openvpi release
+    layout; the file is read with weights_only=True."""
+    from diffsinger_amd import synth
+    from diffsinger_amd.vocoder import NsfHifiGAN
+    h = dict(synth.NSF_HIFIGAN_DEFAULT, num_mels=32, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4],
+             upsample_initial_channel=64, resblock="2", resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2], [2, 6]])
+    with open(tmp_path / "config.json", "w") as f:
+        json.dump(h, f)
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(synth.nsf_hifigan_param_shapes(h), seed=9).items()}
+    torch.save({"generator": sd}, tmp_path / "model.ckpt")
+    hparams.clear()
+    hparams.update(mel_base="e")
+    voc = harness.load_vocoder(tmp_path / "model.ckpt", device="cpu")
+    assert isinstance(voc, NsfHifiGAN) and voc.mel_base == "e"
+    got = voc.model.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
