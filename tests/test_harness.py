@@ -159,3 +159,27 @@ def test_load_vocoder_reads_config_and_generator_weights(tmp_path):
     assert isinstance(voc, NsfHifiGAN) and voc.mel_base == "e"
     got = voc.model.state_dict()
     assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+
+
+def test_load_config_resolves_the_base_config_chain(tmp_path):
+    """base.yaml <- model.yaml (relative to the root, as the reference's `configs/...` paths are) <- exp/config.yaml ('.'-
+    relative); later files win key by key through nested dicts; a saved complete config loads as is; overrides last."""
+    import importlib
+    hp_mod = importlib.import_module("diffsinger_amd.hparams")
+    (tmp_path / "configs").mkdir()
+    (tmp_path / "exp").mkdir()
+    (tmp_path / "configs" / "base.yaml").write_text(
+        "hidden_size: 256\nuse_pos_embed: true\nbackbone_args:\n  num_layers: 20\n  num_channels: 256\nK_step: 1000\n")
+    (tmp_path / "configs" / "model.yaml").write_text(
+        "base_config:\n  - configs/base.yaml\nbackbone_args:\n  num_channels: 512\nuse_rope: true\n")
+    (tmp_path / "exp" / "local.yaml").write_text("K_step: 400\n")
+    (tmp_path / "exp" / "config.yaml").write_text(
+        "base_config: [configs/model.yaml, ./local.yaml, configs/base.yaml]\nbackbone_args:\n  dilation_cycle_length: 4\n")
+    cfg = hp_mod.load_config("exp/config.yaml", root=tmp_path, overrides={"infer": True, "backbone_args": {"num_layers": 10}})
+    assert cfg["hidden_size"] == 256 and cfg["use_rope"] is True and cfg["K_step"] == 400 and cfg["infer"] is True
+    assert cfg["backbone_args"] == {"num_layers": 10, "num_channels": 512, "dilation_cycle_length": 4}
+    assert hp_mod.hparams["backbone_args"]["num_channels"] == 512          # the process-global dict was refilled
+    (tmp_path / "saved.yaml").write_text("hidden_size: 128\nspec_min: [-12.0]\n")
+    assert hp_mod.load_config(tmp_path / "saved.yaml", update_global=False) == {"hidden_size": 128, "spec_min": [-12.0]}
+    assert hp_mod.hparams["hidden_size"] == 256
+    hp_mod.hparams.clear()
