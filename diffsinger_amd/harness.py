@@ -424,3 +424,150 @@ class AcousticHarness:
             else:
                 save_wav(result, out_path, hparams['audio_sample_rate'])
         return result
+
+
+class PhonemeDictionary:
+    """The phoneme <-> token-id table of a (possibly multilingual) model, built like `utils/phoneme_utils.py:10-176` from
+    the pronunciation dictionaries (`word<TAB>ph ph ...` per line), the extra phonemes and the merged phoneme groups of the
+    configuration: AP and SP always exist; with more than one language a dictionary phoneme is named `lang/ph` (an extra
+    phoneme keeps the name it is given); ids run from 1 over the SORTED names, and the phonemes of a merged group share
+    the id of the first of them met in that order; a phoneme is cross-lingual when its group spans languages."""
+
+    def __init__(self, dictionaries: Dict[str, "pathlib.Path"], extra_phonemes: Optional[Sequence[str]] = None,
+                 merged_groups: Optional[Sequence[Sequence[str]]] = None):
+        names = {'AP', 'SP'}
+        for ph in extra_phonemes or ():
+            if '/' in ph:
+                lang, short = ph.split('/', maxsplit=1)
+                if lang not in dictionaries:
+                    raise ValueError(f"Invalid phoneme tag '{ph}' in extra phonemes: unrecognized language name '{lang}'.")
+                if short in names:
+                    raise ValueError(f"Invalid phoneme tag '{ph}' in extra phonemes: short name conflicts with existing tag.")
+            names.add(ph)
+        self._multi_langs = len(dictionaries) > 1
+        for lang, path in dictionaries.items():
+            with open(path, 'r', encoding='utf8') as f:
+                for line in f:
+                    _, phones = line.strip().split('\t')
+                    for ph in phones.split():
+                        if '/' in ph:
+                            raise ValueError(f"Invalid phoneme tag '{ph}' in dictionary '{path}': "
+                                             f"should not contain the reserved character '/'.")
+                        if ph not in names:
+                            names.add(f'{lang}/{ph}' if self._multi_langs else ph)
+        # merged groups: overlapping groups fuse (union-find over the phoneme names)
+        parent: Dict[str, str] = {}
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+
+        for group in merged_groups or ():
+            members = []
+            for ph in group:
+                if '/' in ph:
+                    lang, short = ph.split('/', maxsplit=1)
+                    if lang not in dictionaries:
+                        raise ValueError(f"Invalid phoneme tag '{ph}' in merged group: unrecognized language name '{lang}'.")
+                    member = ph if self._multi_langs else short
+                else:
+                    member = ph
+                if member not in names:
+                    raise ValueError(f"Invalid phoneme tag '{ph}' in merged group: not found in phoneme set.")
+                members.append(member)
+            if len(members) < 2:        # (a group that names one phoneme twice still counts as a group, as in the reference)
+                continue
+            for m in members:
+                parent.setdefault(m, m)
+            for m in members[1:]:
+                parent[find(m)] = find(members[0])
+        groups: Dict[str, List[str]] = {}
+        for m in parent:
+            groups.setdefault(find(m), []).append(m)
+        self._phone_to_id: Dict[str, int] = {}
+        self._id_to_phone: List = []
+        cross = set()
+        for ph in sorted(names):
+            if ph in self._phone_to_id:
+                continue
+            idx = len(self._id_to_phone) + 1
+            if ph in parent:
+                members = sorted(groups[find(ph)])
+                for alias in members:
+                    self._phone_to_id[alias] = idx
+                self._id_to_phone.append(tuple(members))
+                if len({a.split('/', maxsplit=1)[0] if '/' in a else None for a in members}) > 1:
+                    cross.update(a for a in members if '/' in a)
+            else:
+                self._phone_to_id[ph] = idx
+                self._id_to_phone.append(ph)
+        self._cross_lingual_phonemes = frozenset(cross)
+
+    @property
+    def vocab_size(self):
+        return len(self._id_to_phone) + 1
+
+    def __len__(self):
+        return self.vocab_size
+
+    @property
+    def cross_lingual_phonemes(self):
+        return self._cross_lingual_phonemes
+
+    def is_cross_lingual(self, phone):
+        return phone in self._cross_lingual_phonemes
+
+    def encode_one(self, phone, lang=None):
+        if '/' in phone:
+            lang, phone = phone.split('/', maxsplit=1)
+        if lang is None or not self._multi_langs or phone in self._phone_to_id:
+            return self._phone_to_id[phone]
+        return self._phone_to_id[phone if '/' in phone else f'{lang}/{phone}']
+
+    def encode(self, sentence, lang=None):
+        phones = sentence.strip().split() if isinstance(sentence, str) else sentence
+        return [self.encode_one(p, lang=lang) for p in phones]
+
+    def decode_one(self, idx, lang=None, scalar=True):
+        if idx <= 0:
+            return None
+        phone = self._id_to_phone[idx - 1]
+        if not scalar or isinstance(phone, str):
+            return phone
+        if lang is not None and self._multi_langs:
+            for alias in phone:
+                if alias.startswith(f'{lang}/'):
+                    return alias
+        return phone[0]
+
+    def decode(self, ids, lang=None, scalar=True):
+        return ' '.join(self.decode_one(i, lang=lang, scalar=scalar) for i in list(ids) if i >= 1)
+
+    def dump(self, filename):
+        with open(filename, 'w', encoding='utf8') as fp:
+            json.dump(self._phone_to_id, fp, ensure_ascii=False, indent=2)
+
+
+def load_phoneme_dictionary() -> PhonemeDictionary:
+    """`utils/phoneme_utils.py:179-210`: `dictionary-<lang>.txt` in the work directory (else the configured path) for every
+    language of `hparams['dictionaries']`, or the single `dictionary.txt` / `hparams['dictionary']`."""
+    work = pathlib.Path(hparams['work_dir'])
+    configured = hparams.get('dictionaries')
+    if configured is not None:
+        paths = {}
+        for lang, fallback in configured.items():
+            path = work / f'dictionary-{lang}.txt'
+            path = path if path.exists() else pathlib.Path(fallback)
+            if not path.exists():
+                raise FileNotFoundError(f"Could not locate dictionary for language '{lang}'.")
+            paths[lang] = path
+    else:
+        path = work / 'dictionary.txt'
+        path = path if path.exists() else pathlib.Path(hparams['dictionary'])
+        if not path.exists():
+            raise FileNotFoundError("Could not locate dictionary file.")
+        paths = {'default': path}
+    return PhonemeDictionary(paths, extra_phonemes=hparams.get('extra_phonemes'),
+                             merged_groups=hparams.get('merged_phoneme_groups'))

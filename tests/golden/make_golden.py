@@ -717,6 +717,51 @@ def time_reference_cpu():
 
 
 
+# --------------------------------------------------------------------------- G14: phoneme dictionary (token ids of a model)
+G14_DICTS = {
+    "zh": "a\ta\nai\tai\nba\tb a\nshi\tsh ir\nn\tn\nyu\ty v\n",
+    "ja": "a\ta\nka\tk a\nshi\tsh i\nn\tN\ntsu\tts u\ncl\tcl\n",
+}
+G14_CASES = {
+    "multi": dict(langs=["zh", "ja"], extra=["EP", "ja/vf", "GlottalStop"],
+                  merged=[["zh/a", "ja/a"], ["zh/sh", "ja/sh"], ["ja/N", "zh/n"], ["zh/n", "AP"], ["zh/b", "zh/b"], ["zh/y", "zh/v"]]),
+    "single": dict(langs=["zh"], extra=["EP"], merged=[["zh/y", "v"], ["a", "ai"]]),
+}
+
+
+def g14_phoneme_dictionary():
+    """The reference's PhonemeDictionary (utils/phoneme_utils.py:10-176) on two small synthetic pronunciation dictionaries:
+    multilingual naming, extra phonemes, merged (also overlapping and cross-lingual) groups; ids, aliases, encode / decode."""
+    import json
+    import pathlib
+    import shutil
+    from utils.phoneme_utils import PhonemeDictionary  # (reference)
+    work = pathlib.Path(HERE) / "_g14_work"
+    work.mkdir(exist_ok=True)
+    out = {"dicts": G14_DICTS, "cases": {}}
+    try:
+        for lang, text in G14_DICTS.items():
+            (work / f"{lang}.txt").write_text(text, encoding="utf8")
+        for tag, c in G14_CASES.items():
+            d = PhonemeDictionary({l: work / f"{l}.txt" for l in c["langs"]}, extra_phonemes=c["extra"], merged_groups=c["merged"])
+            sent = "a sh ir N" if tag == "multi" else "a sh ir n y"
+            out["cases"][tag] = dict(
+                config=c, vocab_size=d.vocab_size, phone_to_id=d._phone_to_id,
+                id_to_phone=[list(p) if isinstance(p, tuple) else p for p in d._id_to_phone],
+                cross_lingual=sorted(d.cross_lingual_phonemes),
+                encode_zh=d.encode("a sh ir n ja/k EP AP", lang="zh") if tag == "multi" else d.encode(sent),
+                encode_ja=d.encode("a sh i N zh/b", lang="ja") if tag == "multi" else None,
+                decode=[d.decode(range(1, d.vocab_size), lang=l) for l in ([None, "zh", "ja"] if tag == "multi" else [None])],
+                decode_groups=[list(p) if isinstance(p, tuple) else p for p in
+                               (d.decode_one(i, scalar=False) for i in range(1, d.vocab_size))])
+            print(f"  phoneme dictionary {tag}: vocab {d.vocab_size}, cross-lingual {sorted(d.cross_lingual_phonemes)}")
+        with open(os.path.join(HERE, "g14_phoneme_dictionary.json"), "w", encoding="utf8") as f:
+            json.dump(out, f, ensure_ascii=False, indent=1, sort_keys=True)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+
 # --------------------------------------------------------------------------- G12: DiffSingerVariance, tokens -> dur / pitch / variances
 def g12_variance_model():
     """The reference's own top-level variance model (modules/toplevel.py:125-309), infer branch, small nets; configurations
@@ -916,7 +961,7 @@ def g11_harness():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g5c1"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g5c1", "g14"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -937,6 +982,8 @@ if __name__ == "__main__":
         g10_vocoder()
     if "time" in which:
         time_reference_cpu()
+    if "g14" in which:
+        g14_phoneme_dictionary()
     if "g5c1" in which:
         g5_config1_pndm50()
     if "g12" in which:

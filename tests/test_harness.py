@@ -183,3 +183,52 @@ def test_load_config_resolves_the_base_config_chain(tmp_path):
     assert hp_mod.load_config(tmp_path / "saved.yaml", update_global=False) == {"hidden_size": 128, "spec_min": [-12.0]}
     assert hp_mod.hparams["hidden_size"] == 256
     hp_mod.hparams.clear()
+
+
+@pytest.mark.parametrize("tag", ["multi", "single"])
+def test_phoneme_dictionary_vs_reference(tag, tmp_path):
+    """harness.PhonemeDictionary against the reference's (G14: utils/phoneme_utils.py on two synthetic pronunciation
+    dictionaries): ids, merged groups (overlapping and cross-lingual ones too), encode with and without a language, decode."""
+    with open(os.path.join(GOLDEN, "g14_phoneme_dictionary.json"), encoding="utf8") as f:
+        g = json.load(f)
+    for lang, text in g["dicts"].items():
+        (tmp_path / f"{lang}.txt").write_text(text, encoding="utf8")
+    c = g["cases"][tag]
+    cfg = c["config"]
+    d = harness.PhonemeDictionary({l: tmp_path / f"{l}.txt" for l in cfg["langs"]}, extra_phonemes=cfg["extra"],
+                                  merged_groups=cfg["merged"])
+    assert len(d) == d.vocab_size == c["vocab_size"]
+    assert d._phone_to_id == c["phone_to_id"]
+    assert [list(p) if isinstance(p, tuple) else p for p in d._id_to_phone] == c["id_to_phone"]
+    assert sorted(d.cross_lingual_phonemes) == c["cross_lingual"]
+    assert all(d.is_cross_lingual(p) for p in c["cross_lingual"]) and not d.is_cross_lingual("SP")
+    if tag == "multi":
+        assert d.encode("a sh ir n ja/k EP AP", lang="zh") == c["encode_zh"]
+        assert d.encode("a sh i N zh/b", lang="ja") == c["encode_ja"]
+        assert [d.decode(range(1, d.vocab_size), lang=l) for l in (None, "zh", "ja")] == c["decode"]
+    else:
+        assert d.encode("a sh ir n y") == c["encode_zh"]
+        assert [d.decode(range(1, d.vocab_size))] == c["decode"]
+    got = [d.decode_one(i, scalar=False) for i in range(1, d.vocab_size)]
+    assert [list(p) if isinstance(p, tuple) else p for p in got] == c["decode_groups"]
+    d.dump(tmp_path / "phonemes.json")
+    assert json.load(open(tmp_path / "phonemes.json", encoding="utf8")) == c["phone_to_id"]
+    with pytest.raises(ValueError, match="unrecognized language"):
+        harness.PhonemeDictionary({"zh": tmp_path / "zh.txt"}, extra_phonemes=["ko/x"])
+    with pytest.raises(ValueError, match="not found in phoneme set"):
+        harness.PhonemeDictionary({"zh": tmp_path / "zh.txt"}, merged_groups=[["a", "nope"]])
+
+
+def test_load_phoneme_dictionary_prefers_the_work_directory(tmp_path):
+    hparams.clear()
+    (tmp_path / "work").mkdir()
+    (tmp_path / "work" / "dictionary-zh.txt").write_text("a\ta\nba\tb a\n", encoding="utf8")
+    (tmp_path / "ja.txt").write_text("ka\tk a\n", encoding="utf8")
+    hparams.update(work_dir=str(tmp_path / "work"), dictionaries={"zh": "missing/zh.txt", "ja": str(tmp_path / "ja.txt")},
+                   extra_phonemes=[], merged_phoneme_groups=[])
+    d = harness.load_phoneme_dictionary()
+    assert d.encode("a b", lang="zh") == [d._phone_to_id["zh/a"], d._phone_to_id["zh/b"]] and "ja/k" in d._phone_to_id
+    hparams.update(dictionaries={"ko": "missing/ko.txt"})
+    with pytest.raises(FileNotFoundError):
+        harness.load_phoneme_dictionary()
+    hparams.clear()
