@@ -1,6 +1,7 @@
 """-m gpu parity of the NSF-HiFiGAN generator (dsd_vocode) against the fixtures
 generated from the reference Generator (G10) and the numpy oracle.  Stated fp32 tolerance: 1e-4 of the waveform
 range (oracle-vs-reference is <= 5e-5; the source's sin() of accumulated phases is the sensitive part)."""
+import json
 import os
 
 import numpy as np
@@ -203,3 +204,65 @@ def test_ds_harness_segments_to_waveform(tmp_path):
     finally:
         hparams.clear()
         hparams.update(saved)
+
+
+def test_example_script_runs_a_saved_experiment(tmp_path):
+    """examples/ds_to_wav.py as a user would run it: an experiment directory with config.yaml (base_config chain),
+    model_ckpt_steps_<N>.ckpt (`model.` prefix), dictionary.txt and spk_map.json, a vocoder checkpoint with its config.json,
+    a `.ds` project -> a wav file; everything found and loaded by the package's own loaders."""
+    import subprocess
+    import sys
+    import yaml
+    from scipy.io import wavfile
+    from diffsinger_amd.toplevel import DiffSingerAcoustic
+    from diffsinger_amd.hparams import hparams
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = tmp_path / "checkpoints" / "exp"
+    exp.mkdir(parents=True)
+    base = dict(hop_size=512, audio_sample_rate=44100, audio_num_mel_bins=128, hidden_size=256, enc_layers=2, enc_ffn_kernel_size=3,
+                ffn_act="gelu", dropout=0.1, num_heads=2, use_pos_embed=True, rel_pos=True, use_rope=True, use_lang_id=False, num_lang=1,
+                schedule_type="linear", timesteps=1000, spec_min=[-12.0], spec_max=[0.0], mel_base="e",
+                augmentation_args=dict(random_pitch_shifting=dict(range=[-5.0, 5.0]), random_time_stretching=dict(range=[0.5, 2.0])))
+    cfg = dict(base_config=["./base.yaml"], use_spk_id=True, num_spk=3, use_energy_embed=True, use_key_shift_embed=True,
+               use_speed_embed=True, use_shallow_diffusion=True, diffusion_type="reflow", T_start=0.4, T_start_infer=0.4,
+               time_scale_factor=1000, sampling_algorithm="euler", sampling_steps=8, K_step=400, K_step_infer=400,
+               backbone_type="wavenet", backbone_args=dict(num_layers=2, num_channels=64, dilation_cycle_length=2),
+               shallow_diffusion_args=dict(aux_decoder_arch="convnext", val_gt_start=False,
+                                           aux_decoder_args=dict(num_channels=64, num_layers=2, kernel_size=7)))
+    (exp / "base.yaml").write_text(yaml.safe_dump(base))
+    (exp / "config.yaml").write_text(yaml.safe_dump(cfg))
+    (exp / "dictionary.txt").write_text("aa\ta\nbab\tb a b\ncd\tc d\ne\te\n", encoding="utf8")
+    (exp / "spk_map.json").write_text('{"alice": 0, "bob": 1, "carol": 2}')
+    saved = dict(hparams)
+    try:
+        hparams.clear()
+        hparams.update(base)
+        hparams.update({k: v for k, v in cfg.items() if k != "base_config"})
+        model = DiffSingerAcoustic(8, 128)                   # AP SP a b c d e + padding
+        sd = dict(model.state_dict())
+        sd.update({"fs2." + k: torch.from_numpy(v) for k, v in synth.synth_state_dict(synth.fs2_acoustic_param_shapes(
+            8, enc_layers=2, num_spk=3, variances=("energy",), key_shift=True, speed=True), seed=600).items()})
+        sd.update({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(synth.convnext_param_shapes(
+            256, 128, num_channels=64, num_layers=2, prefix="aux_decoder.decoder."), seed=601).items()})
+        sd.update({"diffusion.velocity_fn." + k: torch.from_numpy(v) for k, v in synth.synth_state_dict(
+            synth.backbone_param_shapes("wavenet", 128, 1, hidden_size=256, num_layers=2, num_channels=64,
+                                        dilation_cycle_length=2), seed=602).items()})
+    finally:
+        hparams.clear()
+        hparams.update(saved)
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "category": "acoustic"}, exp / "model_ckpt_steps_100.ckpt")
+    torch.save({"state_dict": {"model." + k: v * 0 for k, v in sd.items()}, "category": "acoustic"}, exp / "model_ckpt_steps_20.ckpt")
+    voc = tmp_path / "voc"
+    voc.mkdir()
+    vh = dict(synth.NSF_HIFIGAN_DEFAULT, upsample_initial_channel=64)
+    (voc / "config.json").write_text(json.dumps(vh))
+    torch.save({"generator": {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(
+        synth.nsf_hifigan_param_shapes(vh), seed=603, gain=GAIN).items()}}, voc / "model.ckpt")
+    out = tmp_path / "song.wav"
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "ds_to_wav.py"), str(exp), os.path.join(GOLDEN, "g11_segments.ds"),
+                        str(voc / "model.ckpt"), "-o", str(out), "--batch-size", "3", "--seed", "3"],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "model_ckpt_steps_100.ckpt" in r.stdout          # the latest step, not the zeroed older one
+    sr, data = wavfile.read(out)
+    assert sr == 44100 and data.shape[0] > 44100 and np.abs(data.astype(np.float64)).max() > 0
