@@ -233,3 +233,36 @@ def test_variance_model_ragged_batch_equals_alone():
     for m in model.modules():
         if hasattr(m, "release_native"):
             m.release_native()
+
+
+def test_example_script_completes_a_project_from_a_saved_experiment(tmp_path):
+    """examples/ds_variance.py as a user would run it: config.yaml, model_ckpt_steps_<N>.ckpt, dictionary.txt and
+    spk_map.json in an experiment directory, a `.ds` project in, the completed `.ds` out."""
+    import json
+    import subprocess
+    import sys
+    import yaml
+    from diffsinger_amd.variance import DiffSingerVariance
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = tmp_path / "exp"
+    exp.mkdir()
+    hp = vc.case_hparams("word_reflow")
+    hp.update(vc.HARNESS_HP, hidden_size=256, use_melody_encoder=True, num_spk=3)
+    (exp / "config.yaml").write_text(yaml.safe_dump(hp))
+    (exp / "dictionary.txt").write_text("ab\ta b\ncd\tc d\ne\te\n", encoding="utf8")
+    (exp / "spk_map.json").write_text(json.dumps(vc.HARNESS_SPK))
+    hparams.clear()
+    hparams.update(hp, infer=True)
+    model = DiffSingerVariance(8)
+    shapes = vc.sorted_param_shapes(model.named_parameters())
+    sd = dict(model.state_dict())
+    sd.update({k: torch.from_numpy(v) for k, v in vc.synth_weights(shapes, 88).items()})
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "category": "variance"}, exp / "model_ckpt_steps_7.ckpt")
+    proj = tmp_path / "song.ds"
+    proj.write_text(json.dumps(vc.make_variance_segments()))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "ds_variance.py"), str(exp), str(proj), "-o", str(tmp_path / "out"),
+                        "--seed", "5", "--batch-size", "4"], capture_output=True, text=True, timeout=300, cwd=root,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    done = json.loads((tmp_path / "out" / "song.ds").read_text(encoding="utf8"))
+    assert len(done) == 4 and all("ph_dur" in s and "f0_seq" in s and "energy" in s and "breathiness" in s for s in done)
