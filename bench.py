@@ -95,13 +95,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the product has no CPU path"
+    if os.environ.get("DSD_BENCH_SHARE_GPU") == "1":      # rehearsal of the N-rank path on a one-GPU box: ranks share cuda:0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("DSD_BENCH_FORCE_DIST") == "1"      # the latter: 1-rank RCCL rehearsal
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if os.environ.get("DSD_BENCH_SHARE_GPU") == "1":   # RCCL refuses two ranks on one device: gloo over host staging
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from diffsinger_amd import synth, sharding
     from diffsinger_amd.hparams import hparams
@@ -244,7 +249,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        el = torch.tensor([elapsed], device=sharding._staging(device), dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
     if rank == 0:

@@ -40,24 +40,31 @@ def utterance_noise(shape_per_utt, utt_indices, seed: int, device) -> torch.Tens
     return torch.stack(outs)
 
 
+def _staging(device):
+    """Where the collectives' buffers live: the compute device over RCCL; host memory when the process group is `gloo`
+    but the tensors are on a GPU (the rehearsal of the N-rank path on a one-GPU box: ranks share the card)."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else device
+
+
 def scatter_condition(cond_all: Optional[torch.Tensor], n_utt: int, t_len: int, hidden: int, device,
                       src: int = 0) -> torch.Tensor:
     """Rank `src` holds cond_all [n_utt, T, H]; every rank returns its shard [n_local, T, H]."""
     world, rank = dist.get_world_size(), dist.get_rank()
     shards = shard_ranges(n_utt, world)
     n_max = max(len(s) for s in shards)
-    recv = torch.empty((n_max, t_len, hidden), device=device, dtype=torch.float32)
+    stage = _staging(device)
+    recv = torch.empty((n_max, t_len, hidden), device=stage, dtype=torch.float32)
     if rank == src:
         pieces = []
         for s in shards:
-            p = torch.zeros((n_max, t_len, hidden), device=device, dtype=torch.float32)
+            p = torch.zeros((n_max, t_len, hidden), device=stage, dtype=torch.float32)
             if len(s):
                 p[:len(s)] = cond_all[s.start:s.stop]
             pieces.append(p)
         dist.scatter(recv, pieces, src=src)
     else:
         dist.scatter(recv, None, src=src)
-    return recv[:len(shards[rank])].contiguous()
+    return recv[:len(shards[rank])].to(device).contiguous()
 
 
 def gather_mels(mel_local: torch.Tensor, n_utt: int, dst: int = 0) -> Optional[torch.Tensor]:
@@ -65,12 +72,12 @@ def gather_mels(mel_local: torch.Tensor, n_utt: int, dst: int = 0) -> Optional[t
     world, rank = dist.get_world_size(), dist.get_rank()
     shards = shard_ranges(n_utt, world)
     n_max = max(len(s) for s in shards)
-    pad = torch.zeros((n_max,) + tuple(mel_local.shape[1:]), device=mel_local.device, dtype=mel_local.dtype)
+    pad = torch.zeros((n_max,) + tuple(mel_local.shape[1:]), device=_staging(mel_local.device), dtype=mel_local.dtype)
     pad[:mel_local.shape[0]] = mel_local
     if rank == dst:
         bufs = [torch.empty_like(pad) for _ in range(world)]
         dist.gather(pad, bufs, dst=dst)
-        return torch.cat([b[:len(s)] for b, s in zip(bufs, shards)], dim=0)
+        return torch.cat([b[:len(s)] for b, s in zip(bufs, shards)], dim=0).to(mel_local.device)
     dist.gather(pad, None, dst=dst)
     return None
 
