@@ -1076,7 +1076,12 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
         while (s16 % 32 != 16) s16 += 4;
         const bool ok = (g.taps == 1 || g.taps == 3) && g.K % 64 == 0 && g.Kreal == g.K && stage != ST_LN &&
                         epi != EP_SWIGLU && epi != EP_LYNX_NEXT && gemm_has_fast(g.taps, 0, s16);
-        if (ok && !generic_only && (force == 1 || (force != 0 && wg32 <= 192))) c.nb = 0;
+        // ... and above that while they still lower the frames the busiest CU has to cover (a launch this small is one
+        // "round" of concurrent workgroups per CU): T = 1100 is 280 32-frame workgroups - 24 CUs get two, 64 frames - or
+        // 552 16-frame ones, three per CU at most, 48 frames (measured at B = 1: 22.2 instead of 26.7 ms for T in (1024, 1536])
+        const long wg16 = (long)batch * ((T + 15) / 16) * mtiles;
+        const long load16 = (wg16 + 255) / 256 * 16, load32 = (wg32 + 255) / 256 * 32;
+        if (ok && !generic_only && (force == 1 || (force != 0 && (wg32 <= 192 || (wg32 <= 768 && load16 < load32))))) c.nb = 0;
     }
     const int BN = c.nb == 0 ? 16 : 32 * c.nb;
     p.tiles_per_b = (T + BN - 1) / BN;
