@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-points = [("wavenet_dpm50", b, 1000) for b in (1, 2, 4, 8, 16, 24)] + [("wavenet_dpm50", 1, t) for t in (128, 256, 512, 768, 2048, 4096)] + \
+points = [("wavenet_dpm50", b, 1000) for b in (1, 2, 4, 8, 16, 24)] + [("wavenet_dpm50", 1, t) for t in (128, 256, 512, 768, 1100, 1536, 2048, 4096)] + \
          [("lynxnet_ddim100", b, 1000) for b in (1, 8)] + [("variance_reflow20", b, 1000) for b in (1, 8)] + \
          [("acoustic_default", 1, 1000), ("acoustic_wav", 1, 1000)]
 out = []
