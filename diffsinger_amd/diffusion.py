@@ -16,7 +16,6 @@ from __future__ import annotations
 import ctypes as C
 from typing import List, Tuple
 
-import numpy as np
 import torch
 from torch import nn
 

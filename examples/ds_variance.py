@@ -12,7 +12,7 @@ import json
 import pathlib
 
 from diffsinger_amd import harness
-from diffsinger_amd.hparams import hparams, load_config
+from diffsinger_amd.hparams import load_config
 from diffsinger_amd.variance import DiffSingerVariance
 from diffsinger_amd.variance_harness import VarianceHarness
 

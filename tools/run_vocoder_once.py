@@ -1,5 +1,5 @@
 """Runs the NSF-HiFiGAN generator three times at B=1, T=1000 (for `rocprofv3 --kernel-trace -- python3 tools/run_vocoder_once.py`)."""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffsinger_amd import synth

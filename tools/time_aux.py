@@ -3,7 +3,6 @@
 encoder (dsd_encode).  GPU box only."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 from diffsinger_amd import synth
 from diffsinger_amd.hparams import hparams

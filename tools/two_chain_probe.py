@@ -5,7 +5,6 @@ store in lockstep)?  Times  (a) one B=1, T=1000 chain,  (b)
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, ".")
