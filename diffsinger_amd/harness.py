@@ -571,3 +571,56 @@ def load_phoneme_dictionary() -> PhonemeDictionary:
         paths = {'default': path}
     return PhonemeDictionary(paths, extra_phonemes=hparams.get('extra_phonemes'),
                              merged_groups=hparams.get('merged_phoneme_groups'))
+
+
+# --------------------------------------------------------------------------------------------------- project edits
+_SHARP_NAMES = ('C', 'C#', 'D', 'D#', 'E', 'F', 'F#', 'G', 'G#', 'A', 'A#', 'B')
+
+
+def midi_to_note(midi) -> str:
+    """60 -> 'C4', 61 -> 'C#4' (sharps, ASCII; C-1 = 0): the nearest semitone's name, like librosa.midi_to_note(unicode=False)."""
+    n = int(round(float(midi)))
+    return f'{_SHARP_NAMES[n % 12]}{n // 12 - 1}'
+
+
+def trans_key(raw_data: List[dict], key: int) -> List[dict]:
+    """`scripts/infer.py --key` (`utils/infer_utils.py:8-38`): every note of every segment moves by `key` semitones (names
+    come back as sharps on the nearest semitone, rests stay), every value of `f0_seq` is multiplied by 2^(key/12) and
+    rounded to 0.1 Hz.  Edits the segments in place and returns them."""
+    from .variance_harness import note_to_midi
+    missing = False
+    for seg in raw_data:
+        seg['note_seq'] = ' '.join(n if n == 'rest' else midi_to_note(int(round(note_to_midi(n))) + key)
+                                   for n in seg['note_seq'].split(' '))
+        if seg.get('f0_seq'):
+            seg['f0_seq'] = ' '.join(str(round(float(v) * 2 ** (key / 12), 1)) for v in seg['f0_seq'].split(' '))
+        else:
+            missing = True
+    if missing:
+        print('Warning: parts of f0_seq do not exist, please freeze the pitch line in the editor.\r\n')
+    return raw_data
+
+
+def parse_commandline_spk_mix(mix: str) -> Dict[str, float]:
+    """`scripts/infer.py --spk` (`utils/infer_utils.py:56-86`): "name", "a|b" or "a:0.3|b:0.5|c" -> proportions that sum to
+    1: speakers without a number share what the given numbers leave of 1, then everything is normalised."""
+    import re
+    name, number = r'[0-9A-Za-z_-]+', r'\d+(\.\d+)?'
+    single = rf'{name}(:{number})?'
+    assert re.fullmatch(rf'{single}(\|{single})*', mix) is not None, f'Invalid mix pattern: {mix}'
+    given, bare = {}, []
+    for part in mix.split('|'):
+        speaker = part.split(':')[0]
+        assert speaker not in bare and speaker not in given, f'Duplicate speaker name: {speaker}'
+        if ':' in part:
+            given[speaker] = float(part.split(':')[1])
+        else:
+            bare.append(speaker)
+    total = sum(given.values())
+    assert total < 1 or len(bare) == 0, \
+        'Proportion of all speakers should be specified if the sum of all given proportions are larger than 1.'
+    for speaker in bare:
+        given[speaker] = (1 - total) / len(bare)
+    norm = sum(given.values())
+    assert norm > 0, 'Sum of all proportions should be positive.'
+    return {speaker: value / norm for speaker, value in given.items()}

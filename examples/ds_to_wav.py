@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--depth", type=float, default=None, help="shallow-diffusion depth in (0, 1] (scripts/infer.py --depth)")
     ap.add_argument("--batch-size", type=int, default=8, help="segments per launch of the acoustic model (ragged batch)")
     ap.add_argument("--seed", type=int, default=-1)
+    ap.add_argument("--key", type=int, default=0, help="transpose by this many semitones (scripts/infer.py --key)")
+    ap.add_argument("--spk", default=None, help='speaker or mix, e.g. "alice" or "alice:0.3|bob" (scripts/infer.py --spk)')
     args = ap.parse_args()
 
     load_config(args.exp / "config.yaml", overrides=dict(infer=True, work_dir=str(args.exp)))
@@ -43,7 +45,14 @@ def main():
     vocoder = harness.load_vocoder(args.vocoder)
     h = harness.AcousticHarness(model, vocoder, dictionary, spk_map=maps["spk_map"], lang_map=maps["lang_map"], device="cuda")
     out = args.out or args.proj.with_suffix(".wav")
-    track = h.run_inference(harness.load_ds(args.proj), out_path=out, seed=args.seed, batch_size=args.batch_size)
+    params = harness.load_ds(args.proj)
+    if args.key:
+        params = harness.trans_key(params, args.key)
+    if args.spk is not None:
+        mix = harness.parse_commandline_spk_mix(args.spk)
+        for seg in params:
+            seg["spk_mix"] = mix
+    track = h.run_inference(params, out_path=out, seed=args.seed, batch_size=args.batch_size)
     print(f"| wrote {out}: {track.shape[0] / hparams['audio_sample_rate']:.2f} s")
 
 

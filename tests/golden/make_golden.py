@@ -762,6 +762,39 @@ def g14_phoneme_dictionary():
 
 
 
+def g15_infer_utils():
+    """The reference's `parse_commandline_spk_mix` on a set of --spk strings, and `trans_key` on a small project.  The
+    latter calls librosa (absent): note_to_midi / midi_to_note come from diffsinger_amd here, so the NOTE NAMES of this
+    fixture are pinned by known answers only (tests/test_harness.py); the f0 arithmetic and the handling of rests are the
+    reference's."""
+    import json
+    import types
+    from diffsinger_amd import harness as hz
+    from diffsinger_amd import variance_harness as vh
+    lib = sys.modules.get("librosa") or types.ModuleType("librosa")
+    lib.__path__ = []
+    lib.note_to_midi = lambda n, round_midi=True: (int(round(vh.note_to_midi(n))) if round_midi else vh.note_to_midi(n))
+    lib.midi_to_note = lambda m, unicode=True: hz.midi_to_note(m)
+    sys.modules["librosa"] = lib
+    from utils.infer_utils import parse_commandline_spk_mix, trans_key  # (reference)
+    mixes = ["opencpop", "a|b", "a:0.5|b:0.5", "a:0.3|b", "a:0.2|b|c", "a:2|b:6", "x_1:0.25|y-2:0.25|z"]
+    bad = ["a|a", "a:0.7|b:0.6|c", "a:|b", "a b", "a:0|b:0"]
+    proj = [dict(note_seq="C4 rest A#3 Db4+20 B3", f0_seq="220.0 0.0 261.6 440.05"), dict(note_seq="rest G9 C-1")]
+    out = dict(mixes={m: parse_commandline_spk_mix(m) for m in mixes}, bad=bad, project=proj, shifted={})
+    for key in (-13, -1, 0, 2, 12):
+        out["shifted"][str(key)] = trans_key(copy.deepcopy(proj), key)
+    for m in bad:
+        try:
+            parse_commandline_spk_mix(m)
+            raise SystemExit(f"expected an assertion for {m!r}")
+        except AssertionError:
+            pass
+    with open(os.path.join(HERE, "g15_infer_utils.json"), "w", encoding="utf8") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"  infer utils: {len(mixes)} mixes, {len(out['shifted'])} key shifts")
+
+
+
 # --------------------------------------------------------------------------- G12: DiffSingerVariance, tokens -> dur / pitch / variances
 def g12_variance_model():
     """The reference's own top-level variance model (modules/toplevel.py:125-309), infer branch, small nets; configurations
@@ -961,7 +994,7 @@ def g11_harness():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g5c1", "g14"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g5c1", "g14", "g15"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -984,6 +1017,8 @@ if __name__ == "__main__":
         time_reference_cpu()
     if "g14" in which:
         g14_phoneme_dictionary()
+    if "g15" in which:
+        g15_infer_utils()
     if "g5c1" in which:
         g5_config1_pndm50()
     if "g12" in which:

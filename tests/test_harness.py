@@ -232,3 +232,24 @@ def test_load_phoneme_dictionary_prefers_the_work_directory(tmp_path):
     with pytest.raises(FileNotFoundError):
         harness.load_phoneme_dictionary()
     hparams.clear()
+
+
+def test_project_edits_vs_reference(capsys):
+    """`--spk` strings and `--key` shifts (G15: the reference's parse_commandline_spk_mix / trans_key; note NAMES come from
+    this package's own note parser there - librosa is absent - and are pinned by the known answers below)."""
+    with open(os.path.join(GOLDEN, "g15_infer_utils.json"), encoding="utf8") as f:
+        g = json.load(f)
+    for mix, want in g["mixes"].items():
+        got = harness.parse_commandline_spk_mix(mix)
+        assert list(got) == list(want) and all(got[k] == want[k] for k in want), mix
+    for mix in g["bad"]:
+        with pytest.raises(AssertionError):
+            harness.parse_commandline_spk_mix(mix)
+    import copy
+    for key, want in g["shifted"].items():
+        assert harness.trans_key(copy.deepcopy(g["project"]), int(key)) == want
+    assert "parts of f0_seq do not exist" in capsys.readouterr().out
+    # known answers for the names: twelve semitones to the octave from C-1 = 0, sharps, nearest semitone
+    assert [harness.midi_to_note(m) for m in (0, 59, 60, 61, 69, 70.4, 70.6, 127)] == ["C-1", "B3", "C4", "C#4", "A4", "A#4", "B4", "G9"]
+    seg = harness.trans_key([dict(note_seq="C4 rest A#3 Db4+20 B3", f0_seq="440.0")], 2)[0]
+    assert seg["note_seq"] == "D4 rest C4 D#4 C#4" and seg["f0_seq"] == "493.9"
