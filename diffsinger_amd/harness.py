@@ -378,12 +378,24 @@ class AcousticHarness:
             return True
         return hparams.get('diff_accelerator') in ('ddim', 'pndm', 'dpm-solver', 'unipc') and hparams.get('diff_speedup', 1) > 1
 
-    def run_inference(self, params: List[dict], out_path=None, seed: int = -1, save_mel: bool = False, batch_size: int = 1):
+    def run_inference(self, params: List[dict], out_path=None, seed: int = -1, save_mel: bool = False, batch_size: int = 1,
+                      out_dir=None, title: Optional[str] = None, num_runs: int = 1):
         """One pass over the segments of a project: returns the assembled waveform (or the list of mels) and, when
         `out_path` is given, writes it.  Each segment is placed at its `offset`; where it overlaps what is already
         there the two are cross-faded.  `batch_size` > 1 runs that many segments per launch of the acoustic model as
         a ragged batch (same mels as one by one - the reference's order of operations, `ds_acoustic.py:214-271`,
-        `batch_size` = 1, is the default); the vocoder still takes them one at a time."""
+        `batch_size` = 1, is the default); the vocoder still takes them one at a time.
+        With `out_dir` and `title` the reference's own calling convention applies: `num_runs` passes, written to
+        `out_dir/title[-NNN].wav` (or `.mel.pt` with `save_mel`); the last pass is returned."""
+        if out_dir is not None:
+            assert title is not None, 'run_inference(out_dir=...) needs a title'
+            suffix = '.mel.pt' if save_mel else '.wav'
+            result = None
+            for run in range(num_runs):
+                name = f'{title}-{str(run).zfill(3)}{suffix}' if num_runs > 1 else title + suffix
+                result = self.run_inference(params, out_path=pathlib.Path(out_dir) / name, seed=seed, save_mel=save_mel,
+                                            batch_size=batch_size)
+            return result
         batches = [self.preprocess_input(param, idx=i) for i, param in enumerate(params)]
         ready = {}
         if batch_size > 1 and self._batchable():

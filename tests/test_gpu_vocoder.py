@@ -192,6 +192,10 @@ def test_ds_harness_segments_to_waveform(tmp_path):
         assert [tuple(m["mel"].shape) for m in mels] == [(1, f, 128) for f in frames]
         different = h.run_inference([dict(s, seed=s["seed"] + 1) for s in segs])
         assert not np.array_equal(track, different)
+        # the reference's calling convention: out_dir / title / num_runs (ds_acoustic.py:214-271)
+        last = h.run_inference(segs, out_dir=tmp_path / "runs", title="song", num_runs=2)
+        assert sorted(p.name for p in (tmp_path / "runs").iterdir()) == ["song-000.wav", "song-001.wav"]
+        assert np.array_equal(last, track)
         # all segments in ONE ragged batch of the acoustic model (dsd_set_lengths): the same mels, the same waveform
         batched_mels = h.run_inference(segs, save_mel=True, batch_size=len(segs))
         for a, b in zip(mels, batched_mels):
