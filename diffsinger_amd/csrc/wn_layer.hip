@@ -1,0 +1,362 @@
+// Fused WaveNet residual layer for gfx950 (MI355X): ONE launch per layer for grids that can give every CU a full-row tile.
+//
+//   ResidualBlock.forward (modules/backbones/wavenet.py:33-48) on a tile of 32 frames x ALL channels:
+//     y = dilated_conv(x + d) + cond_proj            (wavenet.py:34-38; cond_proj + both biases hoisted per utterance)
+//     z = sigmoid(y[:C]) * tanh(y[C:])                (wavenet.py:41-42)
+//     o = output_projection(z)                        (wavenet.py:44)
+//     x' = (x + o[:C]) / sqrt(2);  skip += o[C:]      (wavenet.py:45-48; the running sum replaces stack + sum, :96)
+//
+// Why one kernel: as two launches (gemm.hip: conv + gate, then out-proj + residual / skip) the 8 row-tile workgroups of
+// a frame tile each stage the same x tile, z makes a round trip through memory, and every layer pays two launch
+// boundaries with their cold prologues and drains - at B = 8, T = 1000 that is ~15 % of the layer.  Here a workgroup owns
+// 32 frames and ALL 2C output rows of both GEMMs:
+//   * the C x (32 + 2 * halo) tile of x + d (zero outside [0, T), wavenet.py:36-38) is staged ONCE into LDS;
+//   * 4 waves (one per SIMD) split the 2C rows: wave w owns the gate AND filter rows of channels [C/4 * w, C/4 * (w+1))
+//     (the packed weight blocks of gemm.hip: even block = gate, odd block = filter of 16 channels), 2C/64 16-row blocks
+//     x two 16-frame column blocks = 4C/64 accumulators per lane, initialised with the hoisted conditioner projection;
+//   * the K walk is one uninterrupted stream: weights as 1 KiB fragment blocks straight from L2 into VGPRs (double
+//     buffered one k16 step = 64 MFMAs = 2 k cycles ahead), activations as B fragments from the resident LDS tile;
+//   * the gate runs on the accumulators, z goes to LDS over the dead x tile (C x 32), the out-proj walks it the same
+//     way (wave w: rows [C/2 * w, C/2 * (w+1)): waves 0,1 the residual half, waves 2,3 the skip half);
+//   * the epilogue transposes each wave's accumulators through a wave-private LDS tile, so residual / skip arithmetic and
+//     the global loads / stores are row-major float4 (full 128-B lines).
+// x is double-buffered across layers (a neighbouring tile's halo must read the layer's INPUT): xin -> xout.
+// Per tile: 33.5 MFLOP (C = 256) on 4 SIMDs = 131 k MFMA cycles; weights 2 MB per workgroup from L2 (16 B/clk/CU),
+// algorithmic HBM/fabric bytes 24 C per frame + the layer's weights once per XCD.
+#include <hip/hip_ext.h>
+
+#include "dsd_internal.h"
+
+namespace dsd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float sigmoid_fast(float v) { return __frcp_rn(1.f + __expf(-v)); }
+__device__ __forceinline__ float tanh_fast(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
+__device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
+#ifdef DSD_STAMPS
+__device__ unsigned long long g_wn_stamps[4096][8];
+#define WN_STAMP(i)                                                                     \
+    do {                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                    \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+            g_wn_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime();                  \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+        }                                                                               \
+    } while (0)
+#else
+#define WN_STAMP(i)
+#endif
+
+}  // namespace
+
+#ifdef DSD_STAMPS
+extern "C" int dsd_dbg_read_wn_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wn_stamps), sizeof(g_wn_stamps));
+}
+#endif
+
+// NCH = C / 64 (3: multi-variance nets, 4: acoustic / pitch nets); SW = LDS row stride of the x tile in floats,
+// 48 (halo 8: dilation <= 8) or 80 (halo 16: dilation 16), both 16 (mod 32) so the 4 k-rows x 16 columns of a B
+// fragment read hit 64 distinct banks; RAG = 1: ragged batch (valid-tile list + per-item lengths, as in gemm.hip).
+template <int NCH, int SW, int RAG>
+__global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int C = 64 * NCH;
+    constexpr int MBW = 2 * NCH;                    // 16-row blocks per wave, both GEMMs (2C rows / 4 waves / 16)
+    constexpr int BN = 32;
+    constexpr int HL = SW == 48 ? 8 : 16;           // staged halo columns on each side
+    constexpr int W4 = (BN + 2 * HL) / 4;           // float4 per staged row
+    constexpr int NU = C * W4 / 256;                // staged float4 per thread (exact for C = 192, 256)
+    constexpr int SZ = 48;                          // z tile row stride
+    constexpr int ES = BN + 4;                      // epilogue tile row stride
+    constexpr int NS1 = NCH * 12;                   // k16 steps of the conv:  [64-channel chunk][tap][k16 in chunk]
+    constexpr int NS2 = NCH * 4;                    // k16 steps of the out-proj
+    static_assert(C * W4 % 256 == 0, "staging assumes a whole number of float4 per thread");
+    float* xs = lds;                                 // [C][SW]: x + d tile; later z [C][SZ]
+    float* es = lds + C * SW;                        // [4 waves][16 * MBW][ES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
+    // XCD-aware bijective remap (speed only): XCD k takes a contiguous range of tiles, so the tiles that share halo
+    // columns share an L2
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int rest = RAG ? p.cgmap[work] : work;
+    const int b = fdiv_floor(rest, p.inv_tiles_per_b);
+    const int t0 = (rest - b * p.tiles_per_b) * BN;
+    const int Tb = (RAG && p.lens) ? p.lens[b] : p.T;
+    const int Ts = p.Ts;
+    WN_STAMP(0);
+
+    // ---------------- prologue: x tile + FiLM scalars, conditioner projection -> accumulators, first weights ----------------
+    const float* xb = p.xin + (long)b * p.x_bstride;
+    const float* fl = p.film + p.film_col0 + b * p.film_colb;
+    f32x4 sv[NU];
+    float fa[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int idx = tid + 256 * u;
+        const int row = idx / W4, c4 = idx - row * W4;
+        sv[u] = *reinterpret_cast<const f32x4*>(xb + (long)row * Ts + (t0 - HL + c4 * 4));
+        fa[u] = fl[row * p.film_cstride];
+    }
+    // hoisted conditioner projection (+ conv bias + its own bias) of this wave's rows, in the accumulator layout
+    // (C/D of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + reg): the K walk accumulates on top of it
+    f32x4 acc[MBW][2];
+    {
+        const float* cpb = p.cp + (long)b * p.cp_bstride + t0 + lcol;
+#pragma unroll
+        for (int k = 0; k < MBW; ++k) {
+            const int row0 = (k & 1) * C + (NCH * wave + (k >> 1)) * 16 + rq;     // even block: gate rows, odd: filter rows
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[k][n][r] = cpb[(long)(row0 + r) * Ts + n * 16];
+        }
+    }
+    // weight streams of this wave: MBW row blocks, each a linear sequence of 1 KiB fragment blocks in K-walk order
+    const f32x4* a1p = reinterpret_cast<const f32x4*>(p.Aconv) + (long)(MBW * wave) * NS1 * 64 + lane;
+    const f32x4* a2p = reinterpret_cast<const f32x4*>(p.Aout) + (long)(MBW * wave) * NS2 * 64 + lane;
+    f32x4 wa[MBW], wb[MBW];
+    auto load_w1 = [&](f32x4 (&dst)[MBW], int s) {
+#pragma unroll
+        for (int k = 0; k < MBW; ++k) dst[k] = a1p[(k * NS1 + s) * 64];
+    };
+    auto load_w2 = [&](f32x4 (&dst)[MBW], int s) {
+#pragma unroll
+        for (int k = 0; k < MBW; ++k) dst[k] = a2p[(k * NS2 + s) * 64];
+    };
+    load_w1(wa, 0);
+    WN_STAMP(1);
+    // FiLM add, then the zero padding (wavenet.py:36-38: the pad is applied to x + d), then LDS
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int idx = tid + 256 * u;
+        const int row = idx / W4, c4 = idx - row * W4;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = t0 - HL + c4 * 4 + e;
+            o[e] = (t >= 0 && t < Tb) ? sv[u][e] + fa[u] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(&xs[row * SW + c4 * 4]) = o;
+    }
+    __syncthreads();
+    WN_STAMP(2);
+
+    // ---------------- GEMM 1: dilated conv, K = 3 taps x C channels ----------------
+    // B fragment of a k4 step: lane (lrow, lcol) holds stage(x)[channel 4j + lrow][column lcol (+16)] at the tap's shift
+    const float* bt = xs + lrow * SW + HL + lcol - p.dil;           // tap 0; tap 1 = + dil; tap 2 = + 2 dil
+    const int dil = p.dil;
+    float bq[2][4][2];
+    auto read_b1 = [&](float (&bv)[4][2], const float* chunk_base, int i) {      // i = step within the chunk (0..11)
+        const float* base = chunk_base + (i >> 2) * dil + ((i & 3) * 16) * SW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bv[j][0] = base[j * 4 * SW];
+            bv[j][1] = base[j * 4 * SW + 16];
+        }
+    };
+    auto mfma_step = [&](const f32x4 (&w)[MBW], const float (&bv)[4][2]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < MBW; ++k) {
+                acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k][j], bv[j][0], acc[k][0], 0, 0, 0);
+                acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k][j], bv[j][1], acc[k][1], 0, 0, 0);
+            }
+    };
+    read_b1(bq[0], bt, 0);
+    for (int c = 0; c < NCH; ++c) {
+        const float* cb = bt + c * 64 * SW;
+#pragma unroll
+        for (int i = 0; i < 12; i += 2) {
+            const int s = c * 12 + i;
+            // step s from wa; step s + 1's weights and B fragments travel meanwhile
+            load_w1(wb, s + 1);
+            read_b1(bq[1], cb, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(wa, bq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            // step s + 1 from wb; step s + 2: next conv step, or the out-proj's first block after the last one
+            if (s + 2 < NS1) load_w1(wa, s + 2);
+            else load_w2(wa, 0);
+            if (i + 2 < 12) read_b1(bq[0], cb, i + 2);
+            else read_b1(bq[0], cb + 64 * SW, 0);           // next chunk (after the last one: unused, inside the LDS allocation)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(wb, bq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    WN_STAMP(3);
+
+    // ---------------- gate (wavenet.py:41-42) on the accumulators; z -> LDS over the dead x tile ----------------
+    float zr[NCH][2][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zr[i][n][r] = sigmoid_fast(acc[2 * i][n][r]) * tanh_fast(acc[2 * i + 1][n][r]);
+    // epilogue operands (row-major float4 mapping of the wave's 16 * MBW output rows): residual stream x for waves 0, 1,
+    // running skip sum for waves 2, 3 - fetched now, consumed after GEMM 2
+    constexpr int NE = 16 * MBW * (BN / 4) / 64;                // float4 per lane: 16 (C = 256), 12 (C = 192)
+    f32x4 pre[NE];
+    const int orow0 = 16 * MBW * wave;                           // first output row of this wave (of 2C)
+    const bool is_res = orow0 < C;                               // wave-uniform
+    {
+        const float* src = is_res ? p.xin : p.skip;
+        const float* sb = src + (long)b * p.x_bstride + (long)(is_res ? orow0 : orow0 - C) * Ts + t0;
+        if (is_res || !p.first_layer) {
+#pragma unroll
+            for (int m = 0; m < NE; ++m) {
+                const int idx = lane + 64 * m;
+                pre[m] = *reinterpret_cast<const f32x4*>(sb + (long)(idx >> 3) * Ts + (idx & 7) * 4);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < NE; ++m) pre[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();                                             // every wave is done reading the x tile
+    float* zs = xs;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                zs[((NCH * wave + i) * 16 + rq + r) * SZ + n * 16 + lcol] = zr[i][n][r];
+#pragma unroll
+    for (int k = 0; k < MBW; ++k) {
+        acc[k][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    WN_STAMP(4);
+
+    // ---------------- GEMM 2: output projection, K = C ----------------
+    const float* zt = zs + lrow * SZ + lcol;
+    auto read_b2 = [&](float (&bv)[4][2], int s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bv[j][0] = zt[(s * 16 + j * 4) * SZ];
+            bv[j][1] = zt[(s * 16 + j * 4) * SZ + 16];
+        }
+    };
+    read_b2(bq[0], 0);
+#pragma unroll
+    for (int s = 0; s < NS2; s += 2) {
+        load_w2(wb, s + 1);
+        read_b2(bq[1], s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(wa, bq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < NS2) {
+            load_w2(wa, s + 2);
+            read_b2(bq[0], s + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(wb, bq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    WN_STAMP(5);
+
+    // ---------------- epilogue: residual / skip (wavenet.py:45-48) ----------------
+    float* ew = es + wave * (16 * MBW * ES);                     // wave-private tile [16 * MBW][ES]
+#pragma unroll
+    for (int k = 0; k < MBW; ++k)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ew[(k * 16 + rq + r) * ES + n * 16 + lcol] = acc[k][n][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // same wave wrote what it reads: LDS is in order per wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* dst = (is_res ? p.xout : p.skip) + (long)b * p.x_bstride + (long)(is_res ? orow0 : orow0 - C) * Ts + t0;
+#pragma unroll
+    for (int m = 0; m < NE; ++m) {
+        const int idx = lane + 64 * m;
+        const int rl = idx >> 3, c4 = idx & 7;
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ew[rl * ES + c4 * 4]);
+        const float bv = p.bias_out[orow0 + rl];
+        f32x4 o;
+        if (is_res) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (pre[m][e] + (a4[e] + bv)) / 1.41421356237309504880f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pre[m][e] + (a4[e] + bv);
+        }
+        *reinterpret_cast<f32x4*>(dst + (long)rl * Ts + c4 * 4) = o;
+    }
+    WN_STAMP(6);
+}
+
+int wn_layer_lds_bytes(int nch, int sw) { return (64 * nch * sw + 4 * 16 * 2 * nch * 36) * 4; }
+
+bool wn_layer_supported(int C, int dil) { return (C == 256 || C == 192) && dil >= 1 && dil <= 16; }
+
+template <int NCH, int SW, int RAG>
+static hipError_t wn_launch(const WnLayerP& p, int ntiles, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    const int ldsb = wn_layer_lds_bytes(NCH, SW);
+    static bool attr_done = false;       // per instantiation; set outside any capture by wn_layer_init_all
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wn_layer_kernel<NCH, SW, RAG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (ntiles == 0) return hipSuccess;
+    if (e0 && e1)
+        hipExtLaunchKernelGGL((wn_layer_kernel<NCH, SW, RAG>), dim3(ntiles), dim3(256), ldsb, st, e0, e1, 0, p);
+    else
+        hipLaunchKernelGGL((wn_layer_kernel<NCH, SW, RAG>), dim3(ntiles), dim3(256), ldsb, st, p);
+    return hipGetLastError();
+}
+
+static thread_local hipEvent_t g_wn_ev0 = nullptr, g_wn_ev1 = nullptr;
+void wn_layer_set_timing_events(hipEvent_t start, hipEvent_t stop) {
+    g_wn_ev0 = start;
+    g_wn_ev1 = stop;
+}
+
+hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st) {
+    const int sw = p.dil <= 8 ? 48 : 80;
+    const int ntiles = p.cgmap ? p.ncg : batch * p.tiles_per_b;
+    hipEvent_t e0 = g_wn_ev0, e1 = g_wn_ev1;
+#define WN_CASE(NCH_, SW_)                                                                                  \
+    if (C == 64 * NCH_ && sw == SW_)                                                                        \
+        return p.cgmap ? wn_launch<NCH_, SW_, 1>(p, ntiles, st, e0, e1) : wn_launch<NCH_, SW_, 0>(p, ntiles, st, e0, e1);
+    WN_CASE(4, 48)
+    WN_CASE(4, 80)
+    WN_CASE(3, 48)
+    WN_CASE(3, 80)
+#undef WN_CASE
+    return hipErrorInvalidValue;
+}
+
+// raise the dynamic-LDS limit of every instantiation once, outside any stream capture
+hipError_t wn_layer_init_all() {
+    WnLayerP p{};
+    hipError_t e;
+#define WN_INIT(NCH_, SW_)                                                                       \
+    if ((e = wn_launch<NCH_, SW_, 0>(p, 0, nullptr, nullptr, nullptr)) != hipSuccess) return e;  \
+    if ((e = wn_launch<NCH_, SW_, 1>(p, 0, nullptr, nullptr, nullptr)) != hipSuccess) return e;
+    WN_INIT(4, 48)
+    WN_INIT(4, 80)
+    WN_INIT(3, 48)
+    WN_INIT(3, 80)
+#undef WN_INIT
+    return hipSuccess;
+}
+
+}  // namespace dsd
