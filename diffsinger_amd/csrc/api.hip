@@ -1124,6 +1124,29 @@ int run_gemm(dsd_handle* h, const GemmCall& c, hipStream_t st) {
     return DSD_OK;
 }
 
+// WaveNet: one fused launch per residual layer (wn_layer.hip) when the grid gives (nearly) every CU a full-row tile of 32
+// frames; else the two-GEMM path of gemm.hip, whose 8x finer row tiles fill the chip from a single utterance.  A fused
+// launch is ceil(tiles / 256) rounds of one tile per CU (~t_tile each, MFMA-bound); the two launches cost a fixed part
+// plus a slope per tile (2 x 7.7 us + 8.6 ns per frame at B >= 6).  DSD_FUSED_LAYER=0/1 forces the choice.
+bool wn_use_fused(const dsd_handle* h) {
+    if (!is_wavenet(h)) return false;
+    const int C = C_of(h);
+    const int max_dil = 1 << (std::min(h->cfg.dilation_cycle_length, L_of(h)) - 1);
+    if (!wn_layer_supported(C, max_dil) || h->cfg.dilation_cycle_length < 1) return false;
+    static const int force = getenv("DSD_FUSED_LAYER") ? atoi(getenv("DSD_FUSED_LAYER")) : -1;
+    if (force == 0) return false;
+    if (force == 1) return true;
+    const bool ragged = !h->lens_host.empty();
+    long tiles = 0;
+    if (ragged) for (int v : h->lens_host) tiles += (v + 31) / 32;
+    else tiles = (long)h->B * ((h->T + 31) / 32);
+    static const double t_tile = getenv("DSD_FUSED_TILE_US") ? atof(getenv("DSD_FUSED_TILE_US")) : 62.0;
+    const double scale = (double)C / 256.0 * C / 256.0;                 // FLOPs per frame ~ C^2
+    const double fused = (double)((tiles + 255) / 256) * t_tile * scale;
+    const double split = 15.4 + 0.275 * (double)tiles * scale;
+    return tiles >= 128 && fused < split;
+}
+
 // step tables: E = sinemb(t) -> Hd = act(W0 E + b0) -> E2 = W1 Hd + b1 -> D[l*C + c][col] = Wd_l E2 + bd_l
 int run_step_tables(dsd_handle* h, int ncols, hipStream_t st) {
     const int C = C_of(h), Ns = h->Ns;
@@ -1204,6 +1227,36 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
     }
     if (is_wavenet(h)) {
         const long cps = (long)L * 2 * C * Ts;
+        if (wn_use_fused(h)) {
+            // one launch per residual layer; the residual stream ping-pongs between xh and z (a tile's halo columns must
+            // come from the layer's INPUT, which a neighbouring tile may already have replaced in place)
+            const bool ragged = h->use_cg && !h->lens_host.empty();
+            const float* xi = h->xh;
+            float* xo = h->z;
+            for (int l = 0; l < L; ++l) {
+                WnLayerP p;
+                memset(&p, 0, sizeof(p));
+                p.Aconv = h->blob + h->g_conv[l].a_off;
+                p.Aout = h->blob + h->g_outp[l].a_off;
+                p.bias_out = h->blob + h->g_outp[l].bias_off;
+                p.xin = xi; p.xout = xo; p.skip = h->skip;
+                p.x_bstride = xs; p.Ts = Ts;
+                p.cp = h->cp + (long)l * 2 * C * Ts; p.cp_bstride = cps;
+                p.film = h->D + (long)l * C * Ns; p.film_cstride = Ns; p.film_col0 = film_col0; p.film_colb = film_colb;
+                p.dil = 1 << (l % h->cfg.dilation_cycle_length);
+                p.T = T; p.tiles_per_b = (T + 31) / 32; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
+                p.first_layer = (l == 0);
+                if (ragged) { p.lens = h->lens_dev; p.cgmap = h->cg_dev[1]; p.ncg = h->cg_n[1]; }
+                timed_begin();
+                if (timed_now) wn_layer_set_timing_events(h->ev_pool[h->ev_used].first, h->ev_pool[h->ev_used].second);
+                hipError_t le = launch_wn_layer(p, C, B, st);
+                if (timed_now) wn_layer_set_timing_events(nullptr, nullptr);
+                timed_end();
+                if (le != hipSuccess) return fail(h, DSD_EHIP, "fused WaveNet layer launch failed: %s", hipGetErrorString(le));
+                xi = xo;
+                xo = (xo == h->z) ? h->xh : h->z;
+            }
+        } else
         for (int l = 0; l < L; ++l) {
             const int dil = 1 << (l % h->cfg.dilation_cycle_length);
             GemmCall g = make_gemm(h, h->g_conv[l], h->xh, xs, Ts, B, T, ST_FILM, EP_GATE, dil);
@@ -1321,6 +1374,7 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
         return fail(nullptr, DSD_EINVAL, "dsd_create: device %d out of range [0, %d)", cfg->device, ndev);
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: hipSetDevice failed");
     hipError_t ie = gemm_init_all();
+    if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_layer_init_all();
     if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
     dsd_handle* h = new dsd_handle();
     h->cfg = *cfg;
@@ -2168,6 +2222,8 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
         std::string key((const char*)prog->evals, sizeof(dsd_eval) * prog->n_evals);
         key.append((const char*)&prog->n_bufs, sizeof(int32_t));
         key.append((const char*)&noise, sizeof(noise));
+        key.append((const char*)&B, sizeof(B));             // batch shape: grids and strides are baked into the launches
+        key.append((const char*)&T, sizeof(T));
         key.push_back(h->lens_host.empty() ? 'd' : 'r');       // dense / ragged: other kernels, and grids that follow
         for (int v : h->lens_host) key.append((const char*)&v, sizeof(v));      // the lengths (baked into the launches)
         auto it = h->graphs.find(key);
@@ -2261,7 +2317,7 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
         // 2*(M*C + L*(3*C*2C + C*2C) + C*C + C*M); bytes L*24C + 2*4*M
         out->flops_per_frame_nfe = 2 * (M * C + L * (3 * C * 2 * C + C * 2 * C) + C * C + C * M);
         out->bytes_per_frame_nfe = L * 24 * C + 8 * M;
-        out->kernels_per_nfe = 1 + 2 * (int)L + 2;
+        out->kernels_per_nfe = 1 + (h->arena && wn_use_fused(h) ? 1 : 2) * (int)L + 2;    // fused: one launch per layer
     } else {
         const int64_t inner = inner_of(h), ks = h->cfg.kernel_size;
         out->flops_per_frame_nfe = 2 * (M * C + L * (C * 2 * inner + ks * inner + inner * C) + C * M);

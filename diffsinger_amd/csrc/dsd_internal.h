@@ -112,6 +112,32 @@ int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb, int resident)
 int gemm_fast_chunk_rows(int taps, int nb);
 hipError_t gemm_init_all();
 
+// wn_layer.hip: one WaveNet residual layer (conv + FiLM + gate + out-proj + residual / skip) per launch, for grids of
+// at least one 32-frame tile per CU
+struct WnLayerP {
+    const float* Aconv;     // packed dilated-conv weights (PackedGemm, pairC = C): [2C/16 blocks][C/64 * 12 k16][64][4]
+    const float* Aout;      // packed output-projection weights: [2C/16 blocks][C/16 k16][64][4]
+    const float* bias_out;  // output-projection bias [2C]
+    const float* xin;       // residual stream, internal layout [B][C][Ts]: read (tile + halo)
+    float* xout;            // residual stream after the layer (a different buffer: neighbours read xin's halo)
+    float* skip;            // running skip sum, updated in place
+    long x_bstride;         // floats between batch items of x / skip
+    int Ts;
+    const float* cp;        // this layer's hoisted conditioner projection rows [2C][Ts] (+ conv bias + its own bias)
+    long cp_bstride;
+    const float* film;      // step table: d[c] = film[c * film_cstride + film_col0 + b * film_colb]
+    int film_cstride, film_col0, film_colb;
+    int dil, T, tiles_per_b, first_layer;
+    float inv_tiles_per_b;
+    const int* lens;        // ragged batches: per-item valid length (nullptr: T)
+    const int* cgmap;       // ragged batches: the (item, 32-frame tile) column groups that hold valid frames
+    int ncg;
+};
+hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st);
+bool wn_layer_supported(int C, int dil);
+hipError_t wn_layer_init_all();
+void wn_layer_set_timing_events(hipEvent_t start, hipEvent_t stop);
+
 // aux_kernels.hip
 hipError_t launch_pack(const float* src, long sb, long sr, long st, float* dst, int B, int R, int T, int Ts,
                        hipStream_t stream);

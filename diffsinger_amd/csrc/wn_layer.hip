@@ -38,12 +38,15 @@ __device__ __forceinline__ float tanh_fast(float v) { return 1.f - 2.f * __frcp_
 __device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
 #ifdef DSD_STAMPS
-__device__ unsigned long long g_wn_stamps[4096][8];
+// [workgroup][0..7]: s_memtime at the phase boundaries; [8], [9]: s_memrealtime (100 MHz) at the first and last stamp
+__device__ unsigned long long g_wn_stamps[4096][10];
 #define WN_STAMP(i)                                                                     \
     do {                                                                                \
         if (threadIdx.x == 0 && blockIdx.x < 4096) {                                    \
             __builtin_amdgcn_sched_barrier(0);                                          \
             g_wn_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime();                  \
+            if ((i) == 0) g_wn_stamps[blockIdx.x][8] = __builtin_amdgcn_s_memrealtime(); \
+            if ((i) == 6) g_wn_stamps[blockIdx.x][9] = __builtin_amdgcn_s_memrealtime(); \
             __builtin_amdgcn_sched_barrier(0);                                          \
         }                                                                               \
     } while (0)
@@ -96,56 +99,69 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     const int Ts = p.Ts;
     WN_STAMP(0);
 
-    // ---------------- prologue: x tile + FiLM scalars, conditioner projection -> accumulators, first weights ----------------
-    const float* xb = p.xin + (long)b * p.x_bstride;
-    const float* fl = p.film + p.film_col0 + b * p.film_colb;
+    // Every global access goes through a buffer descriptor built from wave-uniform values (kernel arguments, the tile's
+    // item / first frame, the wave number): 32-bit lane offsets + SGPR offsets + immediates, no 64-bit address arithmetic.
+    // The vector-memory pipe of a CU takes ~25 cycles per wave-instruction whatever its width, so the prologue issues
+    // only what GEMM 1 cannot start without (x tile, FiLM vector, two weight steps: 30 instructions per wave); every
+    // other operand (conditioner projection, biases, residual / skip) is fetched between the MFMAs of the K walks.
+    const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
+    constexpr unsigned kRange = 0x7FFFFFF0u;
+    auto rsrc = [](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, kRange, 0x00020000); };
+    auto ld4 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    auto ld1 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    };
+
+    // ---------------- prologue: x tile, FiLM vector, first two weight steps ----------------
+    const __amdgpu_buffer_rsrc_t r_x = rsrc(p.xin + (long)bu * p.x_bstride + (t0u - HL));       // inside the arena's guard at t0 = 0
+    const __amdgpu_buffer_rsrc_t r_f = rsrc(p.film + p.film_col0 + bu * p.film_colb);
+    const float fmine = ld1(r_f, min(tid, C - 1) * p.film_cstride * 4, 0);      // d[channel tid] of this item / step
     f32x4 sv[NU];
-    float fa[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int idx = tid + 256 * u;
         const int row = idx / W4, c4 = idx - row * W4;
-        sv[u] = *reinterpret_cast<const f32x4*>(xb + (long)row * Ts + (t0 - HL + c4 * 4));
-        fa[u] = fl[row * p.film_cstride];
+        sv[u] = ld4(r_x, (row * Ts + c4 * 4) * 4, 0);
     }
-    // hoisted conditioner projection (+ conv bias + its own bias) of this wave's rows, in the accumulator layout
-    // (C/D of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + reg): the K walk accumulates on top of it
-    f32x4 acc[MBW][2];
-    {
-        const float* cpb = p.cp + (long)b * p.cp_bstride + t0 + lcol;
+    // weight streams of this wave: MBW row blocks, each a linear sequence of 1 KiB fragment blocks in K-walk order.
+    // Three fragment sets in rotation: step s runs from W[s % 3] while step s + 2's MBW loads are spread between its MFMAs
+    // (a set loaded during the previous step only would have a quarter of a step of cover for its last block).
+    const __amdgpu_buffer_rsrc_t r_w1 = rsrc(p.Aconv + (long)(MBW * wave) * NS1 * 256);
+    const __amdgpu_buffer_rsrc_t r_w2 = rsrc(p.Aout + (long)(MBW * wave) * NS2 * 256);
+    int wk1[MBW], wk2[MBW];                                     // lane offset + row-block base: the step goes into soffset / imm
 #pragma unroll
-        for (int k = 0; k < MBW; ++k) {
-            const int row0 = (k & 1) * C + (NCH * wave + (k >> 1)) * 16 + rq;     // even block: gate rows, odd: filter rows
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[k][n][r] = cpb[(long)(row0 + r) * Ts + n * 16];
-        }
+    for (int k = 0; k < MBW; ++k) {
+        wk1[k] = lane * 16 + k * NS1 * 1024;
+        wk2[k] = lane * 16 + k * NS2 * 1024;
     }
-    // weight streams of this wave: MBW row blocks, each a linear sequence of 1 KiB fragment blocks in K-walk order
-    const f32x4* a1p = reinterpret_cast<const f32x4*>(p.Aconv) + (long)(MBW * wave) * NS1 * 64 + lane;
-    const f32x4* a2p = reinterpret_cast<const f32x4*>(p.Aout) + (long)(MBW * wave) * NS2 * 64 + lane;
-    f32x4 wa[MBW], wb[MBW];
+    f32x4 W[3][MBW];
     auto load_w1 = [&](f32x4 (&dst)[MBW], int s) {
 #pragma unroll
-        for (int k = 0; k < MBW; ++k) dst[k] = a1p[(k * NS1 + s) * 64];
+        for (int k = 0; k < MBW; ++k) dst[k] = ld4(r_w1, wk1[k] + (s & 3) * 1024, (s >> 2) * 4096);
     };
     auto load_w2 = [&](f32x4 (&dst)[MBW], int s) {
 #pragma unroll
-        for (int k = 0; k < MBW; ++k) dst[k] = a2p[(k * NS2 + s) * 64];
+        for (int k = 0; k < MBW; ++k) dst[k] = ld4(r_w2, wk2[k] + (s & 3) * 1024, (s >> 2) * 4096);
     };
-    load_w1(wa, 0);
+    load_w1(W[0], 0);
+    load_w1(W[1], 1);
     WN_STAMP(1);
+    // FiLM vector -> LDS (the staging region is free until the gate), so each thread can pick the scalars of its rows
+    if (tid < C) es[tid] = fmine;
+    __syncthreads();
     // FiLM add, then the zero padding (wavenet.py:36-38: the pad is applied to x + d), then LDS
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int idx = tid + 256 * u;
         const int row = idx / W4, c4 = idx - row * W4;
+        const float fa = es[row];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int t = t0 - HL + c4 * 4 + e;
-            o[e] = (t >= 0 && t < Tb) ? sv[u][e] + fa[u] : 0.f;
+            o[e] = (t >= 0 && t < Tb) ? sv[u][e] + fa : 0.f;
         }
         *reinterpret_cast<f32x4*>(&xs[row * SW + c4 * 4]) = o;
     }
@@ -153,12 +169,21 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     WN_STAMP(2);
 
     // ---------------- GEMM 1: dilated conv, K = 3 taps x C channels ----------------
-    // B fragment of a k4 step: lane (lrow, lcol) holds stage(x)[channel 4j + lrow][column lcol (+16)] at the tap's shift
-    const float* bt = xs + lrow * SW + HL + lcol - p.dil;           // tap 0; tap 1 = + dil; tap 2 = + 2 dil
-    const int dil = p.dil;
+    f32x4 acc[MBW][2];
+#pragma unroll
+    for (int k = 0; k < MBW; ++k) {
+        acc[k][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // B fragment of a k4 step: lane (lrow, lcol) holds stage(x)[channel 4j + lrow][column lcol (+16)] at the tap's shift;
+    // one base register per tap, every other part of the address is an immediate
+    const float* bt0 = xs + lrow * SW + HL + lcol - p.dil;
+    const float* bt1 = bt0 + p.dil;
+    const float* bt2 = bt1 + p.dil;
     float bq[2][4][2];
-    auto read_b1 = [&](float (&bv)[4][2], const float* chunk_base, int i) {      // i = step within the chunk (0..11)
-        const float* base = chunk_base + (i >> 2) * dil + ((i & 3) * 16) * SW;
+    auto read_b1 = [&](float (&bv)[4][2], int s) {               // s = k16 step: [64-channel chunk][tap][k16 in chunk]
+        const int c = s / 12, i = s % 12, tap = i >> 2;
+        const float* base = (tap == 0 ? bt0 : (tap == 1 ? bt1 : bt2)) + (c * 64 + (i & 3) * 16) * SW;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bv[j][0] = base[j * 4 * SW];
@@ -174,58 +199,71 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
                 acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k][j], bv[j][1], acc[k][1], 0, 0, 0);
             }
     };
-    read_b1(bq[0], bt, 0);
-    for (int c = 0; c < NCH; ++c) {
-        const float* cb = bt + c * 64 * SW;
+    // One k16 step = 8 * MBW MFMAs on the current weights / B fragments, with the loads of step s + 2 (and one extra
+    // operand load on some steps) and the LDS reads of step s + 1 spread between them: an MFMA holds the issue port for 8
+    // of its 32 cycles, so one load behind every 8 MFMAs costs nothing, MBW loads in a row cost their issue time.
+#define WN_SPREAD()                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* the step's extra operand load, if it has one */ \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
+    _Pragma("unroll") for (int g_ = 1; g_ < MBW; ++g_) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           \
+    }                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // operands fetched during GEMM 1: the hoisted conditioner projection (+ conv bias + its own bias) of this wave's rows
+    // as row-major float4 (local row rl = idx >> 3: [0, 8 MBW) gate rows, [8 MBW, 16 MBW) filter rows), and the
+    // output-projection bias in the accumulator layout
+    constexpr int NE = 16 * MBW * (BN / 4) / 64;                // float4 per lane over the wave's 16 * MBW rows: 16 / 12
+    const int orow0 = 16 * MBW * wave;                           // first output-projection row of this wave (of 2C)
+    const int ev0 = ((lane >> 3) * Ts + (lane & 7) * 4) * 4;    // lane's float4 of row (lane >> 3); + 8 rows per m
+    const __amdgpu_buffer_rsrc_t r_c = rsrc(p.cp + (long)bu * p.cp_bstride + (long)(16 * NCH * wave) * Ts + t0u);
+    const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias_out + orow0);
+    f32x4 cpv[NE];
+    f32x4 bo[MBW];
+    read_b1(bq[0], 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 12; i += 2) {
-            const int s = c * 12 + i;
-            // step s from wa; step s + 1's weights and B fragments travel meanwhile
-            load_w1(wb, s + 1);
-            read_b1(bq[1], cb, i + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step(wa, bq[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            // step s + 1 from wb; step s + 2: next conv step, or the out-proj's first block after the last one
-            if (s + 2 < NS1) load_w1(wa, s + 2);
-            else load_w2(wa, 0);
-            if (i + 2 < 12) read_b1(bq[0], cb, i + 2);
-            else read_b1(bq[0], cb + 64 * SW, 0);           // next chunk (after the last one: unused, inside the LDS allocation)
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step(wb, bq[1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    for (int s = 0; s < NS1; ++s) {
+        // step s + 2: a conv step, or one of the out-proj's first two blocks behind the last conv steps
+        if (s + 2 < NS1) load_w1(W[(s + 2) % 3], s + 2);
+        else load_w2(W[(s + 2) % 3], s + 2 - NS1);
+        if (s < NE)                                              // filter rows sit C rows below the gate rows
+            cpv[s] = ld4(r_c, ev0, ((s % (NE / 2)) * 8 + (s >= NE / 2 ? C : 0)) * Ts * 4);
+        else if (s < NE + MBW)
+            bo[s - NE] = ld4(r_b, rq * 4, (s - NE) * 64);
+        read_b1(bq[(s + 1) & 1], s + 1 < NS1 ? s + 1 : 0);      // (after the last step: unused)
+        mfma_step(W[s % 3], bq[s & 1]);
+        WN_SPREAD()
     }
     WN_STAMP(3);
 
-    // ---------------- gate (wavenet.py:41-42) on the accumulators; z -> LDS over the dead x tile ----------------
+    // ---------------- gate (wavenet.py:41-42); z -> LDS over the dead x tile ----------------
+    // conditioner projection: row-major registers -> wave-private LDS tile -> accumulator layout
+    float* ew = es + wave * (16 * MBW * ES);                     // [16 * MBW][ES]
+#pragma unroll
+    for (int m = 0; m < NE; ++m) {
+        const int idx = lane + 64 * m;
+        *reinterpret_cast<f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]) = cpv[m];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // same wave wrote what it reads: LDS is in order per wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float zr[NCH][2][4];
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) zr[i][n][r] = sigmoid_fast(acc[2 * i][n][r]) * tanh_fast(acc[2 * i + 1][n][r]);
-    // epilogue operands (row-major float4 mapping of the wave's 16 * MBW output rows): residual stream x for waves 0, 1,
-    // running skip sum for waves 2, 3 - fetched now, consumed after GEMM 2
-    constexpr int NE = 16 * MBW * (BN / 4) / 64;                // float4 per lane: 16 (C = 256), 12 (C = 192)
-    f32x4 pre[NE];
-    const int orow0 = 16 * MBW * wave;                           // first output row of this wave (of 2C)
-    const bool is_res = orow0 < C;                               // wave-uniform
-    {
-        const float* src = is_res ? p.xin : p.skip;
-        const float* sb = src + (long)b * p.x_bstride + (long)(is_res ? orow0 : orow0 - C) * Ts + t0;
-        if (is_res || !p.first_layer) {
-#pragma unroll
-            for (int m = 0; m < NE; ++m) {
-                const int idx = lane + 64 * m;
-                pre[m] = *reinterpret_cast<const f32x4*>(sb + (long)(idx >> 3) * Ts + (idx & 7) * 4);
+            for (int r = 0; r < 4; ++r) {
+                const float cg = ew[(i * 16 + rq + r) * ES + n * 16 + lcol];
+                const float cf = ew[(8 * MBW + i * 16 + rq + r) * ES + n * 16 + lcol];
+                zr[i][n][r] = sigmoid_fast(acc[2 * i][n][r] + cg) * tanh_fast(acc[2 * i + 1][n][r] + cf);
             }
-        } else {
-#pragma unroll
-            for (int m = 0; m < NE; ++m) pre[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
     __syncthreads();                                             // every wave is done reading the x tile
     float* zs = xs;
 #pragma unroll
@@ -236,14 +274,25 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
             for (int r = 0; r < 4; ++r)
                 zs[((NCH * wave + i) * 16 + rq + r) * SZ + n * 16 + lcol] = zr[i][n][r];
 #pragma unroll
-    for (int k = 0; k < MBW; ++k) {
-        acc[k][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int k = 0; k < MBW; ++k)                                // GEMM 2 starts from its bias
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[k][0][r] = bo[k][r];
+            acc[k][1][r] = bo[k][r];
+        }
     __syncthreads();
     WN_STAMP(4);
 
     // ---------------- GEMM 2: output projection, K = C ----------------
+    // epilogue operands (row-major float4 of the wave's 16 * MBW output rows): residual stream x for waves 0, 1, running
+    // skip sum for waves 2, 3 - fetched between the MFMAs
+    f32x4 pre[NE];
+    const bool is_res = orow0 < C;                               // wave-uniform
+    const long eoff = (long)bu * p.x_bstride + (long)(is_res ? orow0 : orow0 - C) * Ts + t0u;
+    // (pointer chosen with integer arithmetic: a select between the struct FIELDS makes hipcc load the pointer itself
+    // through a dependent vector load)
+    const unsigned long long xa = (unsigned long long)p.xin, sa = (unsigned long long)p.skip;
+    const __amdgpu_buffer_rsrc_t r_e = rsrc((const float*)(is_res ? xa : sa) + eoff);
     const float* zt = zs + lrow * SZ + lcol;
     auto read_b2 = [&](float (&bv)[4][2], int s) {
 #pragma unroll
@@ -252,51 +301,48 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
             bv[j][1] = zt[(s * 16 + j * 4) * SZ + 16];
         }
     };
+    static_assert(NS1 % 3 == 0 && NE <= NS2, "buffer rotation continues across the two GEMMs; one operand load per step");
     read_b2(bq[0], 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < NS2; s += 2) {
-        load_w2(wb, s + 1);
-        read_b2(bq[1], s + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step(wa, bq[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < NS2) {
-            load_w2(wa, s + 2);
-            read_b2(bq[0], s + 2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step(wb, bq[1]);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < NS2; ++s) {
+        if (s + 2 < NS2) load_w2(W[(s + 2) % 3], s + 2);
+        if (s < NE) pre[s] = ld4(r_e, ev0, s * 8 * Ts * 4);
+        read_b2(bq[(s + 1) & 1], s + 1 < NS2 ? s + 1 : 0);
+        mfma_step(W[s % 3], bq[s & 1]);
+        WN_SPREAD()
     }
+#undef WN_SPREAD
     WN_STAMP(5);
 
     // ---------------- epilogue: residual / skip (wavenet.py:45-48) ----------------
-    float* ew = es + wave * (16 * MBW * ES);                     // wave-private tile [16 * MBW][ES]
 #pragma unroll
     for (int k = 0; k < MBW; ++k)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ew[(k * 16 + rq + r) * ES + n * 16 + lcol] = acc[k][n][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // same wave wrote what it reads: LDS is in order per wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float* dst = (is_res ? p.xout : p.skip) + (long)b * p.x_bstride + (long)(is_res ? orow0 : orow0 - C) * Ts + t0;
+    {
+        const unsigned long long xo = (unsigned long long)p.xout;
+        const __amdgpu_buffer_rsrc_t r_o = rsrc((const float*)(is_res ? xo : sa) + eoff);
+        // (x + o) / sqrt(2) as a multiplication by the fp32 reciprocal, the way torch's CUDA division by a Python scalar
+        // evaluates it (the IEEE division sequence is ~10 VALU operations per element: 4 k cycles of this epilogue);
+        // the first layer's skip sum is the layer's own output (the buffer holds the previous evaluation's sum)
+        const float scale = is_res ? 0.70710678118654752440f : 1.f;
+        const bool add_pre = is_res || !p.first_layer;
 #pragma unroll
-    for (int m = 0; m < NE; ++m) {
-        const int idx = lane + 64 * m;
-        const int rl = idx >> 3, c4 = idx & 7;
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ew[rl * ES + c4 * 4]);
-        const float bv = p.bias_out[orow0 + rl];
-        f32x4 o;
-        if (is_res) {
+        for (int m = 0; m < NE; ++m) {
+            const int idx = lane + 64 * m;
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]);
+            f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (pre[m][e] + (a4[e] + bv)) / 1.41421356237309504880f;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pre[m][e] + (a4[e] + bv);
+            for (int e = 0; e < 4; ++e) o[e] = ((add_pre ? pre[m][e] : 0.f) + a4[e]) * scale;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), r_o, ev0,
+                                                   m * 8 * Ts * 4, 0);
         }
-        *reinterpret_cast<f32x4*>(dst + (long)rl * Ts + c4 * 4) = o;
     }
     WN_STAMP(6);
 }

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Diagnostic (never shipped, never timed): builds libdsdenoise with -DDSD_STAMPS, runs backbone evaluations with the
+fused WaveNet layer kernel (wn_layer.hip) and prints where wave 0 of a workgroup spends its cycles, plus the in-kernel
+clock (s_memtime / s_memrealtime).  Usage on the GPU box: python tools/stamp_wn_layer.py [B] [T] [-DNAME ...]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "diffsinger_amd", "csrc")
+OUT = os.path.join(ROOT, "diffsinger_amd", "libdsdenoise_stamps.so")
+srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "wn_layer.hip", "aux_kernels.hip", "encoder_kernels.hip",
+                                        "vocoder_kernels.hip", "tconv.hip", "api.hip")]
+extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DDSD_STAMPS",
+                "-w", "-shared", "-o", OUT] + extra + srcs, check=True)
+if "--build-only" in sys.argv:
+    sys.exit(0)
+os.environ["DSD_FUSED_LAYER"] = "1"
+
+import numpy as np
+import torch
+from diffsinger_amd import _lib
+_lib.LIB_PATH = OUT
+from diffsinger_amd import synth
+from diffsinger_amd.hparams import hparams
+hparams.update(hidden_size=256)
+from diffsinger_amd.backbones import build_backbone
+
+args = [a for a in sys.argv[1:] if not a.startswith("-")]
+B = int(args[0]) if args else 8
+T = int(args[1]) if len(args) > 1 else 1000
+bargs = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+net = build_backbone(128, 1, "wavenet", bargs)
+sd = synth.synth_state_dict(synth.backbone_param_shapes("wavenet", 128, 1, **bargs), 42)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+net = net.cuda().eval()
+x = torch.randn(B, 1, 128, T, device="cuda")
+c = torch.randn(B, 256, T, device="cuda")
+t = torch.full((B,), 500.0, device="cuda")
+with torch.no_grad():
+    for _ in range(20):         # the stamps of the LAST layer launch survive; the chip is warm by then
+        net(x, t, c)
+torch.cuda.synchronize()
+buf = np.zeros((4096, 10), dtype=np.uint64)
+rc = _lib.lib().dsd_dbg_read_wn_stamps(buf.ctypes.data_as(C.c_void_p))
+assert rc == 0
+st = buf.astype(np.int64)
+live = st[:, 0] > 0
+st = st[live]
+labels = ["tile decode -> loads issued (x, FiLM, cond-proj, weights)", "x tile landed, FiLM + mask, LDS write, barrier",
+          "GEMM 1 (conv, 3072 MFMA per wave)", "gate + barrier + z -> LDS + barrier", "GEMM 2 (out-proj, 1024 MFMA per wave)",
+          "epilogue (LDS transpose, residual / skip, stores)"]
+d = np.diff(st[:, :7], axis=1)
+life = st[:, 6] - st[:, 0]
+real = (st[:, 9] - st[:, 8]) * 10e-9          # s_memrealtime ticks at 100 MHz
+clk = life / np.maximum(real, 1e-12) / 1e9
+print(f"{live.sum()} workgroups; kernel span {st[:, 6].max() - st[:, 0].min()} cyc; start skew {st[:, 0].max() - st[:, 0].min()} cyc; "
+      f"mean life {life.mean():.0f} cyc (min {life.min()}, max {life.max()}); in-kernel clock {np.median(clk):.3f} GHz "
+      f"-> {np.median(real) * 1e6:.1f} us per workgroup")
+for lb, m, mn, mx in zip(labels, d.mean(axis=0), d.min(axis=0), d.max(axis=0)):
+    print(f"    {lb:62s} mean {m:8.0f}  min {mn:8.0f}  max {mx:8.0f}")
