@@ -7,12 +7,16 @@
 
 Workload (BASELINE.json configs[1]): WaveNet 20 layers x 256 channels (dilation cycle 4, 128 mel bins,
 hidden 256), DPM-Solver++ 2M 1000 -> 50 steps (50 NFE), B = 1 utterance of T = 1000 frames per GPU, fp32,
-synthetic seeded weights/inputs.  One "step" = one whole sampling loop over the batch (cond hoist +
-50 NFE + fused solver updates + transposed/denormalised mel); inputs are resident in HBM when the timed
-region starts.  With N > 1 ranks each rank denoises its own utterances (weak scaling); the only exchange
-is the cond scatter before and the mel gather after the loop (RCCL over xGMI), both inside the timed step.
+synthetic seeded weights/inputs.  One "step" = one whole sampling loop over the batch: the per-utterance hoist of
+every layer's conditioner projection (dsd_prepare_cond - a fresh condition tensor every step, as a real caller
+has), 50 NFE with fused solver updates, transposed / denormalised mel; inputs are resident in HBM when the timed
+region starts.  With N > 1 ranks each rank denoises its own utterances (weak scaling); the only exchange is the
+cond scatter before and the mel gather after the loop (RCCL over xGMI), both inside the timed step, through
+buffers allocated once (sharding.Exchange).  --ragged: BASELINE configs[3] as SURVEY 8(d) specifies it - the
+utterances' lengths are drawn from {512, 768, 1024, 1280, 1536} (seed 1234), partitioned longest-first over the
+ranks and run as ragged batches (dsd_set_lengths); frames = the VALID frames.
 
-value = mel-frames/s per denoise step = N * B * T * NFE / seconds per step  (whole-job aggregate).
+value = mel-frames/s per denoise step = (valid frames of all N * B utterances) * NFE / seconds per step.
 """
 from __future__ import annotations
 
@@ -40,6 +44,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1000, help="mel frames per utterance (T)")
     ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100", "acoustic_default", "acoustic_e2e", "acoustic_wav", "variance_reflow20"])
+    ap.add_argument("--ragged", action="store_true",
+                    help="utterance lengths drawn from {512,768,1024,1280,1536} (seed 1234), longest-first shards, ragged batches")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -197,13 +203,26 @@ def main():
     d.use_graph = not args.no_graph
 
     n_utt = world * B
-    cond_all = None
+    lengths = None
+    if args.ragged:         # BASELINE configs[3] as specified: T drawn per utterance, seed 1234
+        assert args.workload == "wavenet_dpm50", "--ragged is defined for the WaveNet / DPM-Solver++ workload"
+        import random
+        rnd = random.Random(1234)
+        lengths = [rnd.choice([512, 768, 1024, 1280, 1536]) for _ in range(n_utt)]
+        T = max(lengths)
+        shards = sharding.shard_longest_first(lengths, world)
+    else:
+        shards = [list(r) for r in sharding.shard_ranges(n_utt, world)]
+    mine = shards[rank]
+    my_lens = [lengths[i] for i in mine] if lengths else None
+    # two condition tensors used in turn: every step sees a tensor it has not hoisted yet, as a real caller's does
+    cond_bufs = None
     if rank == 0:
-        cond_all = torch.from_numpy(synth.synth_normal((n_utt, T, 256), 0)).to(device)
-    mine = sharding.shard_ranges(n_utt, world)[rank]
+        cond_bufs = [torch.from_numpy(synth.synth_normal((n_utt, T, 256), k)).to(device) for k in (0, 7)]
+    cond_all = cond_bufs[0] if rank == 0 else None
     noise = sharding.utterance_noise((1, 64 if variance is not None else 128, T), mine, seed=1, device=device)  # x_T, resident
     noise_v = sharding.utterance_noise((2, 24, T), mine, seed=2, device=device) if variance is not None else None
-    cond_local = cond_all if not use_dist else None
+    exchange = sharding.Exchange(shards, T, 256, 3 if variance is not None else 128, device) if use_dist else None
 
     n_tok = 120
     mel2ph = (torch.arange(T, device=device) * n_tok // T + 1).to(torch.long)[None].expand(len(mine), T).contiguous()
@@ -226,13 +245,15 @@ def main():
                 return acoustic(c, mel2ph, infer=True, noise=noise).diff_out
         if variance is not None:        # [n, T, 3]: delta pitch, energy, breathiness (toplevel.py:262-309 runs them in this order)
             return torch.stack([d(c, infer=True, noise=noise)] + list(variance(c, infer=True, noise=noise_v)), dim=-1)
+        if my_lens is not None:
+            return d(c, infer=True, noise=noise, lengths=my_lens)
         return d(c, infer=True, noise=noise)
 
-    def step():
+    def step(i):
         if not use_dist:
-            return run(cond_local)
-        c = sharding.scatter_condition(cond_all, n_utt, T, 256, device)
-        return sharding.gather_mels(run(c), n_utt)
+            return run(cond_bufs[i & 1])
+        c = exchange.scatter(cond_bufs[i & 1] if rank == 0 else None)
+        return exchange.gather(run(c))
 
     def sync():
         torch.cuda.synchronize(device)
@@ -240,22 +261,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        out = step()
+    for i in range(args.warmup):
+        out = step(i)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0          # this rank's K steps, from the common start to its own last kernel
     sync()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
+    if use_dist:                                # the job's time = the slowest rank's
         el = torch.tensor([elapsed], device=sharding._staging(device), dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
     if rank == 0:
         assert out is not None and torch.isfinite(out).all()
     sec_per_step = elapsed / max(args.steps, 1)
-    frames = n_utt * T * nfe
+    utt_frames = sum(lengths) if lengths else n_utt * T
+    frames = utt_frames * nfe
     value = frames / sec_per_step
 
     stats = dict(d.denoise_fn.stats())
@@ -271,9 +294,12 @@ def main():
         "ms_per_step": round(sec_per_step * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wname, "utterances_per_gpu": B, "frames": T, "nfe": nfe,
-                   "hipgraph": bool(d.use_graph), "sharding": f"{world} rank(s) x {B} utterance(s), cond scatter + mel gather"},
-        "rtf": round(sec_per_step / (n_utt * T * HOP / SR), 6),
+        "config": {"workload": wname + (", utterance lengths drawn from {512,768,1024,1280,1536} (seed 1234)" if lengths else ""),
+                   "utterances_per_gpu": B, "frames": (round(utt_frames / n_utt, 1) if lengths else T), "nfe": nfe,
+                   "hipgraph": bool(d.use_graph),
+                   "sharding": f"{world} rank(s) x {B} utterance(s), " + ("longest-first by length, ragged batches, " if lengths else "")
+                               + "cond scatter + mel gather"},
+        "rtf": round(sec_per_step / (utt_frames * HOP / SR), 6),
         "ms_per_nfe": round(sec_per_step * 1e3 / nfe, 5),
         "path_tflops": round(stats["flops_per_frame_nfe"] * frames / sec_per_step / 1e12 / world, 3),
         "path_mfma_frac": round(stats["flops_per_frame_nfe"] * frames / sec_per_step / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -288,7 +314,7 @@ def main():
         h = d.denoise_fn._handle
         _lib.check(h, _lib.lib().dsd_kernel_timing(h, 1), "dsd_kernel_timing")
         t_pass = time.perf_counter()
-        run(cond_all[:len(mine)] if use_dist else cond_local)
+        run(cond_all[mine] if use_dist else cond_all)
         torch.cuda.synchronize(device)
         t_pass = (time.perf_counter() - t_pass) * 1e3
         raw_ms, empty_ms, n = C.c_double(), C.c_double(), C.c_int64()
@@ -298,19 +324,25 @@ def main():
         mean_ms = raw_ms
         _lib.check(h, _lib.lib().dsd_kernel_timing(h, 0), "dsd_kernel_timing")
         Cc = bargs["num_channels"]
-        if kind == "wavenet":
-            kflops = 2 * 3 * Cc * 2 * Cc * B * T              # 786,432 FLOP/frame
-            kbytes = (4 * Cc + 8 * Cc + 4 * Cc) * B * T       # read x, read hoisted cond-proj, write gated z
+        fused = kind == "wavenet" and stats["kernels_per_nfe"] == bargs["num_layers"] + 3
+        vf = (sum(my_lens) if my_lens else B * T)             # frames one launch covers on this rank
+        if fused:
+            kflops = 2 * (3 * Cc * 2 * Cc + Cc * 2 * Cc) * vf     # conv 786,432 + out-proj 262,144 FLOP/frame
+            kbytes = 24 * Cc * vf                                  # x r/w, hoisted cond-proj read, skip sum r/w
+            kname = "wn_layer_kernel (dilated conv k=3 + FiLM + gate + 1x1 out-proj + residual / skip, one launch per layer)"
+        elif kind == "wavenet":
+            kflops = 2 * 3 * Cc * 2 * Cc * vf                 # 786,432 FLOP/frame
+            kbytes = (4 * Cc + 8 * Cc + 4 * Cc) * vf          # read x, read hoisted cond-proj, write gated z
             kname = "gemm_kernel<ST_FILM,3,EP_GATE> (dilated conv k=3 + FiLM + sigmoid*tanh gate)"
         else:
             inner = Cc * bargs["expansion_factor"]
-            kflops = 2 * Cc * 2 * inner * B * T
-            kbytes = (4 * Cc + 4 * inner) * B * T
+            kflops = 2 * Cc * 2 * inner * vf
+            kbytes = (4 * Cc + 4 * inner) * vf
             kname = "gemm_kernel<ST_LN,1,EP_SWIGLU> (LayerNorm -> 1x1 C->4C -> SwiGLU)"
         traffic, traffic_src, prof_ns, prof_split = None, None, None, None
         try:   # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of this same command
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            ent = tj.get(f"{args.workload}/B{B}/T{T}")
+            ent = tj.get(f"{args.workload}{'_ragged' if lengths else ''}/B{B}/T{T}")
             if ent:
                 traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
                 prof_ns, prof_split = ent.get("rocprof_avg_ns"), ent.get("rocprof_split_ns")
@@ -318,14 +350,8 @@ def main():
             pass
         sec = mean_ms.value / 1e3
         ach = kflops / sec / 1e12 if sec > 0 else 0.0
-        meas = None
-        try:   # sustained v_mfma_f32_16x16x4_f32 rate measured on an MI355X of this pool (tools/peak_bench.hip)
-            meas = json.load(open(os.path.join(ROOT, "profiles", "r01_measured_peaks.json")))["mfma_f32_16x16x4_tflops"]
-        except Exception:
-            pass
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                              "peak_measured": meas, "frac_of_measured": None if not meas else round(ach / meas, 4),
                               "traffic_source": traffic_src,
                               "kernel": kname, "launches_timed": int(n.value),
                               "avg_launch_us": round(mean_ms.value * 1e3, 3), "timing_pass_ms": round(t_pass, 2),

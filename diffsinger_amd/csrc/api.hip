@@ -1126,8 +1126,10 @@ int run_gemm(dsd_handle* h, const GemmCall& c, hipStream_t st) {
 
 // WaveNet: one fused launch per residual layer (wn_layer.hip) when the grid gives (nearly) every CU a full-row tile of 32
 // frames; else the two-GEMM path of gemm.hip, whose 8x finer row tiles fill the chip from a single utterance.  A fused
-// launch is ceil(tiles / 256) rounds of one tile per CU (~t_tile each, MFMA-bound); the two launches cost a fixed part
-// plus a slope per tile (2 x 7.7 us + 8.6 ns per frame at B >= 6).  DSD_FUSED_LAYER=0/1 forces the choice.
+// launch is ceil(tiles / 256) rounds of one tile per CU, ~67 us each at C = 256 (63 us of it the tile's own 152 k cycles);
+// the two launches cost a fixed part plus a slope per tile (measured: 13 us + 0.275 us per tile from B = 5 up).  Batch
+// sweep at T = 1000 (profiles/r02_sweep_fused.txt): fused wins at B = 7-8, 14-16, 22-24, the split path in between.
+// DSD_FUSED_LAYER=0/1 forces the choice.
 bool wn_use_fused(const dsd_handle* h) {
     if (!is_wavenet(h)) return false;
     const int C = C_of(h);
@@ -1140,10 +1142,10 @@ bool wn_use_fused(const dsd_handle* h) {
     long tiles = 0;
     if (ragged) for (int v : h->lens_host) tiles += (v + 31) / 32;
     else tiles = (long)h->B * ((h->T + 31) / 32);
-    static const double t_tile = getenv("DSD_FUSED_TILE_US") ? atof(getenv("DSD_FUSED_TILE_US")) : 62.0;
+    static const double t_tile = getenv("DSD_FUSED_TILE_US") ? atof(getenv("DSD_FUSED_TILE_US")) : 67.0;
     const double scale = (double)C / 256.0 * C / 256.0;                 // FLOPs per frame ~ C^2
     const double fused = (double)((tiles + 255) / 256) * t_tile * scale;
-    const double split = 15.4 + 0.275 * (double)tiles * scale;
+    const double split = 13.0 + 0.275 * (double)tiles * scale;
     return tiles >= 128 && fused < split;
 }
 

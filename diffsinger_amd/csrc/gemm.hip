@@ -49,8 +49,8 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-
 // Gate nonlinearities on the hardware exp / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).  Absolute error of
 // sigmoid(g) * tanh(f) stays below 3e-7 - far inside the 2e-5 per-evaluation parity tolerance - at a fifth of
 // the instruction count of libm's expf / tanhf (the gate is ~1 k cycles of a 23 k-cycle workgroup at B = 1).
-__device__ __forceinline__ float sigmoid_fast(float v) { return __frcp_rn(1.f + __expf(-v)); }
-__device__ __forceinline__ float tanh_fast(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
+__device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float tanh_fast(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * v)); }
 
 #ifdef DSD_STAMPS
 // Diagnostic build only (tools/stamp_profile.py): wave 0 of every workgroup records s_memtime at phase
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
                     f32x4 o;
                     if (row < p.C) {                                   // residual half (wavenet.py:47-48)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (pre[k][e] + (a4[e] + bv)) / 1.41421356237309504880f;
+                        for (int e = 0; e < 4; ++e) o[e] = (pre[k][e] + (a4[e] + bv)) * 0.70710678118654752440f;   // as torch's division by a Python scalar on the GPU: times the fp32 reciprocal
                         *reinterpret_cast<f32x4*>(p.x + colo + (long)row * p.o_rstride) = o;
                     } else {                                           // skip half: running sum replaces stack+sum (wavenet.py:96)
 #pragma unroll

@@ -33,8 +33,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ float sigmoid_fast(float v) { return __frcp_rn(1.f + __expf(-v)); }
-__device__ __forceinline__ float tanh_fast(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
+__device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float tanh_fast(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * v)); }
 __device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
 #ifdef DSD_STAMPS
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     load_w1(W[1], 1);
     WN_STAMP(1);
     // FiLM vector -> LDS (the staging region is free until the gate), so each thread can pick the scalars of its rows
-    if (tid < C) es[tid] = fmine;
+    es[tid] = fmine;                                             // (threads beyond C: a copy of the last channel's, unused)
     __syncthreads();
     // FiLM add, then the zero padding (wavenet.py:36-38: the pad is applied to x + d), then LDS
 #pragma unroll

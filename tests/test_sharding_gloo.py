@@ -92,7 +92,7 @@ def ragged_sampler(cond, noise, lengths):
     return out
 
 
-def _worker_ragged(rank, world, port, n_utt, seed, q):
+def _worker_ragged(rank, world, port, n_utt, seed, q, partition="contiguous"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -102,7 +102,7 @@ def _worker_ragged(rank, world, port, n_utt, seed, q):
         noise = sharding.utterance_noise((1, M, T), range(n_utt), seed, torch.device("cpu"))
         want = ragged_sampler(cond_all, noise, lens)
         out = sharding.sharded_sample(ragged_sampler, cond_all if rank == 0 else None, n_utt, T, H, (1, M, T), seed,
-                                      torch.device("cpu"), lengths=lens if rank == 0 else None)
+                                      torch.device("cpu"), lengths=lens if rank == 0 else None, partition=partition)
         if rank == 0:
             q.put(("ok", bool(torch.equal(out, want)), tuple(out.shape)))
     except Exception as e:  # pragma: no cover
@@ -127,3 +127,78 @@ def test_sharded_ragged_lengths_reach_their_rank(world, n_utt):
         assert p.exitcode == 0
     status, same, shape = q.get()
     assert status == "ok" and same and shape == (n_utt, T, M)
+
+
+@pytest.mark.parametrize("world,n_utt", [(2, 7), (3, 8)])
+def test_sharded_ragged_longest_first_partition(world, n_utt):
+    """Length-balanced (longest-first) shards are not contiguous: the gathered result must still come back in utterance
+    order and equal the single-process one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, n_utt, 79, q, "longest_first")) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    status, same, shape = q.get()
+    assert status == "ok" and same and shape == (n_utt, T, M)
+
+
+def test_shard_longest_first_properties():
+    import random
+    rnd = random.Random(1234)
+    for world in (1, 2, 3, 4, 8):
+        for n in (0, 1, 5, 8, 64):
+            lens = [rnd.choice([512, 768, 1024, 1280, 1536]) for _ in range(n)]
+            shards = sharding.shard_longest_first(lens, world)
+            assert len(shards) == world
+            assert sorted(i for s in shards for i in s) == list(range(n))        # a partition
+            assert all(s == sorted(s) for s in shards)
+            assert shards == sharding.shard_longest_first(lens, world)           # deterministic
+            if n >= world:
+                load = [sum((lens[i] + 31) // 32 for i in s) for s in shards]
+                # the busiest rank carries at most the mean load plus one utterance
+                assert max(load) <= sum(load) / world + max((v + 31) // 32 for v in lens)
+    # BASELINE config 4 as specified (64 utterances, T drawn from {512, ..., 1536}, seed 1234, 8 ranks)
+    rnd = random.Random(1234)
+    lens = [rnd.choice([512, 768, 1024, 1280, 1536]) for _ in range(64)]
+    load = [sum((lens[i] + 31) // 32 for i in s) for s in sharding.shard_longest_first(lens, 8)]
+    assert max(load) / (sum(load) / 8) < 1.03
+
+
+def _worker_exchange(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for shards in ([list(r) for r in sharding.shard_ranges(6, world)], sharding.shard_longest_first([9, 3, 12, 5, 7, 2], world)):
+            ex = sharding.Exchange(shards, T, H, M, torch.device("cpu"))
+            for step in range(3):           # the same buffers serve every step
+                g = torch.Generator().manual_seed(100 + step)
+                cond_all = torch.randn(6, T, H, generator=g)
+                c = ex.scatter(cond_all if rank == 0 else None)
+                ok = ok and torch.equal(c, cond_all[shards[rank]])
+                out = ex.gather(c[..., :M] * 2.0)
+                if rank == 0:
+                    ok = ok and torch.equal(out, cond_all[..., :M] * 2.0)
+        q.put(("ok", bool(ok), rank)) if rank == 0 else None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_buffers_reused_across_steps(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    status, same, _ = q.get()
+    assert status == "ok" and same
