@@ -108,9 +108,9 @@ class GaussianDiffusion(nn.Module, _SamplerMixin):
             assert k_step <= timesteps, 'K_step should not be larger than timesteps.'
         self.timesteps = timesteps
         self.k_step = k_step if self.use_shallow_diffusion else timesteps
-        self._tables = schedule.DDPMTables(betas)
+        tables = schedule.DDPMTables(betas)
         for name in schedule.DDPMTables.NAMES:
-            self.register_buffer(name, torch.from_numpy(getattr(self._tables, name).copy()))
+            self.register_buffer(name, torch.from_numpy(getattr(tables, name).copy()))
         self.register_buffer('spec_min', _spec_buffer(spec_min, out_dims))
         self.register_buffer('spec_max', _spec_buffer(spec_max, out_dims))
         # for compatibility with ONNX continuous acceleration
@@ -118,6 +118,21 @@ class GaussianDiffusion(nn.Module, _SamplerMixin):
         self.t_start = 1 - self.k_step / self.timesteps
         factors = torch.LongTensor([i for i in range(1, self.timesteps + 1) if self.timesteps % i == 0])
         self.register_buffer('timestep_factors', factors, persistent=False)
+
+    @property
+    def _tables(self) -> schedule.DDPMTables:
+        """Host view of the schedule buffers AS THEY STAND: the buffers are persistent, so `load_state_dict` may replace the
+        schedule the constructor derived from hparams - and the reference reads the buffers (ddpm.py:117-167).  Rebuilt
+        (and every cached program dropped) whenever a buffer was reassigned or written in place."""
+        bufs = [getattr(self, n) for n in schedule.DDPMTables.NAMES]
+        key = tuple((b.data_ptr(), b._version) for b in bufs)
+        if getattr(self, '_tables_key', None) != key:
+            view = schedule.DDPMTables.from_arrays(
+                {n: b.detach().cpu().numpy() for n, b in zip(schedule.DDPMTables.NAMES, bufs)})
+            object.__setattr__(self, '_tables_view', view)
+            object.__setattr__(self, '_tables_key', key)
+            self._prog_cache().clear()
+        return self._tables_view
 
     # ---- closed forms kept for API parity (ddpm.py:117-135, 206-210) ---------------------------
     def q_sample(self, x_start, t, noise):
@@ -134,36 +149,24 @@ class GaussianDiffusion(nn.Module, _SamplerMixin):
         raise NotImplementedError("diffsinger_amd is inference-only; train with the reference GaussianDiffusion")
 
     # ---- the loop (ddpm.py:221-351) -----------------------------------------------------------
-    @torch.no_grad()
-    def inference(self, cond, b=1, x_start=None, device=None, *, noise=None, step_noise=None, _denorm=False):
-        depth = hparams.get('K_step_infer', self.k_step)
-        speedup = hparams['diff_speedup']
-        if speedup > 0:
-            assert depth % speedup == 0, f'Acceleration ratio must be a factor of diffusion depth {depth}.'
-        if noise is None:
-            noise = torch.randn(b, self.num_feats, self.out_dims, cond.shape[2], device=device)
-        if self.use_shallow_diffusion:
-            t_max = min(depth, self.k_step)
-        else:
-            t_max = self.k_step
+    def _affine_out(self):
+        """denorm_spec folded into the unpack: (x+1)/2*(max-min)+min = x*scale + shift, one value per (feature, bin)."""
+        rng = (self.spec_max - self.spec_min).reshape(-1)
+        return _expand_fm(self, rng / 2), _expand_fm(self, rng / 2 + self.spec_min.reshape(-1))
 
+    def _start_state(self, t_max, x_start, noise, b, device):
+        """x_T, the forward-diffused shallow source q(x_{t_max-1} | x_start), or the source itself (ddpm.py:232-243)."""
         if t_max >= self.timesteps:
-            x = noise
-        elif t_max > 0:
-            assert x_start is not None, 'Missing shallow diffusion source.'
-            x = self.q_sample(x_start, torch.full((b,), t_max - 1, device=device, dtype=torch.long), noise)
-        else:
-            assert x_start is not None, 'Missing shallow diffusion source.'
-            x = x_start
+            return noise
+        assert x_start is not None, 'Missing shallow diffusion source.'
+        if t_max > 0:
+            return self.q_sample(x_start, torch.full((b,), t_max - 1, device=device, dtype=torch.long), noise)
+        return x_start
 
-        scale = shift = None
-        if _denorm:   # denorm_spec folded into the unpack: (x+1)/2*(max-min)+min = x*scale + shift
-            rng = (self.spec_max - self.spec_min).reshape(-1)
-            scale = self._expand_fm(rng / 2)
-            shift = self._expand_fm(rng / 2 + self.spec_min.reshape(-1))
+    def _run_loop(self, cond, x, t_max, speedup, algorithm, b, device, step_noise, scale, shift):
+        """The sampler dispatch of ddpm.py:245-351 on (t_max, speedup) that the caller has already decided."""
         tb = self._tables
         if speedup > 1 and t_max > 0:
-            algorithm = hparams['diff_accelerator']
             if algorithm == 'dpm-solver':
                 entry = self._cached_program(('dpm', t_max, speedup), lambda: schedule.dpm_solver_pp_program(
                     self.betas[:t_max].cpu(), t_max // speedup))
@@ -201,15 +204,19 @@ class GaussianDiffusion(nn.Module, _SamplerMixin):
             hi = lo
         return x
 
-    def _expand_fm(self, v):
-        # per-(f, m) vector of length F*M from a spec_min/max-shaped tensor ([1,1,M] or [1,F,1,1])
-        f, m = self.num_feats, self.out_dims
-        v = v.reshape(-1)
-        if v.numel() == 1:
-            return v.expand(f * m).contiguous()
-        if f == 1:
-            return v.expand(m).contiguous() if v.numel() == 1 else v.contiguous()
-        return v.reshape(f, 1).expand(f, m).reshape(-1).contiguous()
+    @torch.no_grad()
+    def inference(self, cond, b=1, x_start=None, device=None, *, noise=None, step_noise=None, _denorm=False):
+        depth = hparams.get('K_step_infer', self.k_step)
+        speedup = hparams['diff_speedup']
+        if speedup > 0:
+            assert depth % speedup == 0, f'Acceleration ratio must be a factor of diffusion depth {depth}.'
+        if noise is None:
+            noise = torch.randn(b, self.num_feats, self.out_dims, cond.shape[2], device=device)
+        t_max = min(depth, self.k_step) if self.use_shallow_diffusion else self.k_step
+        x = self._start_state(t_max, x_start, noise, b, device)
+        scale, shift = self._affine_out() if _denorm else (None, None)
+        return self._run_loop(cond, x, t_max, speedup, hparams['diff_accelerator'] if speedup > 1 else None,
+                              b, device, step_noise, scale, shift)
 
     def forward(self, condition, gt_spec=None, src_spec=None, infer=True, *, noise=None, step_noise=None, lengths=None):
         """
@@ -217,25 +224,39 @@ class GaussianDiffusion(nn.Module, _SamplerMixin):
             `lengths` [B]: ragged batch - item b is run as if alone at T = lengths[b] (dsd_set_lengths); frames beyond
             an item's length are unspecified in the result.
         """
-        cond = condition.transpose(1, 2)
-        b, device = condition.shape[0], condition.device
         if not infer:
             raise NotImplementedError(
                 "diffsinger_amd.GaussianDiffusion is inference-only (infer=True); train with the reference module")
-        if src_spec is not None:
-            spec = self.norm_spec(src_spec).transpose(-2, -1)
-            if self.num_feats == 1:
-                spec = spec[:, None, :, :]
-        else:
-            spec = None
-        if lengths is not None:
-            self.denoise_fn.set_lengths(lengths, device)
-        try:
+        cond = condition.transpose(1, 2)
+        b, device = condition.shape[0], condition.device
+        spec = None if src_spec is None else _to_bfmt(self.norm_spec(src_spec), self.num_feats)
+        with _ragged(self.denoise_fn, lengths, device):
             x = self.inference(cond, b=b, x_start=spec, device=device, noise=noise, step_noise=step_noise, _denorm=True)
-        finally:
-            if lengths is not None:
-                self.denoise_fn.set_lengths(None, device)
         return self._finish_denorm(x)
+
+    @torch.no_grad()
+    def forward_onnx(self, condition, x_start=None, depth=None, steps: int = 10, *, noise=None, step_noise=None):
+        """The runtime inputs of the ONNX deployment twin, `GaussianDiffusionONNX.forward(condition, x_start, depth, steps)`
+        (deployment/modules/diffusion.py:105-161): `steps` and `depth` arrive per call, any `steps` is legal - the
+        speed-up is snapped to a factor of `timesteps` (no source) or the depth rounded down to a multiple of the
+        speed-up (with one) where `inference()` asserts divisibility - DDIM only (ancestral when the speed-up is 1), and
+        norm / denorm are the twin's (x - b) / k and x * k + b.  Repeat-bin subclasses return what the twin's
+        `denorm_spec` returns (:185-190, :217-222): the mean over the bins, unclamped and not split (`clamp_spec` is a
+        separate graph there); their twins do not override `norm_spec`, so an `x_start` is taken as it comes."""
+        cond = condition.transpose(1, 2)
+        b, device = condition.shape[0], condition.device
+        if noise is None:       # the twin is exported for one utterance per call (:109); a batch draws one x_T per item
+            noise = torch.randn((b, self.num_feats, self.out_dims, cond.shape[2]), device=device)
+        k, mid = (self.spec_max - self.spec_min) / 2., (self.spec_max + self.spec_min) / 2.
+        t_max, speedup = schedule.onnx_ddpm_plan(self.timesteps, self.k_step, self.timestep_factors.cpu(), steps,
+                                                 None if x_start is None else depth)
+        if x_start is None:
+            x = noise
+        else:
+            x = self._start_state(t_max, _to_bfmt((x_start - mid) / k, self.num_feats), noise, b, device)
+        x = self._run_loop(cond, x, t_max, speedup, 'ddim', b, device, step_noise,
+                           _expand_fm(self, k.reshape(-1)), _expand_fm(self, mid.reshape(-1)))
+        return self._reduce_bins(x)
 
     def norm_spec(self, x):
         return (x - self.spec_min) / (self.spec_max - self.spec_min) * 2 - 1
@@ -243,119 +264,48 @@ class GaussianDiffusion(nn.Module, _SamplerMixin):
     def denorm_spec(self, x):
         return (x + 1) / 2 * (self.spec_max - self.spec_min) + self.spec_min
 
+    # hooks of the repeat-bin codecs below; identities for a plain spectrogram
     def _finish_denorm(self, x):
         return x
 
+    def _pre_norm(self, x):
+        return x
 
-class RepetitiveDiffusion(GaussianDiffusion):
-    def __init__(self, vmin: float | int | list, vmax: float | int | list,
-                 repeat_bins: int, timesteps=1000, k_step=1000,
-                 backbone_type=None, backbone_args=None,
-                 betas=None):
-        assert (isinstance(vmin, (float, int)) and isinstance(vmin, (float, int))) or len(vmin) == len(vmax)
-        num_feats = 1 if isinstance(vmin, (float, int)) else len(vmin)
-        spec_min = [vmin] if num_feats == 1 else [[v] for v in vmin]
-        spec_max = [vmax] if num_feats == 1 else [[v] for v in vmax]
-        self.repeat_bins = repeat_bins
-        super().__init__(
-            out_dims=repeat_bins, num_feats=num_feats,
-            timesteps=timesteps, k_step=k_step,
-            backbone_type=backbone_type, backbone_args=backbone_args,
-            betas=betas, spec_min=spec_min, spec_max=spec_max
-        )
-
-    def norm_spec(self, x):
-        """[B, T] or [B, F, T] -> [B, T, R] or [B, F, T, R]"""
-        repeats = [1, 1, self.repeat_bins] if self.num_feats == 1 else [1, 1, 1, self.repeat_bins]
-        return super().norm_spec(x.unsqueeze(-1).repeat(repeats))
-
-    def denorm_spec(self, x):
-        """[B, T, R] or [B, F, T, R] -> [B, T] or [B, F, T]"""
-        return super().denorm_spec(x).mean(dim=-1)
-
-    def _finish_denorm(self, x):
-        return x.mean(dim=-1)
+    def _reduce_bins(self, x):
+        return x
 
 
-class PitchDiffusion(RepetitiveDiffusion):
-    def __init__(self, vmin: float, vmax: float,
-                 cmin: float, cmax: float, repeat_bins,
-                 timesteps=1000, k_step=1000,
-                 backbone_type=None, backbone_args=None,
-                 betas=None):
-        self.vmin = vmin  # norm min
-        self.vmax = vmax  # norm max
-        self.cmin = cmin  # clip min
-        self.cmax = cmax  # clip max
-        super().__init__(
-            vmin=vmin, vmax=vmax, repeat_bins=repeat_bins,
-            timesteps=timesteps, k_step=k_step,
-            backbone_type=backbone_type, backbone_args=backbone_args,
-            betas=betas
-        )
-
-    def norm_spec(self, x):
-        return super().norm_spec(x.clamp(min=self.cmin, max=self.cmax))
-
-    def denorm_spec(self, x):
-        return super().denorm_spec(x).clamp(min=self.cmin, max=self.cmax)
-
-    def _finish_denorm(self, x):
-        return super()._finish_denorm(x).clamp(min=self.cmin, max=self.cmax)
+def _expand_fm(mod, v):
+    """per-(f, m) vector of length F*M from a spec_min/max-shaped tensor ([1,1,M] or [1,F,1,1])"""
+    f, m = mod.num_feats, mod.out_dims
+    v = v.reshape(-1)
+    if v.numel() == 1:
+        return v.expand(f * m).contiguous()
+    if f == 1:
+        return v.contiguous()
+    return v.reshape(f, 1).expand(f, m).reshape(-1).contiguous()
 
 
-def _clamp_list(xs, clamps):
-    out = []
-    for x, c in zip(xs, clamps):
-        out.append(x if c is None else x.clamp(min=c[0], max=c[1]))
-    return out
+def _to_bfmt(spec, num_feats):
+    """normalised [B,T,M] / [B,F,T,M] -> the backbone's [B,F,M,T]"""
+    spec = spec.transpose(-2, -1)
+    return spec[:, None, :, :] if num_feats == 1 else spec
 
 
-class MultiVarianceDiffusion(RepetitiveDiffusion):
-    def __init__(
-            self, ranges: List[Tuple[float, float]],
-            clamps: List[Tuple[float | None, float | None] | None],
-            repeat_bins, timesteps=1000, k_step=1000,
-            backbone_type=None, backbone_args=None,
-            betas=None
-    ):
-        assert len(ranges) == len(clamps)
-        self.clamps = clamps
-        vmin = [r[0] for r in ranges]
-        vmax = [r[1] for r in ranges]
-        if len(vmin) == 1:
-            vmin = vmin[0]
-        if len(vmax) == 1:
-            vmax = vmax[0]
-        super().__init__(
-            vmin=vmin, vmax=vmax, repeat_bins=repeat_bins,
-            timesteps=timesteps, k_step=k_step,
-            backbone_type=backbone_type, backbone_args=backbone_args,
-            betas=betas
-        )
+class _ragged:
+    """`with _ragged(backbone, lengths, device)`: per-item lengths for the calls inside (dsd_set_lengths), dense after."""
 
-    def clamp_spec(self, xs: list | tuple):
-        return _clamp_list(xs, self.clamps)
+    def __init__(self, net, lengths, device):
+        self.net, self.lengths, self.device = net, lengths, device
 
-    def norm_spec(self, xs: list | tuple):
-        """sequence of [B, T] -> [B, F, T] -> [B, F, T, R]"""
-        assert len(xs) == self.num_feats
-        xs = torch.stack(self.clamp_spec(xs), dim=1)
-        if self.num_feats == 1:
-            xs = xs.squeeze(1)
-        return super().norm_spec(xs)
+    def __enter__(self):
+        if self.lengths is not None:
+            self.net.set_lengths(self.lengths, self.device)
 
-    def _split(self, xs):
-        xs = [xs] if self.num_feats == 1 else xs.unbind(dim=1)
-        assert len(xs) == self.num_feats
-        return self.clamp_spec(xs)
-
-    def denorm_spec(self, xs):
-        """[B, T, R] or [B, F, T, R] -> sequence of [B, T]"""
-        return self._split(super().denorm_spec(xs))
-
-    def _finish_denorm(self, x):
-        return self._split(x.mean(dim=-1))
+    def __exit__(self, *exc):
+        if self.lengths is not None:
+            self.net.set_lengths(None, self.device)
+        return False
 
 
 # ==============================================================================================
@@ -382,6 +332,8 @@ class RectifiedFlow(nn.Module, _SamplerMixin):
     def p_losses(self, *a, **k):
         raise NotImplementedError("diffsinger_amd is inference-only; train with the reference RectifiedFlow")
 
+    _affine_out = GaussianDiffusion._affine_out
+
     @torch.no_grad()
     def inference(self, cond, b=1, x_end=None, device=None, *, noise=None, _denorm=False):
         if noise is None:
@@ -400,11 +352,7 @@ class RectifiedFlow(nn.Module, _SamplerMixin):
 
         algorithm = hparams['sampling_algorithm']
         infer_step = hparams['sampling_steps']
-        scale = shift = None
-        if _denorm:
-            rng = (self.spec_max - self.spec_min).reshape(-1)
-            scale = GaussianDiffusion._expand_fm(self, rng / 2)
-            shift = GaussianDiffusion._expand_fm(self, rng / 2 + self.spec_min.reshape(-1))
+        scale, shift = self._affine_out() if _denorm else (None, None)
         if t_start < 1:
             entry = self._cached_program(
                 ('reflow', algorithm, infer_step, float(t_start), float(self.time_scale_factor)),
@@ -415,25 +363,47 @@ class RectifiedFlow(nn.Module, _SamplerMixin):
 
     def forward(self, condition, gt_spec=None, src_spec=None, infer=True, *, noise=None, lengths=None):
         """`lengths` [B]: ragged batch - item b is run as if alone at T = lengths[b] (dsd_set_lengths)."""
-        cond = condition.transpose(1, 2)
-        b, device = condition.shape[0], condition.device
         if not infer:
             raise NotImplementedError(
                 "diffsinger_amd.RectifiedFlow is inference-only (infer=True); train with the reference module")
-        if src_spec is not None:
-            spec = self.norm_spec(src_spec).transpose(-2, -1)
-            if self.num_feats == 1:
-                spec = spec[:, None, :, :]
-        else:
-            spec = None
-        if lengths is not None:
-            self.velocity_fn.set_lengths(lengths, device)
-        try:
+        cond = condition.transpose(1, 2)
+        b, device = condition.shape[0], condition.device
+        spec = None if src_spec is None else _to_bfmt(self.norm_spec(src_spec), self.num_feats)
+        with _ragged(self.velocity_fn, lengths, device):
             x = self.inference(cond, b=b, x_end=spec, device=device, noise=noise, _denorm=True)
-        finally:
-            if lengths is not None:
-                self.velocity_fn.set_lengths(None, device)
         return self._finish_denorm(x)
+
+    @torch.no_grad()
+    def forward_onnx(self, condition, x_end=None, depth=None, steps: int = 10, *, noise=None):
+        """`RectifiedFlowONNX.forward(condition, x_end, depth, steps)` (deployment/modules/rectified_flow.py:37-68): euler
+        only, start time max(1 - depth, self.t_start) in fp32, fp32 step times, the twin's (x - b) / k norm and
+        x * k + b denorm.  Repeat-bin subclasses return the mean over the bins (the twin's `denorm_spec`)."""
+        cond = condition.transpose(1, 2)
+        b, device = condition.shape[0], condition.device
+        if noise is None:
+            noise = torch.randn((b, self.num_feats, self.out_dims, cond.shape[2]), device=device)
+        k, mid = (self.spec_max - self.spec_min) / 2., (self.spec_max + self.spec_min) / 2.
+        if x_end is None:
+            t_start, x = torch.zeros((), dtype=torch.float32), noise
+        else:
+            t_start = torch.maximum(1 - torch.as_tensor(depth, dtype=torch.float32).cpu(),
+                                    torch.tensor(self.t_start, dtype=torch.float32))
+            xe = _to_bfmt((x_end - mid) / k, self.num_feats)
+            if t_start <= 0.:
+                x = noise
+            elif t_start >= 1.:
+                x = xe
+            else:
+                ts = float(t_start)         # an fp32 value: the device arithmetic below is the twin's
+                x = ts * xe + (1 - ts) * noise
+        ts = float(t_start)
+        if ts >= 1. or steps < 1:           # dt = 0: the twin still evaluates the backbone `steps` times and adds v * 0
+            entry = self._cached_program(('noop',), lambda: schedule.Program(1, 0, []))
+        else:
+            entry = self._cached_program(('reflow_onnx', steps, ts, float(self.time_scale_factor)),
+                                         lambda: schedule.reflow_onnx_program(steps, t_start, self.time_scale_factor))
+        x = self._run_program(entry, cond, x, scale=_expand_fm(self, k.reshape(-1)), shift=_expand_fm(self, mid.reshape(-1)))
+        return self._reduce_bins(x)
 
     def norm_spec(self, x):
         return (x - self.spec_min) / (self.spec_max - self.spec_min) * 2 - 1
@@ -444,97 +414,129 @@ class RectifiedFlow(nn.Module, _SamplerMixin):
     def _finish_denorm(self, x):
         return x
 
+    def _pre_norm(self, x):
+        return x
 
-class RepetitiveRectifiedFlow(RectifiedFlow):
-    def __init__(self, vmin: float | int | list, vmax: float | int | list,
-                 repeat_bins: int, time_scale_factor=1000,
-                 backbone_type=None, backbone_args=None):
-        assert (isinstance(vmin, (float, int)) and isinstance(vmin, (float, int))) or len(vmin) == len(vmax)
-        num_feats = 1 if isinstance(vmin, (float, int)) else len(vmin)
-        spec_min = [vmin] if num_feats == 1 else [[v] for v in vmin]
-        spec_max = [vmax] if num_feats == 1 else [[v] for v in vmax]
+    def _reduce_bins(self, x):
+        return x
+
+
+# ==============================================================================================
+# Repeat-bin value codecs (ddpm.py:386-505, reflow.py:147-261).  The variance model predicts curves (pitch delta, energy,
+# breathiness, ...), not spectrograms: a value v per frame is encoded as R identical "bins" so that the spectrogram
+# denoiser can be reused, and decoded as the mean over the bins.  The reference writes the three flavours out twice
+# (once per wrapper); here each flavour is ONE mixin that sits in front of either wrapper.  A flavour supplies
+#   _pre_norm(x)      what happens to the caller's value(s) before the bins are made (clamp; list -> stacked tensor)
+#   _post_denorm(v)   what happens to the decoded value(s) (clamp; stacked tensor -> list)
+# ==============================================================================================
+def _scalar(v) -> bool:
+    return isinstance(v, (float, int))
+
+
+class _RepeatBins:
+    def _init_bins(self, vmin, vmax, repeat_bins, **wrapper_args):
+        # (the reference's check tests vmin twice - ddpm.py:391, reflow.py:151 - so a scalar vmin with a list vmax passes
+        # there and fails later; both are checked here)
+        assert (_scalar(vmin) and _scalar(vmax)) or len(vmin) == len(vmax)
+        single = _scalar(vmin)
         self.repeat_bins = repeat_bins
-        super().__init__(
-            out_dims=repeat_bins, num_feats=num_feats,
-            time_scale_factor=time_scale_factor,
-            backbone_type=backbone_type, backbone_args=backbone_args,
-            spec_min=spec_min, spec_max=spec_max
-        )
+        super().__init__(out_dims=repeat_bins, num_feats=1 if single else len(vmin),
+                         spec_min=[vmin] if single else [[v] for v in vmin],
+                         spec_max=[vmax] if single else [[v] for v in vmax], **wrapper_args)
 
     def norm_spec(self, x):
-        repeats = [1, 1, self.repeat_bins] if self.num_feats == 1 else [1, 1, 1, self.repeat_bins]
-        return super().norm_spec(x.unsqueeze(-1).repeat(repeats))
+        """value(s) [B, T] / [B, F, T] (or what `_pre_norm` accepts) -> [B, T, R] / [B, F, T, R]"""
+        v = self._pre_norm(x)
+        return super().norm_spec(v.unsqueeze(-1).expand(*v.shape, self.repeat_bins))
 
     def denorm_spec(self, x):
-        return super().denorm_spec(x).mean(dim=-1)
+        """[B, T, R] / [B, F, T, R] -> value(s)"""
+        return self._post_denorm(super().denorm_spec(x).mean(dim=-1))
 
-    def _finish_denorm(self, x):
+    def _finish_denorm(self, x):        # x arrives denormalised (fused into the sampler's last kernel)
+        return self._post_denorm(x.mean(dim=-1))
+
+    def _reduce_bins(self, x):
         return x.mean(dim=-1)
 
-
-class PitchRectifiedFlow(RepetitiveRectifiedFlow):
-    def __init__(self, vmin: float, vmax: float,
-                 cmin: float, cmax: float, repeat_bins,
-                 time_scale_factor=1000,
-                 backbone_type=None, backbone_args=None):
-        self.vmin = vmin  # norm min
-        self.vmax = vmax  # norm max
-        self.cmin = cmin  # clip min
-        self.cmax = cmax  # clip max
-        super().__init__(
-            vmin=vmin, vmax=vmax, repeat_bins=repeat_bins,
-            time_scale_factor=time_scale_factor,
-            backbone_type=backbone_type, backbone_args=backbone_args
-        )
-
-    def norm_spec(self, x):
-        return super().norm_spec(x.clamp(min=self.cmin, max=self.cmax))
-
-    def denorm_spec(self, x):
-        return super().denorm_spec(x).clamp(min=self.cmin, max=self.cmax)
-
-    def _finish_denorm(self, x):
-        return super()._finish_denorm(x).clamp(min=self.cmin, max=self.cmax)
+    def _post_denorm(self, v):
+        return v
 
 
-class MultiVarianceRectifiedFlow(RepetitiveRectifiedFlow):
-    def __init__(
-            self, ranges: List[Tuple[float, float]],
-            clamps: List[Tuple[float | None, float | None] | None],
-            repeat_bins, time_scale_factor=1000,
-            backbone_type=None, backbone_args=None
-    ):
+class _ClampedPitch(_RepeatBins):
+    """one curve, clipped to [cmin, cmax] on the way in and on the way out"""
+
+    def _init_pitch(self, vmin, vmax, cmin, cmax, repeat_bins, **wrapper_args):
+        self.vmin, self.vmax = vmin, vmax       # range of the normalisation
+        self.cmin, self.cmax = cmin, cmax       # clipping range
+        self._init_bins(vmin, vmax, repeat_bins, **wrapper_args)
+
+    def _pre_norm(self, x):
+        return x.clamp(min=self.cmin, max=self.cmax)
+
+    _post_denorm = _pre_norm
+
+
+class _MultiCurve(_RepeatBins):
+    """F curves handed over (and back) as a sequence of [B, T] tensors, each with its own optional clipping range"""
+
+    def _init_curves(self, ranges, clamps, repeat_bins, **wrapper_args):
         assert len(ranges) == len(clamps)
         self.clamps = clamps
-        vmin = [r[0] for r in ranges]
-        vmax = [r[1] for r in ranges]
-        if len(vmin) == 1:
-            vmin = vmin[0]
-        if len(vmax) == 1:
-            vmax = vmax[0]
-        super().__init__(
-            vmin=vmin, vmax=vmax, repeat_bins=repeat_bins,
-            time_scale_factor=time_scale_factor,
-            backbone_type=backbone_type, backbone_args=backbone_args
-        )
+        lo, hi = [r[0] for r in ranges], [r[1] for r in ranges]
+        self._init_bins(lo[0] if len(lo) == 1 else lo, hi[0] if len(hi) == 1 else hi, repeat_bins, **wrapper_args)
 
     def clamp_spec(self, xs: list | tuple):
-        return _clamp_list(xs, self.clamps)
+        return [x if c is None else x.clamp(min=c[0], max=c[1]) for x, c in zip(xs, self.clamps)]
 
-    def norm_spec(self, xs: list | tuple):
+    def _pre_norm(self, xs: list | tuple):
         assert len(xs) == self.num_feats
-        xs = torch.stack(self.clamp_spec(xs), dim=1)
-        if self.num_feats == 1:
-            xs = xs.squeeze(1)
-        return super().norm_spec(xs)
+        clipped = self.clamp_spec(xs)
+        return clipped[0] if self.num_feats == 1 else torch.stack(clipped, dim=1)
 
-    def _split(self, xs):
-        xs = [xs] if self.num_feats == 1 else xs.unbind(dim=1)
-        assert len(xs) == self.num_feats
-        return self.clamp_spec(xs)
+    def _post_denorm(self, v):
+        curves = [v] if self.num_feats == 1 else list(v.unbind(dim=1))
+        assert len(curves) == self.num_feats
+        return self.clamp_spec(curves)
 
-    def denorm_spec(self, xs):
-        return self._split(super().denorm_spec(xs))
 
-    def _finish_denorm(self, x):
-        return self._split(x.mean(dim=-1))
+class RepetitiveDiffusion(_RepeatBins, GaussianDiffusion):
+    def __init__(self, vmin: float | int | list, vmax: float | int | list, repeat_bins: int, timesteps=1000, k_step=1000,
+                 backbone_type=None, backbone_args=None, betas=None):
+        self._init_bins(vmin, vmax, repeat_bins, timesteps=timesteps, k_step=k_step, backbone_type=backbone_type,
+                        backbone_args=backbone_args, betas=betas)
+
+
+class PitchDiffusion(_ClampedPitch, GaussianDiffusion):
+    def __init__(self, vmin: float, vmax: float, cmin: float, cmax: float, repeat_bins, timesteps=1000, k_step=1000,
+                 backbone_type=None, backbone_args=None, betas=None):
+        self._init_pitch(vmin, vmax, cmin, cmax, repeat_bins, timesteps=timesteps, k_step=k_step,
+                         backbone_type=backbone_type, backbone_args=backbone_args, betas=betas)
+
+
+class MultiVarianceDiffusion(_MultiCurve, GaussianDiffusion):
+    def __init__(self, ranges: List[Tuple[float, float]], clamps: List[Tuple[float | None, float | None] | None],
+                 repeat_bins, timesteps=1000, k_step=1000, backbone_type=None, backbone_args=None, betas=None):
+        self._init_curves(ranges, clamps, repeat_bins, timesteps=timesteps, k_step=k_step, backbone_type=backbone_type,
+                          backbone_args=backbone_args, betas=betas)
+
+
+class RepetitiveRectifiedFlow(_RepeatBins, RectifiedFlow):
+    def __init__(self, vmin: float | int | list, vmax: float | int | list, repeat_bins: int, time_scale_factor=1000,
+                 backbone_type=None, backbone_args=None):
+        self._init_bins(vmin, vmax, repeat_bins, time_scale_factor=time_scale_factor, backbone_type=backbone_type,
+                        backbone_args=backbone_args)
+
+
+class PitchRectifiedFlow(_ClampedPitch, RectifiedFlow):
+    def __init__(self, vmin: float, vmax: float, cmin: float, cmax: float, repeat_bins, time_scale_factor=1000,
+                 backbone_type=None, backbone_args=None):
+        self._init_pitch(vmin, vmax, cmin, cmax, repeat_bins, time_scale_factor=time_scale_factor,
+                         backbone_type=backbone_type, backbone_args=backbone_args)
+
+
+class MultiVarianceRectifiedFlow(_MultiCurve, RectifiedFlow):
+    def __init__(self, ranges: List[Tuple[float, float]], clamps: List[Tuple[float | None, float | None] | None],
+                 repeat_bins, time_scale_factor=1000, backbone_type=None, backbone_args=None):
+        self._init_curves(ranges, clamps, repeat_bins, time_scale_factor=time_scale_factor, backbone_type=backbone_type,
+                          backbone_args=backbone_args)

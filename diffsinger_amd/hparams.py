@@ -13,15 +13,23 @@ def set_hparams(**kw):
 
 
 def use_reference_hparams():
-    """Alias to `utils.hparams.hparams` of an importable DiffSinger checkout."""
+    """Alias to `utils.hparams.hparams` of an importable DiffSinger checkout.
+
+    Every module of this package that did `from .hparams import hparams` holds a reference to the OLD dict object; all of
+    them (whichever are imported already, in any order) are rebound to the reference's dict, and the old dict's entries are
+    carried over, so no reader is left behind on a dict that is never filled."""
     global hparams
+    import sys
     from utils.hparams import hparams as ref  # noqa: WPS433  (reference package, optional)
-    ref.update({k: v for k, v in hparams.items() if k not in ref})
+    old = hparams
+    if ref is old:
+        return ref
+    ref.update({k: v for k, v in old.items() if k not in ref})
     hparams = ref
-    import diffsinger_amd.backbones as _b
-    import diffsinger_amd.diffusion as _d
-    _b.hparams = ref
-    _d.hparams = ref
+    for name, mod in list(sys.modules.items()):
+        if mod is not None and (name == "diffsinger_amd" or name.startswith("diffsinger_amd.")) \
+                and getattr(mod, "hparams", None) is old:
+            mod.hparams = ref
     return ref
 
 

@@ -148,6 +148,15 @@ class DDPMTables:
         self.posterior_mean_coef1 = f(betas * np.sqrt(ac_prev) / (1.0 - ac))
         self.posterior_mean_coef2 = f((1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac))
 
+    @classmethod
+    def from_arrays(cls, arrays) -> "DDPMTables":
+        """The tables as they STAND in a module's registered buffers (a loaded checkpoint may carry another schedule
+        than the current hparams; the reference reads the buffers, ddpm.py:117-167)."""
+        tb = cls.__new__(cls)
+        for name in cls.NAMES:
+            setattr(tb, name, np.ascontiguousarray(np.asarray(arrays[name], dtype=np.float32)))
+        return tb
+
     NAMES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
              "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
              "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
@@ -452,3 +461,39 @@ def reflow_program(algorithm: str, steps: int, t_start: float, time_scale_factor
             e = Eval(TMP, tt(t, 1.0))
             e.emit(X, x + (k1 * 7.0 + k3 * 32.0 + k4 * 12.0 + k5 * 32.0 + m * 7.0) * (dt / 90.0)); evals.append(e)
     return Program(7 if algorithm == "rk5" else (5 if algorithm == "rk4" else 2), X, evals)
+
+
+# --------------------------------------------------------------------------------------------
+# Runtime inputs of the ONNX deployment twins (deployment/modules/diffusion.py:105-131,
+# deployment/modules/rectified_flow.py:37-68): `steps` and `depth` arrive per call instead of through hparams
+# --------------------------------------------------------------------------------------------
+def onnx_ddpm_plan(timesteps: int, k_step: int, factors, steps: int, depth=None) -> Tuple[int, int]:
+    """(t_max, speedup) as GaussianDiffusionONNX.forward derives them.
+
+    depth None (no shallow source): speed-up = timesteps // steps snapped DOWN to a factor of `timesteps`
+    (`timestep_factors`), loop over [0, k_step).  Otherwise depth * timesteps is rounded (fp32, half to even, as
+    torch.round), capped at k_step, the speed-up is depth // steps - NOT snapped - and the depth is rounded down to a
+    multiple of it."""
+    if depth is None:
+        speedup = max(1, timesteps // steps)
+        f = torch.as_tensor(factors)
+        return k_step, int(f[int(torch.sum(f <= speedup)) - 1])
+    d = torch.round(torch.as_tensor(depth, dtype=torch.float32) * timesteps).long()
+    depth_i = min(int(d), k_step)
+    speedup = max(1, depth_i // steps)
+    return depth_i // speedup * speedup, speedup
+
+
+def reflow_onnx_program(steps: int, t_start, time_scale_factor) -> Program:
+    """RectifiedFlowONNX's euler loop: dt = (1 - t_start) / max(1, steps) and the step times i * dt + t_start are fp32
+    tensor arithmetic there (rectified_flow.py:58-62), not the Python-float arithmetic of reflow.py:117-126."""
+    ts = torch.as_tensor(t_start, dtype=torch.float32)
+    dt = (1.0 - ts) / max(1, steps)
+    times = torch.arange(steps, dtype=torch.long).float() * dt + ts
+    x, m = Lin.of(X), Lin.of(MODEL)
+    evals: List[Eval] = []
+    for i in range(steps):
+        e = Eval(X, _f(times[i] * time_scale_factor))
+        e.emit(X, x + m * _f(dt))
+        evals.append(e)
+    return Program(2, X, evals)

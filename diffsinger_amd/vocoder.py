@@ -138,8 +138,16 @@ class Generator(_NativeBackbone):
             sb, sm, st_ = x.stride()
         f0 = f0.detach().to(device=dev, dtype=torch.float32).contiguous()
         dim = self.harmonic_num + 1
+        want_pre = self.noise_sigma is not None and self.noise_sigma > 0      # models.py:272-273
+        # the reference's order of random draws (same generator state in, same state out): SineGen's initial phases
+        # (models.py:145), its additive noise (:165), and only then - after conv_pre - the noise_sigma normals (:272-273)
+        if not self.mini_nsf:
+            if rand_ini is None:
+                rand_ini = torch.rand(dim, device=dev)
+            if noise is None:
+                noise = torch.randn((b, t * self.upp, dim), device=dev)
         pre_ptr = None
-        if self.noise_sigma is not None and self.noise_sigma > 0:           # models.py:272-273
+        if want_pre:
             c0 = self.upsample_initial_channel
             if pre_noise is None:
                 pre_noise = torch.randn((b, c0, t), device=dev)
@@ -147,16 +155,12 @@ class Generator(_NativeBackbone):
             if tuple(pre_noise.shape) != (b, c0, t):
                 raise ValueError(f"pre_noise [{b}, {c0}, {t}] expected")
             pre_ptr = C.c_void_p(pre_noise.data_ptr())
-        if self.mini_nsf:           # deterministic source (models.py:251-260): nothing to draw
+        if self.mini_nsf:           # deterministic source (models.py:251-260): nothing else to draw
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(handle, _lib.lib().dsd_vocode(handle, C.c_void_p(x.data_ptr()), b, t, sb, sm, st_,
                                                      C.c_void_p(f0.data_ptr()), None, None, pre_ptr,
                                                      C.c_void_p(out.data_ptr()), C.c_void_p(stream)), "dsd_vocode")
             return out
-        if rand_ini is None:
-            rand_ini = torch.rand(dim, device=dev)                          # models.py:145
-        if noise is None:
-            noise = torch.randn((b, t * self.upp, dim), device=dev)         # models.py:165
         rand_ini = rand_ini.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
         noise = noise.detach().to(device=dev, dtype=torch.float32).contiguous()
         if rand_ini.numel() != dim or tuple(noise.shape) != (b, t * self.upp, dim):

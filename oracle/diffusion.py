@@ -430,6 +430,53 @@ class GaussianDiffusion:
             x = x[:, 0]
         return np.ascontiguousarray(x, dtype=F32)
 
+    # -- the ONNX deployment twin's runtime inputs (deployment/modules/diffusion.py:93-161) ------
+    def onnx_plan(self, steps, depth=None):
+        """(t_max, speedup) of GaussianDiffusionONNX.forward(condition, x_start, depth, steps):
+        without a shallow source the speed-up is timesteps // steps snapped DOWN to a factor of timesteps and the
+        loop covers [0, k_step) (:112-115); with one, depth * timesteps is rounded, capped at k_step, the speed-up
+        is depth // steps (not snapped) and the depth is rounded down to a multiple of it (:117-120)."""
+        if depth is None:
+            speedup = max(1, self.timesteps // steps)
+            factors = [i for i in range(1, self.timesteps + 1) if self.timesteps % i == 0]
+            speedup = [f for f in factors if f <= speedup][-1]
+            return self.k_step, speedup
+        depth_i = min(int(np.round(F32(depth) * F32(self.timesteps))), self.k_step)     # torch.round: half to even, as numpy
+        speedup = max(1, depth_i // steps)
+        return depth_i // speedup * speedup, speedup
+
+    def forward_onnx(self, condition, noise, x_start=None, depth=None, steps=10, step_noise=None):
+        """GaussianDiffusionONNX.forward (deployment/modules/diffusion.py:105-161): DDIM when the speed-up exceeds 1,
+        ancestral sampling otherwise; norm / denorm in the (x - b) / k form (:93-103).  condition [B,T,H]."""
+        cond = np.ascontiguousarray(np.swapaxes(_f(condition), 1, 2))
+        noise = _f(noise)
+        k = ((self.spec_max - self.spec_min) / F32(2)).astype(F32)
+        b = ((self.spec_max + self.spec_min) / F32(2)).astype(F32)
+        t_max, speedup = self.onnx_plan(steps, None if x_start is None else depth)
+        if x_start is None:
+            x = noise
+        else:
+            xs = np.swapaxes(((_f(x_start) - b) / k).astype(F32), -2, -1)
+            if self.num_feats == 1:
+                xs = xs[:, None]
+            if t_max >= self.timesteps:
+                x = noise
+            elif t_max > 0:
+                x = self.q_sample(xs, t_max - 1, noise)
+            else:
+                x = xs
+        if speedup > 1:
+            for i in reversed(range(0, t_max, speedup)):
+                x = self.p_sample_ddim(x, i, speedup, cond)
+        else:
+            it = iter(step_noise if step_noise is not None else [])
+            for i in reversed(range(0, t_max)):
+                x = self.p_sample(x, i, cond, _f(next(it)))
+        x = np.swapaxes(x, 2, 3)
+        if x.shape[1] == 1:
+            x = x[:, 0]
+        return (np.ascontiguousarray(x, dtype=F32) * k + b).astype(F32)
+
     def forward(self, condition, noise, src_spec=None, **kw):
         """GaussianDiffusion.forward(infer=True) (ddpm.py:353-377). condition [B,T,H]."""
         cond = np.ascontiguousarray(np.swapaxes(_f(condition), 1, 2))
@@ -539,6 +586,38 @@ class RectifiedFlow:
                 spec = spec[:, None]
         x = self.inference(cond, noise, x_end=spec, **kw)
         return self.denorm_spec(x)
+
+    def forward_onnx(self, condition, noise, x_end=None, depth=None, steps=10):
+        """RectifiedFlowONNX.forward (deployment/modules/rectified_flow.py:37-68): euler only; t_start =
+        max(1 - depth, self.t_start) in fp32; the step times i * dt + t_start are fp32 tensor arithmetic."""
+        cond = np.ascontiguousarray(np.swapaxes(_f(condition), 1, 2))
+        noise = _f(noise)
+        k = ((self.spec_max - self.spec_min) / F32(2)).astype(F32)
+        b = ((self.spec_max + self.spec_min) / F32(2)).astype(F32)
+        if x_end is None:
+            t_start = F32(0.0)
+            x = noise
+        else:
+            t_start = max(F32(F32(1) - F32(depth)), F32(self.t_start))
+            xe = np.swapaxes(((_f(x_end) - b) / k).astype(F32), -2, -1)
+            if self.num_feats == 1:
+                xe = xe[:, None]
+            if t_start <= 0.0:
+                x = noise
+            elif t_start >= 1.0:
+                x = xe
+            else:
+                x = (t_start * xe + F32(F32(1) - t_start) * noise).astype(F32)
+        t_width = F32(F32(1) - t_start)
+        if t_width >= 0.0:
+            dt = F32(t_width / F32(max(1, steps)))
+            for i in range(steps):
+                t = _f([F32(F32(i) * dt) + t_start])
+                x = (x + self._v(x, t, cond) * dt).astype(F32)
+        x = np.swapaxes(x, 2, 3)
+        if x.shape[1] == 1:
+            x = x[:, 0]
+        return (np.ascontiguousarray(x, dtype=F32) * k + b).astype(F32)
 
     norm_spec = GaussianDiffusion.norm_spec
     denorm_spec = GaussianDiffusion.denorm_spec

@@ -103,12 +103,14 @@ def save(name, **arrays):
 class InjectRandn:
     """Replace torch.randn by a queue of seed-derived tensors for the duration of a block."""
 
-    def __init__(self, seed0):
+    def __init__(self, seed0, patch_like=False):
         self.seed = seed0
         self.seeds = []
+        self.patch_like = patch_like        # also torch.randn_like (the ONNX twin's p_sample draws with it)
 
     def __enter__(self):
         self._orig = torch.randn
+        self._orig_like = torch.randn_like
 
         def fake(*size, **kw):
             if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
@@ -119,10 +121,13 @@ class InjectRandn:
             return to_t(arr)
 
         torch.randn = fake
+        if self.patch_like:
+            torch.randn_like = lambda t, **kw: fake(tuple(t.shape))
         return self
 
     def __exit__(self, *exc):
         torch.randn = self._orig
+        torch.randn_like = self._orig_like
 
 
 # ----------------------------------------------------------------------------
@@ -993,8 +998,69 @@ def g11_harness():
     save("g11_harness", **out)
 
 
+
+def g16_onnx_twins():
+    """The runtime inputs (`depth`, `steps`) of the ONNX deployment twins, from the reference's own
+    GaussianDiffusionONNX / RectifiedFlowONNX (deployment/modules/diffusion.py:18-161, rectified_flow.py:12-68)
+    with the same seeded weights and injected normals as G5."""
+    from deployment.modules.diffusion import GaussianDiffusionONNX  # noqa: E402  (reference)
+    from deployment.modules.rectified_flow import RectifiedFlowONNX  # noqa: E402  (reference)
+    out = {}
+    sn = SAMPLER_NET
+    t_len, hsz = 50, 256
+
+    def run_gd(tag, steps, depth=None, k_step=1000, shallow=False, noise_seed=6000):
+        set_hp(use_shallow_diffusion=shallow)
+        d = GaussianDiffusionONNX(sn["in_dims"], sn["n_feats"], timesteps=1000, k_step=k_step, backbone_type="wavenet",
+                                  backbone_args=sn["args"], spec_min=[-12.0], spec_max=[0.0])
+        load_synth(d.denoise_fn, "wavenet", sn["in_dims"], sn["n_feats"], sn["args"], sn["wseed"])
+        cond = synth.synth_normal((1, t_len, hsz), noise_seed + 500)
+        src = None
+        if depth is not None:
+            src = (synth.synth_normal((1, t_len, sn["in_dims"]), noise_seed + 501) * 1.5 - 6.0).astype(np.float32)
+        with InjectRandn(noise_seed, patch_like=True) as inj, torch.no_grad():
+            y = d(to_t(cond), x_start=None if src is None else to_t(src),
+                  depth=None if depth is None else torch.tensor(depth, dtype=torch.float32), steps=steps).numpy()
+        out[f"{tag}_out"] = y
+        out[f"{tag}_meta"] = np.array([t_len, noise_seed, len(inj.seeds), k_step, int(shallow), steps], dtype=np.int64)
+        out[f"{tag}_depth"] = np.array(-1.0 if depth is None else depth, dtype=np.float64)
+        print(f"  {tag}: randn calls={len(inj.seeds)} out={y.shape} absmax={np.abs(y).max():.3f}")
+
+    run_gd("gd_steps30", 30)                                        # 1000 // 30 = 33 -> factor 25: 40 DDIM steps
+    run_gd("gd_steps7", 7)                                          # 142 -> factor 125: 8 steps
+    run_gd("gd_depth037_steps11", 11, depth=0.37, k_step=400, shallow=True)     # 370 // 11 = 33 -> depth 363, 11 steps
+    run_gd("gd_depth06_steps50", 50, depth=0.6, k_step=400, shallow=True)       # capped at k_step 400, speed-up 8
+    run_gd("gd_depth1_steps20", 20, depth=1.0)                      # depth == timesteps: starts from noise
+    run_gd("gd_depth0012_steps20", 20, depth=0.012, k_step=400, shallow=True)   # 12 // 20 = 0 -> speed-up 1: ancestral
+
+    def run_rf(tag, steps, depth=None, t_start=0.0, shallow=False, noise_seed=6500):
+        set_hp(use_shallow_diffusion=shallow)
+        r = RectifiedFlowONNX(sn["in_dims"], sn["n_feats"], t_start=t_start, time_scale_factor=1000,
+                              backbone_type="wavenet", backbone_args=sn["args"], spec_min=[-12.0], spec_max=[0.0])
+        load_synth(r.velocity_fn, "wavenet", sn["in_dims"], sn["n_feats"], sn["args"], sn["wseed"])
+        cond = synth.synth_normal((1, t_len, hsz), noise_seed + 500)
+        src = None
+        if depth is not None:
+            src = (synth.synth_normal((1, t_len, sn["in_dims"]), noise_seed + 501) * 1.5 - 6.0).astype(np.float32)
+        with InjectRandn(noise_seed) as inj, torch.no_grad():
+            y = r(to_t(cond), x_end=None if src is None else to_t(src),
+                  depth=None if depth is None else torch.tensor(depth, dtype=torch.float32), steps=steps).numpy()
+        out[f"{tag}_out"] = y
+        out[f"{tag}_meta"] = np.array([t_len, noise_seed, len(inj.seeds), int(shallow), steps], dtype=np.int64)
+        out[f"{tag}_depth"] = np.array(-1.0 if depth is None else depth, dtype=np.float64)
+        out[f"{tag}_tstart"] = np.array(t_start, dtype=np.float64)
+        print(f"  {tag}: randn calls={len(inj.seeds)} out={y.shape} absmax={np.abs(y).max():.3f}")
+
+    run_rf("rf_steps20", 20)
+    run_rf("rf_depth05_steps13", 13, depth=0.5, t_start=0.2, shallow=True)      # starts at max(0.5, 0.2)
+    run_rf("rf_depth09_steps9", 9, depth=0.9, t_start=0.4, shallow=True)        # the model's own T_start wins: 0.4
+    run_rf("rf_depth1_steps10", 10, depth=1.0)                                  # t_start 0: from noise
+    run_rf("rf_depth0_steps5", 5, depth=0.0, t_start=0.3, shallow=True)         # t_start 1: the source itself, dt = 0
+    save("g16_onnx_twins", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g5c1", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g5c1", "g14", "g15", "g16"]
     if "g1" in which:
         g1_posemb()
     if "g23" in which:
@@ -1025,5 +1091,7 @@ if __name__ == "__main__":
         g12_variance_model()
     if "g13" in which:
         g13_variance_harness()
+    if "g16" in which:
+        g16_onnx_twins()
     if "g11" in which:
         g11_harness()

@@ -483,3 +483,133 @@ def test_config1_full_size_wavenet_pndm50_vs_golden():
     err = rel_err(out, g["out"])
     assert err < TOL_SAMPLER, err
     d.denoise_fn.release_native()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G16: the runtime inputs of the ONNX deployment twins (deployment/modules/diffusion.py:105-161, rectified_flow.py:37-68)
+# ---------------------------------------------------------------------------------------------------------------
+from gpu_util import check  # noqa: E402
+
+GD_ONNX = ["gd_steps30", "gd_steps7", "gd_depth037_steps11", "gd_depth06_steps50", "gd_depth1_steps20",
+           "gd_depth0012_steps20"]
+RF_ONNX = ["rf_steps20", "rf_depth05_steps13", "rf_depth09_steps9", "rf_depth1_steps10", "rf_depth0_steps5"]
+
+
+@pytest.mark.parametrize("tag", GD_ONNX)
+def test_g16_gaussian_diffusion_onnx_twin_vs_golden(tag):
+    g = load("g16_onnx_twins")
+    t_len, nseed, n_randn, k_step, shallow, steps = (int(v) for v in g[f"{tag}_meta"])
+    depth = float(g[f"{tag}_depth"])
+    set_hp(use_shallow_diffusion=bool(shallow))
+    d = _gd(k_step)
+    cond = dev(synth.synth_normal((1, t_len, 256), nseed + 500))
+    src = None if depth < 0 else dev((synth.synth_normal((1, t_len, 32), nseed + 501) * 1.5 - 6.0).astype(np.float32))
+    noise = dev(synth.synth_normal((1, 1, 32, t_len), nseed))
+    step_noise = None
+    if n_randn > 1:
+        step_noise = dev(np.stack([synth.synth_normal((1, 1, 32, t_len), nseed + 1 + i) for i in range(n_randn - 1)]))
+    out = d.forward_onnx(cond, x_start=src, depth=None if depth < 0 else torch.tensor(depth), steps=steps, noise=noise,
+                         step_noise=step_noise)
+    check(out, g[f"{tag}_out"], 1e-4, what=tag)
+    # any `steps` is legal here; the hparams-driven path asserts divisibility instead (ddpm.py:225)
+    d.denoise_fn.release_native()
+
+
+@pytest.mark.parametrize("tag", RF_ONNX)
+def test_g16_rectified_flow_onnx_twin_vs_golden(tag):
+    from diffsinger_amd.diffusion import RectifiedFlow
+    g = load("g16_onnx_twins")
+    t_len, nseed, _, shallow, steps = (int(v) for v in g[f"{tag}_meta"])
+    depth, t_start = float(g[f"{tag}_depth"]), float(g[f"{tag}_tstart"])
+    set_hp(use_shallow_diffusion=bool(shallow))
+    r = RectifiedFlow(SN["in_dims"], 1, t_start=t_start, time_scale_factor=1000, backbone_type="wavenet",
+                      backbone_args=SN["args"], spec_min=[-12.0], spec_max=[0.0])
+    load_synth(r.velocity_fn, synth_params("wavenet", SN["in_dims"], 1, SN["args"], SN["wseed"]))
+    r = r.cuda().eval()
+    cond = dev(synth.synth_normal((1, t_len, 256), nseed + 500))
+    src = None if depth < 0 else dev((synth.synth_normal((1, t_len, 32), nseed + 501) * 1.5 - 6.0).astype(np.float32))
+    noise = dev(synth.synth_normal((1, 1, 32, t_len), nseed))
+    out = r.forward_onnx(cond, x_end=src, depth=None if depth < 0 else torch.tensor(depth), steps=steps, noise=noise)
+    check(out, g[f"{tag}_out"], 5e-5, what=tag)
+    r.velocity_fn.release_native()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full-length runs of the remaining BASELINE configs
+# ---------------------------------------------------------------------------------------------------------------
+def test_config3_lynxnet_properties_full_size():
+    """BASELINE config 3 at full size (LYNXNet 6x1024, k = 31, strong_cond, PReLU; DDIM 1000 -> 100 NFE; B = 8, T = 1000)
+    through size-independent properties: determinism, batch independence, and time-locality outside the +-90-frame
+    receptive field of one evaluation (6 layers x 15 frames of the depthwise k = 31)."""
+    largs = dict(num_layers=6, num_channels=1024, expansion_factor=2, kernel_size=31, activation="PReLU", strong_cond=True)
+    set_hp(diff_accelerator="ddim", diff_speedup=10, K_step_infer=1000)
+    d = _gd(1000, kind="lynxnet", in_dims=128, args=largs, wseed=77)
+    bsz, t_len = 8, 1000
+    cond = dev(synth.synth_normal((bsz, t_len, 256), 72))
+    noise = dev(synth.synth_normal((bsz, 1, 128, t_len), 73))
+    out = d(cond, infer=True, noise=noise)
+    assert tuple(out.shape) == (bsz, t_len, 128) and torch.isfinite(out).all()
+    assert torch.equal(out, d(cond, infer=True, noise=noise))                      # deterministic (graph replay included)
+    one = d(cond[5:6].contiguous(), infer=True, noise=noise[5:6].contiguous())      # B = 1: other tile widths, same utterance
+    check(one, out[5:6].cpu().numpy(), 2e-5, what="item 5 alone vs in the batch of 8")
+    net = d.denoise_fn
+    x = dev(synth.synth_normal((1, 1, 128, t_len), 74))
+    c1 = cond[:1].transpose(1, 2).contiguous()
+    t = dev(np.array([412.0], np.float32))
+    with torch.no_grad():
+        y1 = net(x, t, c1)
+        x2 = x.clone()
+        x2[..., 600:] += 1.0
+        y2 = net(x2, t, c1)
+    assert torch.equal(y1[..., :600 - 90], y2[..., :600 - 90])
+    assert not torch.equal(y1[..., 600:], y2[..., 600:])
+    net.release_native()
+
+
+def test_config4_per_gpu_share_all_50_steps_vs_oracle():
+    """BASELINE config 4's per-GPU share at FULL length: 8 utterances x 1000 frames, 20x256 WaveNet, DPM-Solver++ 1000 -> 50
+    (50 NFE) - the fused residual-layer kernel (wn_layer.hip) - against the numpy oracle (about half a minute of host time),
+    and one of the utterances alone (the two-GEMM kernels of gemm.hip) against the same."""
+    set_hp(diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    d = _gd(1000, in_dims=128, args=args, wseed=42)
+    bsz, t_len = 8, 1000
+    cond = synth.synth_normal((bsz, t_len, 256), 40)
+    noise = synth.synth_normal((bsz, 1, 128, t_len), 41)
+    out = d(dev(cond), infer=True, noise=dev(noise))
+    stats = d.denoise_fn.stats()
+    assert stats["kernels_per_nfe"] == 20 + 3, stats               # one launch per layer: the fused path really ran
+    params = synth_params("wavenet", 128, 1, args, 42)
+    fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=4)   # noqa: E731
+    o = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
+    want = o.forward(cond, noise, diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
+    check(out, want, 5e-5, what="8 x 1000 frames, 50 NFE, fused layers")
+    one = d(dev(cond[3:4]), infer=True, noise=dev(noise[3:4]))
+    assert d.denoise_fn.stats()["kernels_per_nfe"] == 2 * 20 + 3
+    check(one, want[3:4], 5e-5, what="utterance 3 alone, two GEMMs per layer")
+    d.denoise_fn.release_native()
+
+
+def test_schedule_follows_loaded_buffers():
+    """A checkpoint's schedule buffers win over the constructor's (ddpm.py reads the registered buffers): load a state
+    dict with another beta schedule, then DDIM must follow the LOADED tables - against the oracle built from them."""
+    from diffsinger_amd import schedule
+    set_hp(diff_accelerator="ddim", diff_speedup=50, K_step_infer=1000)
+    d = _gd(1000)
+    betas = schedule.cosine_beta_schedule(1000)
+    other = schedule.DDPMTables(betas)
+    sd = d.state_dict()
+    for name in schedule.DDPMTables.NAMES:
+        sd[name] = torch.from_numpy(getattr(other, name).copy())
+    cond = synth.synth_normal((1, 40, 256), 11)
+    noise = synth.synth_normal((1, 1, 32, 40), 12)
+    before = d(dev(cond), infer=True, noise=dev(noise))            # caches a program for the linear schedule
+    d.load_state_dict(sd, strict=True)
+    after = d(dev(cond), infer=True, noise=dev(noise))
+    params = synth_params("wavenet", SN["in_dims"], 1, SN["args"], SN["wseed"])
+    fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=SN["args"]["dilation_cycle_length"])   # noqa: E731
+    o = od.GaussianDiffusion(fn, 32, 1, spec_min=[-12.0], spec_max=[0.0], betas=betas)
+    want = o.forward(cond, noise, diff_accelerator="ddim", diff_speedup=50, K_step_infer=1000)
+    check(after, want, 1e-4, what="DDIM on the loaded cosine schedule")
+    assert not torch.allclose(before, after)
+    d.denoise_fn.release_native()

@@ -270,3 +270,26 @@ def test_example_script_runs_a_saved_experiment(tmp_path):
     assert "model_ckpt_steps_100.ckpt" in r.stdout          # the latest step, not the zeroed older one
     sr, data = wavfile.read(out)
     assert sr == 44100 and data.shape[0] > 44100 and np.abs(data.astype(np.float64)).max() > 0
+
+
+def test_vocoder_random_draws_in_reference_order():
+    """With noise_sigma > 0 the reference draws SineGen's initial phases (models.py:145), its additive noise (:165) and
+    only then - after conv_pre - the noise_sigma normals (:272-273).  A seeded run with no injected tensor must consume
+    the device generator in exactly that order and leave it where the reference leaves it."""
+    gen, h, _ = build(OVER["small_sigma"], 430)
+    bsz, t_len = 2, 40
+    upp = int(np.prod(h["upsample_rates"]))
+    mel = dev((synth.synth_normal((bsz, h["num_mels"], t_len), 431) * 3.0 - 11.0).astype(np.float32))
+    f0 = dev(np.full((bsz, t_len), 220.0, np.float32))
+    with torch.no_grad():
+        torch.manual_seed(1234)
+        seeded = gen(mel, f0)
+        state_after = torch.cuda.get_rng_state()
+        torch.manual_seed(1234)
+        rand_ini = torch.rand(9, device="cuda")
+        noise = torch.randn((bsz, t_len * upp, 9), device="cuda")
+        pre = torch.randn((bsz, h["upsample_initial_channel"], t_len), device="cuda")
+        assert torch.equal(torch.cuda.get_rng_state(), state_after)
+        injected = gen(mel, f0, rand_ini=rand_ini, noise=noise, pre_noise=pre)
+    assert torch.equal(seeded, injected)
+    gen.release_native()

@@ -534,3 +534,52 @@ def test_g5_config1_full_size_wavenet_pndm50():
     out = d.forward(synth.synth_normal((bsz, t_len, 256), cseed), synth.synth_normal((bsz, 1, 128, t_len), nseed),
                     diff_accelerator="pndm", diff_speedup=20, K_step_infer=1000)
     assert rel_err(out, g["out"]) < 2e-4
+
+
+# --------------------------------------------------------------------------- G16: the ONNX twins' runtime inputs
+GD_ONNX = ["gd_steps30", "gd_steps7", "gd_depth037_steps11", "gd_depth06_steps50", "gd_depth1_steps20",
+           "gd_depth0012_steps20"]
+RF_ONNX = ["rf_steps20", "rf_depth05_steps13", "rf_depth09_steps9", "rf_depth1_steps10", "rf_depth0_steps5"]
+
+
+@pytest.mark.parametrize("tag", GD_ONNX)
+def test_g16_gaussian_diffusion_onnx_twin(tag):
+    """GaussianDiffusionONNX.forward(condition, x_start, depth, steps) - factor-snapped speed-up, depth rounded down to
+    a multiple (deployment/modules/diffusion.py:105-161): oracle against the reference class's own output."""
+    g = load("g16_onnx_twins")
+    t_len, nseed, n_randn, k_step, shallow, steps = (int(v) for v in g[f"{tag}_meta"])
+    depth = float(g[f"{tag}_depth"])
+    d = od.GaussianDiffusion(_sampler_net(), 32, 1, timesteps=1000, k_step=k_step, spec_min=[-12.0], spec_max=[0.0],
+                             use_shallow_diffusion=bool(shallow))
+    cond = synth.synth_normal((1, t_len, 256), nseed + 500)
+    src = None if depth < 0 else (synth.synth_normal((1, t_len, 32), nseed + 501) * 1.5 - 6.0).astype(np.float32)
+    noise = synth.synth_normal((1, 1, 32, t_len), nseed)
+    step_noise = [synth.synth_normal((1, 1, 32, t_len), nseed + 1 + i) for i in range(n_randn - 1)]
+    out = d.forward_onnx(cond, noise, x_start=src, depth=None if depth < 0 else depth, steps=steps, step_noise=step_noise)
+    assert out.shape == g[f"{tag}_out"].shape
+    assert rel_err(out, g[f"{tag}_out"]) < 1e-4, tag
+
+
+def test_g16_onnx_plan_known_answers():
+    d = od.GaussianDiffusion(None, 32, 1, timesteps=1000, k_step=400, spec_min=[-12.0], spec_max=[0.0],
+                             use_shallow_diffusion=True)
+    assert d.onnx_plan(30) == (400, 25) and d.onnx_plan(7) == (400, 125) and d.onnx_plan(5000) == (400, 1)
+    assert d.onnx_plan(11, 0.37) == (363, 33) and d.onnx_plan(50, 0.6) == (400, 8) and d.onnx_plan(20, 0.012) == (12, 1)
+    from diffsinger_amd import schedule
+    factors = [i for i in range(1, 1001) if 1000 % i == 0]
+    for steps, depth in [(30, None), (7, None), (5000, None), (11, 0.37), (50, 0.6), (20, 0.012), (20, 1.0), (3, 0.0005)]:
+        assert schedule.onnx_ddpm_plan(1000, 400, factors, steps, depth) == d.onnx_plan(steps, depth)
+
+
+@pytest.mark.parametrize("tag", RF_ONNX)
+def test_g16_rectified_flow_onnx_twin(tag):
+    g = load("g16_onnx_twins")
+    t_len, nseed, _, shallow, steps = (int(v) for v in g[f"{tag}_meta"])
+    depth, t_start = float(g[f"{tag}_depth"]), float(g[f"{tag}_tstart"])
+    r = od.RectifiedFlow(_sampler_net(), 32, 1, t_start=t_start, time_scale_factor=1000, spec_min=[-12.0],
+                         spec_max=[0.0], use_shallow_diffusion=bool(shallow))
+    cond = synth.synth_normal((1, t_len, 256), nseed + 500)
+    src = None if depth < 0 else (synth.synth_normal((1, t_len, 32), nseed + 501) * 1.5 - 6.0).astype(np.float32)
+    noise = synth.synth_normal((1, 1, 32, t_len), nseed)
+    out = r.forward_onnx(cond, noise, x_end=src, depth=None if depth < 0 else depth, steps=steps)
+    assert rel_err(out, g[f"{tag}_out"]) < 5e-5, tag
