@@ -18,7 +18,7 @@ from oracle import aux_decoder as oa  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL_AUX = 2e-5
-TOL_SAMPLER = 5e-4
+TOL_SAMPLER = 1.5e-5      # measured <= 1.3e-6 (profiles/r02_parity.json)
 
 
 def load(name):

@@ -156,5 +156,5 @@ def test_diffsinger_acoustic_tokens_to_mel_vs_golden(tag):
     with torch.no_grad():
         out = model(dev(g["tokens"]), dev(g["mel2ph"]), dev(g["f0"]), infer=True, noise=noise)
     assert rel_err(out.aux_out, g[f"{tag}_aux"]) < 2e-5
-    assert rel_err(out.diff_out, g[f"{tag}_mel"]) < 5e-4
+    assert rel_err(out.diff_out, g[f"{tag}_mel"]) < 1.5e-5       # measured 1.1e-6 (profiles/r02_parity.json)
     set_hp()

@@ -1,10 +1,13 @@
 """Parity of the HIP path (through the C-ABI) against the numpy oracle and the committed golden
 fixtures generated from the reference.  Run on the MI355X box: `pytest tests -m gpu`.
 
-Stated fp32 tolerances (max abs error / max abs reference value):
-  * one backbone evaluation            <= 2e-5   (oracle-vs-reference itself is <= 6e-6)
-  * full sampler runs (<= 120 NFE)     <= 5e-4   (oracle-vs-reference is <= 2e-6; random weights make the
-                                                  denoiser expansive, so rounding differences grow per step)
+Stated fp32 tolerances, held by BOTH max |a - b| / max |ref| and rms(a - b) / rms(ref) (gpu_util.check; the second cannot
+be flattered by the ~260 peaks of the random-weight sampler fixtures on a [-12, 0] mel range):
+  * one backbone evaluation            <= 2e-5    (measured worst case 6.1e-6: T = 4128; typical 1-3e-6)
+  * full sampler runs (<= 120 NFE)     <= 1.5e-5  (measured worst case 1.8e-6: 50-NFE DPM-Solver++ at B = 8; the headline
+                                                   50-NFE run 1.7e-6) - i.e. at most ~10x what profiles/r02_parity.json
+                                                   records, so a drift of one order of magnitude fails
+Every comparison is appended to gpurun_out/parity.jsonl; tools/summarize_parity.py writes profiles/<round>_parity.json.
 """
 import os
 
@@ -15,13 +18,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from diffsinger_amd import synth  # noqa: E402
-from gpu_util import dev, load_synth, make_backbone, rel_err, set_hp, synth_params  # noqa: E402
+from gpu_util import check, dev, load_synth, make_backbone, rel_err, set_hp, synth_params  # noqa: E402
 from oracle import backbones as ob  # noqa: E402
 from oracle import diffusion as od  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL_NFE = 2e-5
-TOL_SAMPLER = 5e-4
+TOL_SAMPLER = 1.5e-5
 
 
 def load(name):
@@ -68,8 +71,7 @@ def _golden_backbone_cases(kind, name, table, prefix):
             out = net(dev(x), dev(t), dev(cond))
         torch.cuda.synchronize()
         assert tuple(out.shape) == g[f"c{ci}_out"].shape
-        err = rel_err(out, g[f"c{ci}_out"])
-        assert err < TOL_NFE, (name, ci, err)
+        check(out, g[f"c{ci}_out"], TOL_NFE, what=(name, ci, err))
         ci += 1
     assert ci > 0
     net.release_native()
@@ -98,7 +100,7 @@ def test_wavenet_vs_oracle_ragged_sizes(bsz, t_len):
     with torch.no_grad():
         out = net(dev(x), dev(t), dev(cond))
         out2 = net(dev(x), dev(t), dev(cond))              # second call: cached cond, same result
-    assert rel_err(out, want) < TOL_NFE
+    check(out, want, TOL_NFE)
     assert torch.equal(out, out2)
     net.release_native()
 
@@ -116,7 +118,7 @@ def test_wavenet_intermediate_state_does_not_leak_between_calls():
         with torch.no_grad():
             outs.append(net(dev(x), dev(t), dev(cond)).cpu().numpy())
         want = ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=2)
-        assert rel_err(outs[-1], want) < TOL_NFE
+        check(outs[-1], want, TOL_NFE)
     np.testing.assert_array_equal(outs[0], outs[2])
     net.release_native()
 
@@ -133,7 +135,7 @@ def test_lynxnet_vs_oracle_ragged():
         want = ob.lynxnet_forward(params, x, t, cond, activation="PReLU", strong_cond=True)
         with torch.no_grad():
             out = net(dev(x), dev(t), dev(cond))
-        assert rel_err(out, want) < TOL_NFE
+        check(out, want, TOL_NFE)
     net.release_native()
 
 
@@ -187,8 +189,7 @@ def test_gaussian_diffusion_samplers_vs_golden(tag, use_graph):
         step_noise = dev(np.stack([synth.synth_normal((bsz, 1, 32, t_len), nseed + 1 + i) for i in range(n_randn - 1)]))
     out = d(cond, src_spec=src, infer=True, noise=noise, step_noise=step_noise)
     out_again = d(cond, src_spec=src, infer=True, noise=noise, step_noise=step_noise)   # graph replay / cache
-    err = rel_err(out, g[f"{tag}_out"])
-    assert err < TOL_SAMPLER, (tag, err)
+    check(out, g[f"{tag}_out"], TOL_SAMPLER, what=tag)
     assert torch.equal(out, out_again)
     d.denoise_fn.release_native()
 
@@ -213,8 +214,7 @@ def test_rectified_flow_samplers_vs_golden(tag):
     if shallow:
         src = dev((synth.synth_normal((bsz, t_len, 32), nseed + 501) * 1.5 - 6.0).astype(np.float32))
     out = r(cond, src_spec=src, infer=True, noise=dev(synth.synth_normal((bsz, 1, 32, t_len), nseed)))
-    err = rel_err(out, g[f"{tag}_out"])
-    assert err < TOL_SAMPLER, (tag, err)
+    check(out, g[f"{tag}_out"], TOL_SAMPLER, what=tag)
     r.velocity_fn.release_native()
 
 
@@ -225,8 +225,7 @@ def test_full_size_wavenet_dpm20_vs_golden():
     d = _gd(1000, in_dims=128, args=dict(num_layers=20, num_channels=256, dilation_cycle_length=4), wseed=42)
     out = d(dev(synth.synth_normal((bsz, t_len, 256), cseed)), infer=True,
             noise=dev(synth.synth_normal((bsz, 1, 128, t_len), nseed)))
-    err = rel_err(out, g["out"])
-    assert err < TOL_SAMPLER, err
+    check(out, g["out"], TOL_SAMPLER)
     d.denoise_fn.release_native()
 
 
@@ -240,14 +239,14 @@ def test_lynxnet_samplers_vs_golden():
     set_hp(diff_accelerator="ddim", diff_speedup=50, K_step_infer=1000)
     d = _gd(1000, kind="lynxnet", in_dims=128, args=largs, wseed=wseed)
     out = d(cond, infer=True, noise=dev(synth.synth_normal((bsz, 1, 128, t_len), s_ddim)))
-    assert rel_err(out, g["ddim20_out"]) < TOL_SAMPLER
+    check(out, g["ddim20_out"], TOL_SAMPLER)
     d.denoise_fn.release_native()
     set_hp(sampling_algorithm="euler", sampling_steps=10)
     r = RectifiedFlow(128, 1, backbone_type="lynxnet", backbone_args=largs, spec_min=[-12.0], spec_max=[0.0])
     load_synth(r.velocity_fn, synth_params("lynxnet", 128, 1, largs, wseed))
     r = r.cuda().eval()
     out2 = r(cond, infer=True, noise=dev(synth.synth_normal((bsz, 1, 128, t_len), s_rf)))
-    assert rel_err(out2, g["rf_euler10_out"]) < TOL_SAMPLER
+    check(out2, g["rf_euler10_out"], TOL_SAMPLER)
     r.velocity_fn.release_native()
 
 
@@ -292,8 +291,7 @@ def test_headline_config_full_size_vs_oracle():
     fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=4)
     o = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
     want = o.forward(cond, noise, diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
-    err = rel_err(out, want)
-    assert err < TOL_SAMPLER, err
+    check(out, want, TOL_SAMPLER)
     d.denoise_fn.release_native()
 
 
@@ -310,7 +308,7 @@ def test_long_utterance_single_nfe_vs_oracle():
     want = ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=4)
     with torch.no_grad():
         out = net(dev(x), dev(t), dev(cond))
-    assert rel_err(out, want) < TOL_NFE
+    check(out, want, TOL_NFE)
     net.release_native()
 
 
@@ -403,8 +401,7 @@ def test_config3_lynxnet_full_width_ddim_vs_oracle():
     fn = lambda x, t, c: ob.lynxnet_forward(params, x, t, c, activation="PReLU", strong_cond=True)   # noqa: E731
     o = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
     want = o.forward(cond, noise, diff_accelerator="ddim", diff_speedup=100, K_step_infer=1000)
-    err = rel_err(out, want)
-    assert err < TOL_SAMPLER, err
+    check(out, want, TOL_SAMPLER)
     d.denoise_fn.release_native()
 
 
@@ -422,8 +419,7 @@ def test_config4_per_gpu_batch_vs_oracle():
     fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=4)   # noqa: E731
     o = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
     want = o.forward(cond, noise, diff_accelerator="dpm-solver", diff_speedup=100, K_step_infer=1000)
-    err = rel_err(out, want)
-    assert err < TOL_SAMPLER, err
+    check(out, want, TOL_SAMPLER)
     d.denoise_fn.release_native()
 
 
@@ -480,15 +476,13 @@ def test_config1_full_size_wavenet_pndm50_vs_golden():
     d = _gd(1000, in_dims=128, args=dict(num_layers=20, num_channels=256, dilation_cycle_length=4), wseed=42)
     out = d(dev(synth.synth_normal((bsz, t_len, 256), cseed)), infer=True,
             noise=dev(synth.synth_normal((bsz, 1, 128, t_len), nseed)))
-    err = rel_err(out, g["out"])
-    assert err < TOL_SAMPLER, err
+    check(out, g["out"], TOL_SAMPLER)
     d.denoise_fn.release_native()
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # G16: the runtime inputs of the ONNX deployment twins (deployment/modules/diffusion.py:105-161, rectified_flow.py:37-68)
 # ---------------------------------------------------------------------------------------------------------------
-from gpu_util import check  # noqa: E402
 
 GD_ONNX = ["gd_steps30", "gd_steps7", "gd_depth037_steps11", "gd_depth06_steps50", "gd_depth1_steps20",
            "gd_depth0012_steps20"]
@@ -510,7 +504,7 @@ def test_g16_gaussian_diffusion_onnx_twin_vs_golden(tag):
         step_noise = dev(np.stack([synth.synth_normal((1, 1, 32, t_len), nseed + 1 + i) for i in range(n_randn - 1)]))
     out = d.forward_onnx(cond, x_start=src, depth=None if depth < 0 else torch.tensor(depth), steps=steps, noise=noise,
                          step_noise=step_noise)
-    check(out, g[f"{tag}_out"], 1e-4, what=tag)
+    check(out, g[f"{tag}_out"], 5e-6, what=tag)
     # any `steps` is legal here; the hparams-driven path asserts divisibility instead (ddpm.py:225)
     d.denoise_fn.release_native()
 
@@ -530,7 +524,7 @@ def test_g16_rectified_flow_onnx_twin_vs_golden(tag):
     src = None if depth < 0 else dev((synth.synth_normal((1, t_len, 32), nseed + 501) * 1.5 - 6.0).astype(np.float32))
     noise = dev(synth.synth_normal((1, 1, 32, t_len), nseed))
     out = r.forward_onnx(cond, x_end=src, depth=None if depth < 0 else torch.tensor(depth), steps=steps, noise=noise)
-    check(out, g[f"{tag}_out"], 5e-5, what=tag)
+    check(out, g[f"{tag}_out"], 2e-6, what=tag)
     r.velocity_fn.release_native()
 
 
@@ -551,7 +545,7 @@ def test_config3_lynxnet_properties_full_size():
     assert tuple(out.shape) == (bsz, t_len, 128) and torch.isfinite(out).all()
     assert torch.equal(out, d(cond, infer=True, noise=noise))                      # deterministic (graph replay included)
     one = d(cond[5:6].contiguous(), infer=True, noise=noise[5:6].contiguous())      # B = 1: other tile widths, same utterance
-    check(one, out[5:6].cpu().numpy(), 2e-5, what="item 5 alone vs in the batch of 8")
+    check(one, out[5:6].cpu().numpy(), 5e-6, what="item 5 alone vs in the batch of 8")
     net = d.denoise_fn
     x = dev(synth.synth_normal((1, 1, 128, t_len), 74))
     c1 = cond[:1].transpose(1, 2).contiguous()
@@ -583,10 +577,10 @@ def test_config4_per_gpu_share_all_50_steps_vs_oracle():
     fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=4)   # noqa: E731
     o = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
     want = o.forward(cond, noise, diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
-    check(out, want, 5e-5, what="8 x 1000 frames, 50 NFE, fused layers")
+    check(out, want, TOL_SAMPLER, what="8 x 1000 frames, 50 NFE, fused layers")
     one = d(dev(cond[3:4]), infer=True, noise=dev(noise[3:4]))
     assert d.denoise_fn.stats()["kernels_per_nfe"] == 2 * 20 + 3
-    check(one, want[3:4], 5e-5, what="utterance 3 alone, two GEMMs per layer")
+    check(one, want[3:4], TOL_SAMPLER, what="utterance 3 alone, two GEMMs per layer")
     d.denoise_fn.release_native()
 
 
@@ -610,6 +604,6 @@ def test_schedule_follows_loaded_buffers():
     fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=SN["args"]["dilation_cycle_length"])   # noqa: E731
     o = od.GaussianDiffusion(fn, 32, 1, spec_min=[-12.0], spec_max=[0.0], betas=betas)
     want = o.forward(cond, noise, diff_accelerator="ddim", diff_speedup=50, K_step_infer=1000)
-    check(after, want, 1e-4, what="DDIM on the loaded cosine schedule")
+    check(after, want, TOL_SAMPLER, what="DDIM on the loaded cosine schedule")
     assert not torch.allclose(before, after)
     d.denoise_fn.release_native()

@@ -15,7 +15,7 @@ from gpu_util import dev, rel_err  # noqa: E402
 from oracle import vocoder as ov  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TOL = 1e-4
+TOL = 5e-5        # measured <= 5.7e-6 (profiles/r02_parity.json)
 GAIN = 0.7
 OVER = {
     "default": dict(),
