@@ -1099,6 +1099,16 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     p.inv_w4 = 1.0f / (float)w4;
     p.lpr_shift = 3;
     while ((1 << p.lpr_shift) < w4) ++p.lpr_shift;
+    {   // L2 blocking of the work order for GEMMs with many row tiles (GemmP::gm_shift): groups of 8 row tiles
+        static const int gm_env = getenv("DSD_GM_SHIFT") ? atoi(getenv("DSD_GM_SHIFT")) : -1;       // diagnostic override
+        const int shift = gm_env >= 0 ? gm_env : 3;
+        const long nft = ragged ? (long)p.ncg : (long)batch * p.tiles_per_b;
+        if (shift > 0 && mtiles >= (2 << shift) && mtiles % (1 << shift) == 0 && nft * mtiles >= 2048 && (nft << shift) < (1L << 22)) {
+            p.gm_shift = shift;
+            p.per_group = (int)(nft << shift);
+            p.inv_per_group = 1.0f / (float)p.per_group;
+        }
+    }
     // a k=3 conv keeps all its input channels resident on the generic path (its walk does not mix taps and chunks)
     if (g.taps > 1) p.KC = g.K;
     c.fast = !generic_only && (g.taps == 1 || g.taps == 3) && (g.K % gemm_fast_chunk_rows(g.taps, c.nb) == 0) &&

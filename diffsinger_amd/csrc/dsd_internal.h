@@ -57,6 +57,13 @@ struct GemmP {
     int mtiles;             // 64-row tiles (EP_GATE / EP_SWIGLU: 32 pairs each)
     int lds_bytes;          // dynamic LDS of this launch
     float inv_mtiles, inv_tiles_per_b, inv_w4;   // reciprocals for the prologue's index arithmetic
+    // L2 blocking of the work order (many row tiles: LYNXNet's 1x1 GEMMs): row tiles are taken in groups of 2^gm_shift, a
+    // group walks ALL frame tiles before the next group starts - so the ~100 workgroups an XCD runs at a time share one
+    // group's weights (which stay in its 4 MiB L2) and each activation tile is fetched once per group.  0: row tile fastest
+    // over all row tiles (every frame tile re-streams the whole weight matrix through L2).
+    int gm_shift;
+    int per_group;          // frame tiles of the launch << gm_shift
+    float inv_per_group;
     int lpr_shift;          // staging: 2^lpr_shift lanes per staged row (>= float4 per row)
     int dil;                // dilation (taps > 1)
     int taps;               // kernel size along time (1, 3, or any odd k on the generic path)

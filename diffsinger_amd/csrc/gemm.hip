@@ -149,8 +149,16 @@ __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_ke
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int rest0 = fdiv_floor(work, p.inv_mtiles);
-    const int mtile = work - rest0 * p.mtiles;
+    int rest0, mtile;
+    if (p.gm_shift > 0) {           // grouped order: work = (row group * frame tiles + frame tile) << gm_shift | row tile in group
+        const int mg = fdiv_floor(work, p.inv_per_group);
+        const int r = work - mg * p.per_group;
+        rest0 = r >> p.gm_shift;
+        mtile = (mg << p.gm_shift) + (r & ((1 << p.gm_shift) - 1));
+    } else {
+        rest0 = fdiv_floor(work, p.inv_mtiles);
+        mtile = work - rest0 * p.mtiles;
+    }
     const int rest = RAG ? p.cgmap[__builtin_amdgcn_readfirstlane(rest0)] : rest0;     // scalar loads: off the vmcnt ledger
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;

@@ -71,7 +71,7 @@ def _golden_backbone_cases(kind, name, table, prefix):
             out = net(dev(x), dev(t), dev(cond))
         torch.cuda.synchronize()
         assert tuple(out.shape) == g[f"c{ci}_out"].shape
-        check(out, g[f"c{ci}_out"], TOL_NFE, what=(name, ci, err))
+        check(out, g[f"c{ci}_out"], TOL_NFE, what=(name, ci))
         ci += 1
     assert ci > 0
     net.release_native()
