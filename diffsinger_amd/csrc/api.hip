@@ -1272,6 +1272,33 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
         for (int l = 0; l < L; ++l) {
             const int dil = 1 << (l % h->cfg.dilation_cycle_length);
             GemmCall g = make_gemm(h, h->g_conv[l], h->xh, xs, Ts, B, T, ST_FILM, EP_GATE, dil);
+            // 32-frame tiles on a grid of about one workgroup per CU (one utterance of ~1000 frames): the row-split pair
+            // of wn_rowsplit.hip - every weight block loaded once, compiler-counted waits - instead of the two GEMMs
+            static const int rs_env = getenv("DSD_ROWSPLIT") ? atoi(getenv("DSD_ROWSPLIT")) : -1;
+            if (rs_env != 0 && g.nb == 1 && g.fast && wn_rowsplit_supported(C, dil)) {
+                const bool ragged = h->use_cg && !h->lens_host.empty();
+                WnLayerP p;
+                memset(&p, 0, sizeof(p));
+                p.Aconv = h->blob + h->g_conv[l].a_off;
+                p.Aout = h->blob + h->g_outp[l].a_off;
+                p.bias_out = h->blob + h->g_outp[l].bias_off;
+                p.xin = h->xh; p.xout = h->xh; p.skip = h->skip; p.z = h->z;
+                p.x_bstride = xs; p.Ts = Ts;
+                p.cp = h->cp + (long)l * 2 * C * Ts; p.cp_bstride = cps;
+                p.film = h->D + (long)l * C * Ns; p.film_cstride = Ns; p.film_col0 = film_col0; p.film_colb = film_colb;
+                p.dil = dil;
+                p.T = T; p.tiles_per_b = (T + 31) / 32; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
+                p.first_layer = (l == 0);
+                if (ragged) { p.lens = h->lens_dev; p.cgmap = h->cg_dev[1]; p.ncg = h->cg_n[1]; }
+                timed_begin();
+                if (timed_now) wn_rowsplit_set_timing_events(h->ev_pool[h->ev_used].first, h->ev_pool[h->ev_used].second);
+                hipError_t le = launch_wn_rowsplit(p, 0, C, B, st);
+                if (timed_now) wn_rowsplit_set_timing_events(nullptr, nullptr);
+                timed_end();
+                if (le == hipSuccess) le = launch_wn_rowsplit(p, 1, C, B, st);
+                if (le != hipSuccess) return fail(h, DSD_EHIP, "row-split WaveNet layer launch failed: %s", hipGetErrorString(le));
+                continue;
+            }
             g.p.film = h->D + (long)l * C * Ns; g.p.film_cstride = Ns; g.p.film_col0 = film_col0; g.p.film_colb = film_colb;
             g.p.aux = h->cp + (long)l * 2 * C * Ts; g.p.aux_bstride = cps; g.p.aux_rstride = Ts;
             g.p.out = h->z; g.p.o_bstride = xs; g.p.o_rstride = Ts;
@@ -1387,6 +1414,7 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: hipSetDevice failed");
     hipError_t ie = gemm_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_layer_init_all();
+    if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_rowsplit_init_all();
     if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
     dsd_handle* h = new dsd_handle();
     h->cfg = *cfg;

@@ -128,7 +128,8 @@ struct WnLayerP {
     const float* xin;       // residual stream, internal layout [B][C][Ts]: read (tile + halo)
     float* xout;            // residual stream after the layer (a different buffer: neighbours read xin's halo)
     float* skip;            // running skip sum, updated in place
-    long x_bstride;         // floats between batch items of x / skip
+    float* z;               // row-split pair only (wn_rowsplit.hip): the gated conv output between the two launches
+    long x_bstride;         // floats between batch items of x / skip / z
     int Ts;
     const float* cp;        // this layer's hoisted conditioner projection rows [2C][Ts] (+ conv bias + its own bias)
     long cp_bstride;
@@ -144,6 +145,13 @@ hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st);
 bool wn_layer_supported(int C, int dil);
 hipError_t wn_layer_init_all();
 void wn_layer_set_timing_events(hipEvent_t start, hipEvent_t stop);
+// wn_rowsplit.hip: the same layer as two launches with the 2C rows split over 2C / 64 workgroups per 32-frame tile, for
+// grids too small for full-row tiles.  which = 0: conv + FiLM + gate (xin -> z); 1: out-proj + residual / skip (in place
+// when xout == xin)
+hipError_t launch_wn_rowsplit(const WnLayerP& p, int which, int C, int batch, hipStream_t st);
+hipError_t wn_rowsplit_init_all();
+bool wn_rowsplit_supported(int C, int dil);
+void wn_rowsplit_set_timing_events(hipEvent_t start, hipEvent_t stop);
 
 // aux_kernels.hip
 hipError_t launch_pack(const float* src, long sb, long sr, long st, float* dst, int B, int R, int T, int Ts,

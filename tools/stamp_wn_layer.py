@@ -11,14 +11,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "diffsinger_amd", "csrc")
 OUT = os.path.join(ROOT, "diffsinger_amd", "libdsdenoise_stamps.so")
-srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "wn_layer.hip", "aux_kernels.hip", "encoder_kernels.hip",
+srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "wn_layer.hip", "wn_rowsplit.hip", "aux_kernels.hip", "encoder_kernels.hip",
                                         "vocoder_kernels.hip", "tconv.hip", "api.hip")]
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DDSD_STAMPS",
                 "-w", "-shared", "-o", OUT] + extra + srcs, check=True)
 if "--build-only" in sys.argv:
     sys.exit(0)
-os.environ["DSD_FUSED_LAYER"] = "1"
+ROWSPLIT = "--rowsplit" in sys.argv           # the B = 1 pair of wn_rowsplit.hip instead of the fused kernel
+if not ROWSPLIT:
+    os.environ["DSD_FUSED_LAYER"] = "1"
 
 import numpy as np
 import torch
@@ -44,6 +46,26 @@ with torch.no_grad():
     for _ in range(20):         # the stamps of the LAST layer launch survive; the chip is warm by then
         net(x, t, c)
 torch.cuda.synchronize()
+if ROWSPLIT:
+    buf2 = np.zeros((2, 4096, 10), dtype=np.uint64)
+    assert _lib.lib().dsd_dbg_read_rs_stamps(buf2.ctypes.data_as(C.c_void_p)) == 0
+    names = [("conv + FiLM + gate", ["tile decode -> loads issued (x, FiLM, 5 weight blocks)",
+                                     "x tile landed, FiLM + mask, LDS write, 2 barriers", "K walk (48 x 8 MFMA per wave)",
+                                     "LDS transpose, gate, z store", "-"]),
+             ("out-proj + residual / skip", ["tile decode -> loads issued (z, 5 weight blocks, bias)",
+                                             "z tile landed, LDS write, barrier", "K walk (16 x 8 MFMA per wave)",
+                                             "LDS transpose, residual / skip, stores", "-"])]
+    for k, (nm, labels) in enumerate(names):
+        st = buf2[k].astype(np.int64)
+        st = st[st[:, 0] > 0]
+        d = np.diff(st[:, :6], axis=1)
+        life = st[:, 5] - st[:, 0]
+        real = (st[:, 9] - st[:, 8]) * 10e-9
+        print(f"{nm}: {len(st)} workgroups; mean life {life.mean():.0f} cyc; in-kernel clock "
+              f"{np.median(life / np.maximum(real, 1e-12) / 1e9):.3f} GHz -> {np.median(real) * 1e6:.2f} us per workgroup")
+        for lb, m, mn, mx in zip(labels, d.mean(axis=0), d.min(axis=0), d.max(axis=0)):
+            print(f"    {lb:62s} mean {m:8.0f}  min {mn:8.0f}  max {mx:8.0f}")
+    sys.exit(0)
 buf = np.zeros((4096, 10), dtype=np.uint64)
 rc = _lib.lib().dsd_dbg_read_wn_stamps(buf.ctypes.data_as(C.c_void_p))
 assert rc == 0
