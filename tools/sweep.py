@@ -1,20 +1,22 @@
 #!/usr/bin/env python3
-"""Batch and frame sweep of the headline workload with the current build -> profiles/r01_sweep.json (GPU box only).
-Each point is one `bench.py` run (its JSON line, minus the CPU baseline); see DESIGN.md section 6."""
+"""Batch and frame sweep of the headline workload with the current build -> gpurun_out/<tag>_sweep.json (GPU box only;
+copy it to profiles/).  Each point is one `bench.py` run (its JSON line, minus the CPU baseline); see DESIGN.md section 6.
+Usage: python tools/sweep.py [tag, default r02]"""
 import json
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-points = [("wavenet_dpm50", b, 1000) for b in (1, 2, 4, 8, 16, 24)] + [("wavenet_dpm50", 1, t) for t in (128, 256, 512, 768, 1100, 1536, 2048, 4096)] + \
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+points = [("wavenet_dpm50", b, 1000) for b in (1, 2, 4, 8, 16, 24)] + [("wavenet_dpm50_ragged", 8, 0)] + [("wavenet_dpm50", 1, t) for t in (128, 256, 512, 768, 1100, 1536, 2048, 4096)] + \
          [("lynxnet_ddim100", b, 1000) for b in (1, 8)] + [("variance_reflow20", b, 1000) for b in (1, 8)] + \
          [("acoustic_default", 1, 1000), ("acoustic_wav", 1, 1000)]
 out = []
 for wl, b, t in points:
     steps = 10 if b * t <= 4000 else 4
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--batch", str(b), "--frames", str(t), "--steps", str(steps),
-           "--warmup", "2", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl.replace("_ragged", ""), "--batch", str(b), "--steps", str(steps),
+           "--warmup", "2", "--no-cpu-baseline"] + (["--ragged"] if wl.endswith("_ragged") else ["--frames", str(t)])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     try:
@@ -25,9 +27,9 @@ for wl, b, t in points:
     rf = j.get("roofline", {})
     row = dict(workload=wl, batch=b, frames=t, value=j["value"], ms_per_step=j["ms_per_step"], rtf=j.get("rtf"),
                path_tflops=j.get("path_tflops"), path_mfma_frac=j.get("path_mfma_frac"), kernel_avg_launch_us=rf.get("avg_launch_us"),
-               kernel_frac=rf.get("frac"), kernel_frac_of_measured=rf.get("frac_of_measured"))
+               kernel_frac=rf.get("frac"), kernel=rf.get("kernel", "")[:40], frames_mean=j["config"].get("frames"))
     out.append(row)
     print(json.dumps(row), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-with open(os.path.join(ROOT, "gpurun_out", "r01_sweep.json"), "w") as f:
+with open(os.path.join(ROOT, "gpurun_out", f"{tag}_sweep.json"), "w") as f:
     json.dump(out, f, indent=1)
