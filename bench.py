@@ -338,7 +338,8 @@ def main():
             inner = Cc * bargs["expansion_factor"]
             kflops = 2 * Cc * 2 * inner * vf
             kbytes = (4 * Cc + 4 * inner) * vf
-            kname = "gemm_kernel<ST_LN,1,EP_SWIGLU> (LayerNorm -> 1x1 C->4C -> SwiGLU)"
+            kname = ("LayerNorm -> 1x1 C->4C -> SwiGLU GEMM (lx_pw1_kernel, K resident in LDS, on batched grids; "
+                     "gemm_kernel<ST_LN,1,EP_SWIGLU> on small ones)")
         traffic, traffic_src, prof_ns, prof_split = None, None, None, None
         try:   # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of this same command
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))

@@ -1333,7 +1333,48 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
         g.p.ln_stats = h->stats; g.p.ln_ts = Ts;
         return DSD_OK;
     };
+    // Batched grids: the two pointwise GEMMs with the whole K extent of a 32-frame tile resident in LDS (lynx_layer.hip);
+    // pw2 launches only C / 512 workgroups per frame tile, so a single utterance stays on the GEMM family
+    const bool lx_ragged = h->use_cg && !h->lens_host.empty();
+    const long lx_tiles = lx_ragged ? (long)h->cg_n[1] : (long)B * ((T + 31) / 32);
+    static const int lx_env = getenv("DSD_LYNX_RESIDENT") ? atoi(getenv("DSD_LYNX_RESIDENT")) : -1;
+    const bool lx_res = lx_env != 0 && lx_layer_supported(C, inner) && (lx_env == 1 || lx_tiles * (C / 512) >= 192);      // measured at C = 1024: slower at B = 2, +4 % at 3, +12 % at 4, +10 % at 8
     for (int l = 0; l < L; ++l) {
+        if (lx_res) {
+            hipError_t me = launch_ln_merge(h->lnpart, ln_tiles, C, B, T, Ts, 1e-5f, h->stats, st);
+            if (me != hipSuccess) return fail(h, DSD_EHIP, "LayerNorm merge launch failed: %s", hipGetErrorString(me));
+            LxLayerP p;
+            memset(&p, 0, sizeof(p));
+            p.A1 = h->blob + h->g_pw1[l].a_off; p.bias1 = h->blob + h->g_pw1[l].bias_off;
+            p.A2 = h->blob + h->g_pw2[l].a_off; p.bias2 = h->blob + h->g_pw2[l].bias_off;
+            p.xin = h->xin; p.stats = h->stats; p.u = h->ubuf; p.v = h->vbuf; p.x = h->xh;
+            p.x_bstride = xs; p.u_bstride = us; p.inner = inner; p.Ts = Ts; p.T = T;
+            p.tiles_per_b = (T + 31) / 32; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
+            p.nft = B * p.tiles_per_b;
+            if (lx_ragged) { p.cgmap = h->cg_dev[1]; p.ncg = h->cg_n[1]; }
+            p.inv_nft = 1.0f / (float)std::max(1, lx_ragged ? p.ncg : p.nft);
+            p.strong = h->cfg.strong_cond;
+            p.lnpart = h->lnpart; p.lnpart_ts = Ts; p.ln_tiles = ln_tiles;
+            const int next = l + 1;
+            p.xin_out = next < L ? h->xin : nullptr;
+            if (next < L) {
+                p.cpn = h->cp + (long)next * C * Ts; p.cpn_bstride = (long)L * C * Ts;
+                p.film = h->D + (long)next * C * Ns; p.film_cstride = Ns; p.film_col0 = film_col0; p.film_colb = film_colb;
+            }
+            timed_begin();
+            if (timed_now) lx_layer_set_timing_events(h->ev_pool[h->ev_used].first, h->ev_pool[h->ev_used].second);
+            hipError_t le = launch_lx_layer(p, 0, C, st);
+            if (timed_now) lx_layer_set_timing_events(nullptr, nullptr);
+            timed_end();
+            if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw1 launch failed: %s", hipGetErrorString(le));
+            e = launch_dwconv(h->ubuf, h->vbuf, us, Ts, inner, B, T, h->lens_host.empty() ? nullptr : h->lens_dev,
+                              h->blob + h->dw_w[l], h->blob + h->dw_b[l], h->cfg.kernel_size, h->cfg.activation,
+                              h->dw_prelu[l] == SIZE_MAX ? nullptr : h->blob + h->dw_prelu[l], st);
+            if (e != hipSuccess) return fail(h, DSD_EHIP, "dwconv launch failed: %s", hipGetErrorString(e));
+            if ((le = launch_lx_layer(p, 1, C, st)) != hipSuccess)
+                return fail(h, DSD_EHIP, "LYNXNet pw2 launch failed: %s", hipGetErrorString(le));
+            continue;
+        }
         GemmCall g = make_gemm(h, h->g_pw1[l], h->xin, xs, Ts, B, T, ST_LN, EP_SWIGLU, 0);
         if ((rc = ln_input(g))) return rc;
         g.p.out = h->ubuf; g.p.o_bstride = us; g.p.o_rstride = Ts;
@@ -1415,6 +1456,7 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
     hipError_t ie = gemm_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_layer_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_rowsplit_init_all();
+    if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_LYNXNET) ie = lx_layer_init_all();
     if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
     dsd_handle* h = new dsd_handle();
     h->cfg = *cfg;

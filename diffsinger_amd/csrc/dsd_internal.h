@@ -153,6 +153,35 @@ hipError_t wn_rowsplit_init_all();
 bool wn_rowsplit_supported(int C, int dil);
 void wn_rowsplit_set_timing_events(hipEvent_t start, hipEvent_t stop);
 
+// lynx_layer.hip: LYNXNet's two pointwise GEMMs with the whole K extent of a 32-frame tile resident in LDS (batched grids)
+struct LxLayerP {
+    const float* A1;        // packed pw1 weights (PackedGemm, pairC = inner; LayerNorm affine folded in)
+    const float* bias1;     // [2 inner]
+    const float* A2;        // packed pw2 weights
+    const float* bias2;     // [C]
+    const float* xin;       // pw1 input: the layer's pre-LayerNorm activations [B][C][Ts]
+    const float* stats;     // [B][2][Ts]: mean, rstd per frame (ln_merge_kernel)
+    float* u;               // pw1 output [B][inner][Ts]
+    const float* v;         // pw2 input (depthwise conv output) [B][inner][Ts]
+    float* x;               // residual stream [B][C][Ts]: read and replaced by pw2
+    float* xin_out;         // the NEXT layer's pre-LayerNorm input (nullptr after the last layer)
+    const float* cpn;       // next layer's hoisted conditioner projection rows [C][Ts] (nullptr after the last layer)
+    long cpn_bstride;
+    const float* film;      // next layer's step projection: d[c] = film[c * film_cstride + film_col0 + b * film_colb]
+    int film_cstride, film_col0, film_colb;
+    float* lnpart;          // [B][C / 64][2][lnpart_ts]: per 64-row tile mean and sum of squared deviations of xin_out
+    int lnpart_ts, ln_tiles;
+    long x_bstride, u_bstride;
+    int inner, Ts, T, tiles_per_b, nft, strong;
+    float inv_tiles_per_b, inv_nft;     // inv_nft = 1 / (ragged ? ncg : nft)
+    const int* cgmap;       // ragged batches: the (item, 32-frame tile) column groups that hold valid frames
+    int ncg;
+};
+hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st);      // which: 0 = pw1, 1 = pw2
+bool lx_layer_supported(int C, int inner);
+hipError_t lx_layer_init_all();
+void lx_layer_set_timing_events(hipEvent_t start, hipEvent_t stop);
+
 // aux_kernels.hip
 hipError_t launch_pack(const float* src, long sb, long sr, long st, float* dst, int B, int R, int T, int Ts,
                        hipStream_t stream);

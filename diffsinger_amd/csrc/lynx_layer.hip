@@ -1,0 +1,471 @@
+// LYNXNet's two pointwise GEMMs (lynxnet.py:53-59 inside LYNXConvModule, :76-84 around it) for batched grids, in the
+// style of wn_layer.hip: a workgroup owns 32 frames and 512 output rows, the WHOLE K extent (up to 1024 channels) of its
+// activation tile is resident in LDS, and the K walk is one uninterrupted, fully unrolled stream - weights as 1 KiB
+// fragment blocks straight from L2 into a three-set register rotation, compiler-counted waits, one load behind every 8
+// MFMAs.  (gemm.hip walks K in 64-channel chunks with a barrier per chunk and 16 MFMAs per k16 step: 71 % of the fp32
+// MFMA peak on these shapes; the resident walk of wn_layer.hip runs at 33 cycles per MFMA.)
+//
+//   lx_pw1_kernel : u = out * silu(gate),  [out; gate] = W1 LayerNorm(xin) + b1      (LN affine folded into W1 / b1;
+//                   per-frame (mean, rstd) from ln_merge_kernel applied while the tile is staged)
+//   lx_pw2_kernel : v = W2 u' + b2 + x  (residual), then the NEXT layer's transition exactly as gemm.hip's EP_LYNX_NEXT:
+//                   strong: x = v + cpn, xin = x + d;  else: x = v, xin = v + cpn + d;  no next layer: x = xin = v;
+//                   plus the LayerNorm partials (mean, sum of squared deviations) of xin per 64-row tile and frame.
+//                   K = inner (2048) is walked as two resident phases of 1024 channels.
+//
+// LDS tile: [K][32] floats with NO padding (a 1024-channel tile is 128 KiB): the 4 k-rows x 16 columns of a B-fragment
+// read hit 64 distinct banks because odd rows are stored with their two 16-column halves swapped (physical column =
+// column XOR 16 * (row & 1)); a lane's row parity is its own (lane >> 4) & 1, so the swizzle is a per-lane constant.
+#include <hip/hip_ext.h>
+
+#include "dsd_internal.h"
+
+namespace dsd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+constexpr unsigned kRange = 0x7FFFFFF0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* ptr) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, kRange, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void st4(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
+
+constexpr int BN = 32;          // frames per tile
+constexpr int MBW = 8;          // 16-row blocks per wave: 128 rows, 512 per workgroup
+constexpr int ES = BN + 4;      // row stride of the epilogue transpose tiles
+
+// XCD-aware remap (speed only): an XCD takes a contiguous range of work items; with the row tile SLOWEST an XCD walks all
+// frame tiles of (about) one row tile, whose 2 MiB of weights then stay in its L2 while the activation tiles stream
+__device__ __forceinline__ int xcd_work() {
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+}
+
+// 64 MFMAs of a k16 step with the step's MBW weight loads (for step s + 2), one optional operand load and the 8 LDS reads
+// of step s + 1 between them
+#define LX_SPREAD()                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
+    _Pragma("unroll") for (int g_ = 1; g_ < MBW; ++g_) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           \
+    }                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+
+// One resident K phase of KT channels: NS = KT / 16 steps from the weight stream r_w starting at block step0.  The three
+// weight sets rotate: local step s runs from W[(s + ROT) % 3]; W[ROT % 3], W[(ROT + 1) % 3] must hold steps step0,
+// step0 + 1 on entry, and with MORE the last two steps fetch the next phase's first two blocks (whose ROT is
+// (ROT + NS) % 3), so that two phases chain without a bubble.  extra(s) is called once per step for operand loads that
+// ride along.
+template <int KT, int ROT, bool MORE, typename Extra>
+__device__ __forceinline__ void k_phase(f32x4 (&acc)[MBW][2], f32x4 (&W)[3][MBW], const __amdgpu_buffer_rsrc_t r_w, const int (&wk)[MBW],
+                                        int step0, const float* zt0, const float* zt1, Extra extra) {
+    constexpr int NS = KT / 16;
+    float bq[2][4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bq[0][j][0] = zt0[(j * 4) * BN];
+        bq[0][j][1] = zt1[(j * 4) * BN];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 2 < NS || MORE) {
+            const int g = step0 + s + 2;
+#pragma unroll
+            for (int k = 0; k < MBW; ++k) W[(s + 2 + ROT) % 3][k] = ld4(r_w, wk[k] + (g & 3) * 1024, (g >> 2) * 4096);
+        }
+        extra(s);
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bq[(s + 1) & 1][j][0] = zt0[((s + 1) * 16 + j * 4) * BN];
+                bq[(s + 1) & 1][j][1] = zt1[((s + 1) * 16 + j * 4) * BN];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < MBW; ++k) {
+                acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[(s + ROT) % 3][k][j], bq[s & 1][j][0], acc[k][0], 0, 0, 0);
+                acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[(s + ROT) % 3][k][j], bq[s & 1][j][1], acc[k][1], 0, 0, 0);
+            }
+        LX_SPREAD()
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// pw1: LayerNorm -> 1x1 C -> 2 * inner -> SwiGLU.  KT = C (512 or 1024); packed rows: pairs (out row r, gate row r + inner)
+// interleaved per 16-row block (PackedGemm with pairC = inner): even block = out, odd = gate of 16 channels.
+// Workgroup = 256 pairs (channels [256 mtile, +256) of u) x 32 frames; wave w: channels [256 mtile + 64 w, +64).
+// ---------------------------------------------------------------------------------------------------------------
+template <int KT, int RAG>
+__global__ __launch_bounds__(256, 1) void lx_pw1_kernel(const LxLayerP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NS = KT / 16;
+    constexpr int NU = KT * (BN / 4) / 256;         // staged float4 per thread: 32 (K = 1024), 16 (K = 512)
+    float* xs = lds;                                 // [KT][32], odd rows half-swapped; later the epilogue tiles
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
+    const int work = xcd_work();
+    const int nft = RAG ? p.ncg : p.nft;
+    const int mtile = fdiv_floor(work, p.inv_nft);
+    const int ft = work - mtile * nft;
+    const int rest = RAG ? p.cgmap[ft] : ft;
+    const int b = fdiv_floor(rest, p.inv_tiles_per_b);
+    const int t0 = (rest - b * p.tiles_per_b) * BN;
+    const int Ts = p.Ts;
+    const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
+    const int mu = __builtin_amdgcn_readfirstlane(mtile);
+
+    // ---------------- prologue: LayerNorm statistics of the tile's frames, the activation tile, two weight steps ----------------
+    const int c4 = tid & 7;                                      // the thread's frames 4 c4 .. 4 c4 + 3, for every staged row
+    const __amdgpu_buffer_rsrc_t r_s = rsrc(p.stats + (long)bu * 2 * Ts + t0u);
+    const f32x4 mean = ld4(r_s, c4 * 16, 0), rstd = ld4(r_s, c4 * 16, Ts * 4);
+    const __amdgpu_buffer_rsrc_t r_x = rsrc(p.xin + (long)bu * p.x_bstride + t0u);
+    const __amdgpu_buffer_rsrc_t r_w = rsrc(p.A1 + (long)(MBW * 4 * mu + MBW * wave) * NS * 256);
+    int wk[MBW];
+#pragma unroll
+    for (int k = 0; k < MBW; ++k) wk[k] = lane * 16 + k * NS * 1024;
+    f32x4 W[3][MBW];
+    const int xv0 = ((tid >> 3) * Ts + c4 * 4) * 4;              // row tid >> 3 (+ 32 per slot)
+    constexpr int NB4 = 8;                                       // slots per staging batch (bounds the registers in flight)
+#pragma unroll
+    for (int u0 = 0; u0 < NU; u0 += NB4) {
+        f32x4 sv[NB4];
+#pragma unroll
+        for (int u = 0; u < NB4; ++u) sv[u] = ld4(r_x, xv0, (u0 + u) * 32 * Ts * 4);
+        if (u0 == 0) {
+#pragma unroll
+            for (int k = 0; k < MBW; ++k) {
+                W[0][k] = ld4(r_w, wk[k], 0);
+                W[1][k] = ld4(r_w, wk[k] + 1024, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB4; ++u) {
+            const int row = (tid >> 3) + 32 * (u0 + u);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (sv[u][e] - mean[e]) * rstd[e];        // LayerNorm (lynxnet.py:53), affine in W1 / b1
+            *reinterpret_cast<f32x4*>(&xs[row * BN + ((c4 * 4) ^ ((row & 1) << 4))]) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- K walk ----------------
+    f32x4 acc[MBW][2];
+#pragma unroll
+    for (int k = 0; k < MBW; ++k) acc[k][0] = acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sw = (lrow & 1) << 4;
+    const float* zt0 = xs + lrow * BN + (lcol ^ sw);
+    const float* zt1 = xs + lrow * BN + ((16 + lcol) ^ sw);
+    // biases of the wave's rows in the accumulator layout (rows rq .. rq + 3 of each block), fetched during the walk
+    const int ch0 = 256 * mu + 64 * wave;                        // first u channel of this wave
+    const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias1);
+    f32x4 bo[MBW];
+    k_phase<KT, 0, false>(acc, W, r_w, wk, 0, zt0, zt1, [&](int s) {
+        if (s < MBW) bo[s] = ld4(r_b, rq * 4, ((s & 1) * p.inner + ch0 + (s >> 1) * 16) * 4);
+    });
+
+    // ---------------- SwiGLU (common_layers.py:116-117: out * silu(gate)), transposed through LDS, float4 stores ----------------
+    __syncthreads();                                             // every wave is done with the activation tile
+    float* ew = xs + wave * (64 * ES);                           // wave-private [64 channels][ES]
+#pragma unroll
+    for (int i = 0; i < MBW / 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u0 = acc[2 * i][n][r] + bo[2 * i][r];
+                const float u1 = acc[2 * i + 1][n][r] + bo[2 * i + 1][r];
+                ew[(i * 16 + rq + r) * ES + n * 16 + lcol] = u0 * (u1 * sigmoid_f(u1));
+            }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        const __amdgpu_buffer_rsrc_t r_o = rsrc(p.u + (long)bu * p.u_bstride + (long)ch0 * Ts + t0u);
+        const int ev0 = ((lane >> 3) * Ts + (lane & 7) * 4) * 4;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int idx = lane + 64 * m;
+            st4(*reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]), r_o, ev0, m * 8 * Ts * 4);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pw2: 1x1 inner -> C on the depthwise conv's output, + bias + residual, then the next layer's transition and the
+// LayerNorm partials of its input.  K = inner walked as NP = inner / 1024 resident phases of KT = 1024 channels (or one
+// phase of 512 / 1024).  Workgroup = 512 rows x 32 frames; wave w: rows [512 mtile + 128 w, +128) = 64-row tiles 2w, 2w+1.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KT, int RAG>
+__global__ __launch_bounds__(256, 1) void lx_pw2_kernel(const LxLayerP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NS = KT / 16;
+    constexpr int NU = KT * (BN / 4) / 256;
+    float* xs = lds;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
+    const int work = xcd_work();
+    const int nft = RAG ? p.ncg : p.nft;
+    const int mtile = fdiv_floor(work, p.inv_nft);
+    const int ft = work - mtile * nft;
+    const int rest = RAG ? p.cgmap[ft] : ft;
+    const int b = fdiv_floor(rest, p.inv_tiles_per_b);
+    const int t0 = (rest - b * p.tiles_per_b) * BN;
+    const int Ts = p.Ts;
+    const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
+    const int mu = __builtin_amdgcn_readfirstlane(mtile);
+    const int np = p.inner / KT;                                 // resident phases
+    const int NSA = p.inner / 16;                                // k16 steps of the whole weight stream
+
+    const int c4 = tid & 7;
+    const __amdgpu_buffer_rsrc_t r_v = rsrc(p.v + (long)bu * p.u_bstride + t0u);
+    const __amdgpu_buffer_rsrc_t r_w = rsrc(p.A2 + (long)(MBW * 4 * mu + MBW * wave) * NSA * 256);
+    int wk[MBW];
+#pragma unroll
+    for (int k = 0; k < MBW; ++k) wk[k] = lane * 16 + k * NSA * 1024;
+    f32x4 W[3][MBW];
+    const int xv0 = ((tid >> 3) * Ts + c4 * 4) * 4;
+    constexpr int NB4 = 8;
+    auto stage = [&](int phase, bool first) {
+#pragma unroll
+        for (int u0 = 0; u0 < NU; u0 += NB4) {
+            f32x4 sv[NB4];
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) sv[u] = ld4(r_v, xv0, (phase * KT + (u0 + u) * 32) * Ts * 4);
+            if (first && u0 == 0) {
+#pragma unroll
+                for (int k = 0; k < MBW; ++k) {
+                    W[0][k] = ld4(r_w, wk[k], 0);
+                    W[1][k] = ld4(r_w, wk[k] + 1024, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) {
+                const int row = (tid >> 3) + 32 * (u0 + u);
+                *reinterpret_cast<f32x4*>(&xs[row * BN + ((c4 * 4) ^ ((row & 1) << 4))]) = sv[u];
+            }
+        }
+    };
+    // bias and the next layer's step-projection scalar of the workgroup's 512 rows -> LDS tables behind the tiles
+    constexpr int TBL = (KT * BN > 4 * 128 * ES) ? KT * BN : 4 * 128 * ES;
+    {
+        const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias2 + 512 * mu);
+        const float b0 = ld1(r_b, tid * 4, 0), b1 = ld1(r_b, tid * 4, 1024);
+        float f0 = 0.f, f1 = 0.f;
+        if (p.film) {
+            const __amdgpu_buffer_rsrc_t r_f = rsrc(p.film + p.film_col0 + bu * p.film_colb + (long)512 * mu * p.film_cstride);
+            f0 = ld1(r_f, tid * p.film_cstride * 4, 0);
+            f1 = ld1(r_f, (tid + 256) * p.film_cstride * 4, 0);
+        }
+        lds[TBL + tid] = b0;
+        lds[TBL + 256 + tid] = b1;
+        lds[TBL + 512 + tid] = f0;
+        lds[TBL + 768 + tid] = f1;
+    }
+    stage(0, true);
+    __syncthreads();
+
+    f32x4 acc[MBW][2];
+#pragma unroll
+    for (int k = 0; k < MBW; ++k) acc[k][0] = acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sw = (lrow & 1) << 4;
+    const float* zt0 = xs + lrow * BN + (lcol ^ sw);
+    const float* zt1 = xs + lrow * BN + ((16 + lcol) ^ sw);
+    // epilogue operands, row-major float4 over the wave's 128 rows (lane -> row (lane >> 3) + 8 m, frames 4 (lane & 7)):
+    // residual x, the next layer's conditioner projection; and per row its bias and step-projection scalar
+    const int row0 = 512 * mu + 128 * wave;
+    const int ev0 = ((lane >> 3) * Ts + (lane & 7) * 4) * 4;
+    const __amdgpu_buffer_rsrc_t r_a = rsrc(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    const __amdgpu_buffer_rsrc_t r_c = rsrc((p.cpn ? p.cpn : p.x) + (long)bu * (p.cpn ? p.cpn_bstride : p.x_bstride) + (long)row0 * Ts + t0u);
+    f32x4 aux[16], cpv[16];
+    auto tail_loads = [&](int s) {
+        if (s < 16) aux[s] = ld4(r_a, ev0, s * 8 * Ts * 4);
+        else if (s < 32) cpv[s - 16] = ld4(r_c, ev0, (s - 16) * 8 * Ts * 4);
+    };
+    auto none = [](int) {};
+    if (np == 1) {
+        k_phase<KT, 0, false>(acc, W, r_w, wk, 0, zt0, zt1, tail_loads);
+    } else {                                                     // two resident phases (inner = 2 KT)
+        k_phase<KT, 0, true>(acc, W, r_w, wk, 0, zt0, zt1, none);
+        __syncthreads();                                         // every wave is done with the first phase's tile
+        stage(1, false);
+        __syncthreads();
+        k_phase<KT, NS % 3, false>(acc, W, r_w, wk, NS, zt0, zt1, tail_loads);
+    }
+    __syncthreads();                                             // the tile is dead: the epilogue tiles go over it
+    const float* tb = lds + TBL;                                 // bias and step-projection scalar of the workgroup's 512 rows
+    const float* tf = tb + 512;
+
+    // ---------------- transition (gemm.hip EP_LYNX_NEXT; lynxnet.py:76-84 of the next layer), row-major ----------------
+    float* ew = xs + wave * (128 * ES);                          // wave-private [128 rows][ES]: 18 KiB x 4 waves
+#pragma unroll
+    for (int k = 0; k < MBW; ++k)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ew[(k * 16 + rq + r) * ES + n * 16 + lcol] = acc[k][n][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const __amdgpu_buffer_rsrc_t r_xo = rsrc(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    const __amdgpu_buffer_rsrc_t r_xi = rsrc((p.xin_out ? p.xin_out : p.x) + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    f32x4 xi[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int idx = lane + 64 * m;
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]);
+        const float brow = tb[128 * wave + (idx >> 3)], frow = tf[128 * wave + (idx >> 3)];
+        f32x4 xo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = (a4[e] + brow) + aux[m][e];              // + bias, + residual (lynxnet.py:86)
+            float o = v, in = v;
+            if (p.cpn) {
+                in = v + cpv[m][e];
+                if (p.strong) o = in;
+            }
+            if (p.film) in = in + frow;
+            xo[e] = o;
+            xi[m][e] = in;
+        }
+        st4(xo, r_xo, ev0, m * 8 * Ts * 4);
+        if (p.xin_out) st4(xi[m], r_xi, ev0, m * 8 * Ts * 4);
+    }
+    // LayerNorm partials of xin per 64-row tile (tiles 2w, 2w + 1 of this workgroup's 8): two passes over the registers.
+    // A frame's 64 rows sit in 8 slots m of the 8 lanes with equal (lane & 7): sum over m, then over lanes 8, 16, 32 apart.
+    if (p.lnpart) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 8; ++m) s += xi[8 * h + m];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += __shfl_xor(s[e], 8, 64);
+                s[e] += __shfl_xor(s[e], 16, 64);
+                s[e] += __shfl_xor(s[e], 32, 64);
+            }
+            const f32x4 mu4 = s * (1.f / 64.f);
+            f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const f32x4 d = xi[8 * h + m] - mu4;
+                q += d * d;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                q[e] += __shfl_xor(q[e], 8, 64);
+                q[e] += __shfl_xor(q[e], 16, 64);
+                q[e] += __shfl_xor(q[e], 32, 64);
+            }
+            if (lane < 8) {
+                const int tile = 8 * mu + 2 * wave + h;
+                float* lp = p.lnpart + ((long)bu * p.ln_tiles + tile) * 2 * p.lnpart_ts + t0u + lane * 4;
+                *reinterpret_cast<f32x4*>(lp) = mu4;
+                *reinterpret_cast<f32x4*>(lp + p.lnpart_ts) = q;
+            }
+        }
+    }
+}
+#undef LX_SPREAD
+
+int lx_lds_bytes(int kt) { return (kt * 32 * 4 > 4 * 128 * 36 * 4 ? kt * 32 * 4 : 4 * 128 * 36 * 4) + 1024 * 4; }
+
+bool lx_layer_supported(int C, int inner) {
+    // pw1 needs C = the resident K (512 / 1024) and 2 * inner rows in workgroups of 512; pw2 C rows in workgroups of 512 and
+    // inner a whole number of resident phases
+    return (C == 512 || C == 1024) && (2 * inner) % 512 == 0 && C % 512 == 0 && inner % C == 0 && inner / C <= 2;
+}
+
+template <typename K>
+static hipError_t lx_attr(K kern) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+static thread_local hipEvent_t g_lx_ev0 = nullptr, g_lx_ev1 = nullptr;
+void lx_layer_set_timing_events(hipEvent_t start, hipEvent_t stop) {
+    g_lx_ev0 = start;
+    g_lx_ev1 = stop;
+}
+
+template <int KT, int RAG>
+static hipError_t lx_launch(const LxLayerP& p, int which, int nwg, hipStream_t st) {
+    static bool attr1 = false, attr2 = false;
+    if (which == 0 && !attr1) {
+        hipError_t e = lx_attr(lx_pw1_kernel<KT, RAG>);
+        if (e != hipSuccess) return e;
+        attr1 = true;
+    }
+    if (which == 1 && !attr2) {
+        hipError_t e = lx_attr(lx_pw2_kernel<KT, RAG>);
+        if (e != hipSuccess) return e;
+        attr2 = true;
+    }
+    if (nwg == 0) return hipSuccess;
+    const int ldsb = lx_lds_bytes(KT);
+    if (which == 0) {
+        if (g_lx_ev0 && g_lx_ev1)
+            hipExtLaunchKernelGGL((lx_pw1_kernel<KT, RAG>), dim3(nwg), dim3(256), ldsb, st, g_lx_ev0, g_lx_ev1, 0, p);
+        else
+            hipLaunchKernelGGL((lx_pw1_kernel<KT, RAG>), dim3(nwg), dim3(256), ldsb, st, p);
+    } else {
+        hipLaunchKernelGGL((lx_pw2_kernel<KT, RAG>), dim3(nwg), dim3(256), ldsb, st, p);
+    }
+    return hipGetLastError();
+}
+
+// which = 0: pw1 (LayerNorm -> C -> 2 inner -> SwiGLU);  1: pw2 (inner -> C + residual + next-layer transition)
+hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st) {
+    const int nft = p.cgmap ? p.ncg : p.nft;
+    const int mtiles = which == 0 ? (2 * p.inner) / 512 : C / 512;
+    const int nwg = nft * mtiles;
+    if (C == 1024) return p.cgmap ? lx_launch<1024, 1>(p, which, nwg, st) : lx_launch<1024, 0>(p, which, nwg, st);
+    if (C == 512) return p.cgmap ? lx_launch<512, 1>(p, which, nwg, st) : lx_launch<512, 0>(p, which, nwg, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t lx_layer_init_all() {
+    LxLayerP p{};
+    hipError_t e;
+    for (int C : {512, 1024})
+        for (int rag = 0; rag < 2; ++rag) {
+            p.inner = 2 * C;
+            p.cgmap = rag ? reinterpret_cast<const int*>(&p) : nullptr;
+            p.ncg = 0;
+            p.nft = 0;
+            if ((e = launch_lx_layer(p, 0, C, nullptr)) != hipSuccess) return e;
+            if ((e = launch_lx_layer(p, 1, C, nullptr)) != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
+}  // namespace dsd
