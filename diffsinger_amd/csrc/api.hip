@@ -1338,7 +1338,12 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
     const bool lx_ragged = h->use_cg && !h->lens_host.empty();
     const long lx_tiles = lx_ragged ? (long)h->cg_n[1] : (long)B * ((T + 31) / 32);
     static const int lx_env = getenv("DSD_LYNX_RESIDENT") ? atoi(getenv("DSD_LYNX_RESIDENT")) : -1;
-    const bool lx_res = lx_env != 0 && lx_layer_supported(C, inner) && (lx_env == 1 || lx_tiles * (C / 512) >= 192);      // measured at C = 1024: slower at B = 2, +4 % at 3, +12 % at 4, +10 % at 8
+    const bool lx_ok = lx_env != 0 && lx_layer_supported(C, inner);
+    // pw1 launches 2 inner / 512 workgroups per frame tile (8 at C = 1024: one utterance of ~1000 frames already fills the
+    // chip), pw2 only C / 512 (measured at C = 1024: slower at B = 2, +4 % at 3, +12 % at 4, +10 % at 8)
+    const bool lx_res1 = lx_ok && (lx_env == 1 || lx_tiles * (2 * inner / 512) >= 192);
+    const bool lx_res2 = lx_ok && (lx_env == 1 || lx_tiles * (C / 512) >= 192);
+    const bool lx_res = lx_res1;
     for (int l = 0; l < L; ++l) {
         if (lx_res) {
             hipError_t me = launch_ln_merge(h->lnpart, ln_tiles, C, B, T, Ts, 1e-5f, h->stats, st);
@@ -1371,8 +1376,16 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                               h->blob + h->dw_w[l], h->blob + h->dw_b[l], h->cfg.kernel_size, h->cfg.activation,
                               h->dw_prelu[l] == SIZE_MAX ? nullptr : h->blob + h->dw_prelu[l], st);
             if (e != hipSuccess) return fail(h, DSD_EHIP, "dwconv launch failed: %s", hipGetErrorString(e));
-            if ((le = launch_lx_layer(p, 1, C, st)) != hipSuccess)
-                return fail(h, DSD_EHIP, "LYNXNet pw2 launch failed: %s", hipGetErrorString(le));
+            if (lx_res2) {
+                if ((le = launch_lx_layer(p, 1, C, st)) != hipSuccess)
+                    return fail(h, DSD_EHIP, "LYNXNet pw2 launch failed: %s", hipGetErrorString(le));
+            } else {
+                GemmCall o = make_gemm(h, h->g_pw2[l], h->vbuf, us, Ts, B, T, ST_PLAIN, EP_LYNX_NEXT, 0);
+                o.p.act = ACT_NONE;
+                o.p.aux = h->xh; o.p.aux_bstride = xs; o.p.aux_rstride = Ts;
+                lynx_next(o, l + 1);
+                if ((rc = run_gemm(h, o, st))) return rc;
+            }
             continue;
         }
         GemmCall g = make_gemm(h, h->g_pw1[l], h->xin, xs, Ts, B, T, ST_LN, EP_SWIGLU, 0);
