@@ -118,13 +118,18 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     const __amdgpu_buffer_rsrc_t r_x = rsrc(p.xin + (long)bu * p.x_bstride + (t0u - HL));       // inside the arena's guard at t0 = 0
     const __amdgpu_buffer_rsrc_t r_f = rsrc(p.film + p.film_col0 + bu * p.film_colb);
     const float fmine = ld1(r_f, min(tid, C - 1) * p.film_cstride * 4, 0);      // d[channel tid] of this item / step
+    // Only the first 64-channel chunk of the tile (all the first 12 steps of GEMM 1 read) is fetched before the walk starts;
+    // the other chunks travel one float4 per step behind its MFMAs and go to LDS after step 11.
+    constexpr int NU0 = W4 / 4;                     // float4 per thread of a 64-channel chunk (idx = tid + 256 u)
+    static_assert(64 * W4 == NU0 * 256 && NU - NU0 <= 12, "chunk 0 = the first NU0 staging slots; the rest fit 12 steps");
     f32x4 sv[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    auto x_voff = [&](int u) {
         const int idx = tid + 256 * u;
         const int row = idx / W4, c4 = idx - row * W4;
-        sv[u] = ld4(r_x, (row * Ts + c4 * 4) * 4, 0);
-    }
+        return (row * Ts + c4 * 4) * 4;
+    };
+#pragma unroll
+    for (int u = 0; u < NU0; ++u) sv[u] = ld4(r_x, x_voff(u), 0);
     // weight streams of this wave: MBW row blocks, each a linear sequence of 1 KiB fragment blocks in K-walk order.
     // Three fragment sets in rotation: step s runs from W[s % 3] while step s + 2's MBW loads are spread between its MFMAs
     // (a set loaded during the previous step only would have a quarter of a step of cover for its last block).
@@ -152,8 +157,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     es[tid] = fmine;                                             // (threads beyond C: a copy of the last channel's, unused)
     __syncthreads();
     // FiLM add, then the zero padding (wavenet.py:36-38: the pad is applied to x + d), then LDS
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    auto stage_write = [&](int u) {
         const int idx = tid + 256 * u;
         const int row = idx / W4, c4 = idx - row * W4;
         const float fa = es[row];
@@ -164,7 +168,9 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
             o[e] = (t >= 0 && t < Tb) ? sv[u][e] + fa : 0.f;
         }
         *reinterpret_cast<f32x4*>(&xs[row * SW + c4 * 4]) = o;
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < NU0; ++u) stage_write(u);
     __syncthreads();
     WN_STAMP(2);
 
@@ -227,19 +233,33 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     f32x4 bo[MBW];
     read_b1(bq[0], 0);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < NS1; ++s) {
+    auto conv_step = [&](int s) {
         // step s + 2: a conv step, or one of the out-proj's first two blocks behind the last conv steps
         if (s + 2 < NS1) load_w1(W[(s + 2) % 3], s + 2);
         else load_w2(W[(s + 2) % 3], s + 2 - NS1);
-        if (s < NE)                                              // filter rows sit C rows below the gate rows
-            cpv[s] = ld4(r_c, ev0, ((s % (NE / 2)) * 8 + (s >= NE / 2 ? C : 0)) * Ts * 4);
-        else if (s < NE + MBW)
-            bo[s - NE] = ld4(r_b, rq * 4, (s - NE) * 64);
-        read_b1(bq[(s + 1) & 1], s + 1 < NS1 ? s + 1 : 0);      // (after the last step: unused)
+        // the step's one extra operand load: the rest of the x tile first, then the conditioner projection (filter rows sit
+        // C rows below the gate rows), then the out-proj bias
+        if (s < NU - NU0)
+            sv[NU0 + s] = ld4(r_x, x_voff(NU0 + s), 0);
+        else if (s >= 12 && s < 12 + NE)
+            cpv[s - 12] = ld4(r_c, ev0, (((s - 12) % (NE / 2)) * 8 + (s - 12 >= NE / 2 ? C : 0)) * Ts * 4);
+        else if (s >= 12 + NE && s < 12 + NE + MBW)
+            bo[s - 12 - NE] = ld4(r_b, rq * 4, (s - 12 - NE) * 64);
+        if (s != 11) read_b1(bq[(s + 1) & 1], s + 1 < NS1 ? s + 1 : 0);      // (after the last step: unused)
         mfma_step(W[s % 3], bq[s & 1]);
         WN_SPREAD()
-    }
+    };
+#pragma unroll
+    for (int s = 0; s < 12; ++s) conv_step(s);
+    // chunks 1.. of the x tile are read from step 12 on
+#pragma unroll
+    for (int u = NU0; u < NU; ++u) stage_write(u);
+    __syncthreads();
+    read_b1(bq[0], 12);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 12; s < NS1; ++s) conv_step(s);
+    static_assert(12 + NE + MBW <= NS1, "one extra operand load per step");
     WN_STAMP(3);
 
     // ---------------- gate (wavenet.py:41-42); z -> LDS over the dead x tile ----------------
