@@ -29,6 +29,7 @@ EXPORTS = [
     "dsd_token_encoder_create", "dsd_token_encode", "dsd_predict_dur", "dsd_cond_assemble", "dsd_set_lengths",
 ]
 POS_ROPE, POS_REL, POS_NONE, POS_SIN = 0, 1, 2, 3       # DSD_POS_*
+FFN_ACTS = {"gelu": 0, "relu": 1, "swish": 2, "swiglu": 3}    # DSD_FFN_* (TransformerFFNLayer, common_layers.py:126-136)
 EMBED_FLAGS = {"energy": 1, "breathiness": 2, "voicing": 4, "tension": 8, "key_shift": 16, "speed": 32}
 
 
@@ -42,7 +43,7 @@ class DsdEncoderConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("vocab_size", C.c_int32), ("hidden_size", C.c_int32),
                 ("enc_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_kernel_size", C.c_int32),
                 ("num_spk", C.c_int32), ("num_lang", C.c_int32), ("embed_flags", C.c_uint32), ("pos_mode", C.c_int32),
-                ("device", C.c_int32)]
+                ("device", C.c_int32), ("ffn_act", C.c_int32)]
 
 
 class DsdVocoderConfig(C.Structure):
@@ -57,7 +58,8 @@ class DsdVocoderConfig(C.Structure):
 class DsdTokenEncoderConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("hidden_size", C.c_int32), ("enc_layers", C.c_int32), ("num_heads", C.c_int32),
                 ("ffn_kernel_size", C.c_int32), ("out_dims", C.c_int32), ("dur_layers", C.c_int32), ("dur_chans", C.c_int32),
-                ("dur_kernel_size", C.c_int32), ("dur_offset", C.c_float), ("pos_mode", C.c_int32), ("device", C.c_int32)]
+                ("dur_kernel_size", C.c_int32), ("dur_offset", C.c_float), ("pos_mode", C.c_int32), ("device", C.c_int32),
+                ("ffn_act", C.c_int32)]
 
 
 class _AssembleGather(C.Structure):
@@ -147,7 +149,7 @@ def _load():
     lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     for name in EXPORTS:
         getattr(lib, name)
-    if lib.dsd_api_version() != 8:
+    if lib.dsd_api_version() != 9:
         raise NativeLibraryError("libdsdenoise.so API version mismatch")
     return lib
 

@@ -101,6 +101,7 @@ struct dsd_handle {
     size_t e_lng = 0, e_lnb = 0, e_txt = 0, e_lang = SIZE_MAX, e_durw = 0, e_durb = 0, e_freqs = 0, e_spk = SIZE_MAX;
     size_t e_linw[7], e_linb[7];                     // pitch, energy, breathiness, voicing, tension, key shift, speed
     int eL = 0, eLs = 0, eB = 0, e_pos = 0;
+    int e_ffn_act = DSD_FFN_GELU;                    // TransformerFFNLayer's activation (DSD_FFN_*)
     float *e_x = nullptr, *e_y = nullptr, *e_qkv = nullptr, *e_mid = nullptr, *e_nonpad = nullptr;
     int* e_dur = nullptr;
     float* e_arena = nullptr;
@@ -290,7 +291,8 @@ inline bool lin_present(const dsd_encoder_config& e, int k) {
 
 // FastSpeech2Encoder state_dict (tts_modules.py:353-383; common_layers.py:120-234)
 void expected_fs2_layers(std::vector<std::pair<std::string, std::vector<int64_t>>>& v, int64_t H, int layers, int heads,
-                         int64_t ks, int pos_mode) {
+                         int64_t ks, int pos_mode, int ffn_act) {
+    const int64_t F1 = (ffn_act == DSD_FFN_SWIGLU ? 8 : 4) * H;       // SwiGLU: filter_size * 2 (common_layers.py:134)
     auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
     if (pos_mode == DSD_POS_REL) add("encoder.embed_positions.div_term", {H / 2});
     if (pos_mode == DSD_POS_SIN) add("encoder.embed_positions.freqs", {H / 2});
@@ -307,8 +309,8 @@ void expected_fs2_layers(std::vector<std::pair<std::string, std::vector<int64_t>
         add(p + "self_attn.out_proj.weight", {H, H});
         add(p + "layer_norm2.weight", {H});
         add(p + "layer_norm2.bias", {H});
-        add(p + "ffn.ffn_1.weight", {4 * H, H, ks});
-        add(p + "ffn.ffn_1.bias", {4 * H});
+        add(p + "ffn.ffn_1.weight", {F1, H, ks});
+        add(p + "ffn.ffn_1.bias", {F1});
         add(p + "ffn.ffn_2.weight", {H, 4 * H});
         add(p + "ffn.ffn_2.bias", {H});
     }
@@ -322,7 +324,7 @@ std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_tok(co
     std::vector<std::pair<std::string, std::vector<int64_t>>> v;
     const int64_t H = t.hidden_size;
     auto add = [&](const std::string& n, std::vector<int64_t> s) { v.emplace_back(n, std::move(s)); };
-    expected_fs2_layers(v, H, t.enc_layers, t.num_heads, t.ffn_kernel_size, t.pos_mode);
+    expected_fs2_layers(v, H, t.enc_layers, t.num_heads, t.ffn_kernel_size, t.pos_mode, t.ffn_act);
     if (t.out_dims > 0) {
         add("out_proj.weight", {t.out_dims, H});
         add("out_proj.bias", {t.out_dims});
@@ -350,7 +352,7 @@ std::vector<std::pair<std::string, std::vector<int64_t>>> expected_params_enc(co
     if (e.num_lang > 0) add("lang_embed.weight", {e.num_lang + 1, H});
     add("dur_embed.weight", {H, 1});
     add("dur_embed.bias", {H});
-    expected_fs2_layers(v, H, e.enc_layers, e.num_heads, ks, e.pos_mode);
+    expected_fs2_layers(v, H, e.enc_layers, e.num_heads, ks, e.pos_mode, e.ffn_act);
     for (int k = 0; k < 7; ++k)
         if (lin_present(e, k)) {
             add(std::string(kLinNames[k]) + ".weight", {H, 1});
@@ -641,7 +643,7 @@ void pack_fs2_layers(dsd_handle* h, int H, int L, int ks, int pos_mode) {
         const float fs = (float)fscale;
         WGet w1f = [w1, H, ks, fs](int r, int k, int tap) { return (double)(w1->data[((size_t)r * H + k) * ks + tap] * fs); };
         std::function<double(int)> b1f = [b1, fs](int i) { return (double)(b1->data[i] * fs); };
-        h->g_ffn1[l] = pack_gemm(h, 4 * H, H, ks, 0, w1f, &b1f);
+        h->g_ffn1[l] = pack_gemm(h, (h->e_ffn_act == DSD_FFN_SWIGLU ? 8 : 4) * H, H, ks, 0, w1f, &b1f);
         const HostTensor* b2 = &W(h, p + "ffn.ffn_2.bias");
         std::function<double(int)> b2f = [b2](int i) { return (double)b2->data[i]; };
         h->g_ffn2[l] = pack_gemm(h, H, 4 * H, 1, 0, lin(p + "ffn.ffn_2.weight", 4 * H), &b2f);
@@ -1606,6 +1608,7 @@ int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out) {
         return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: enc_ffn_kernel_size must be odd and <= 15");
     if (cfg->num_spk < 0 || cfg->num_lang < 0) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: negative table size");
     if (cfg->pos_mode < DSD_POS_ROPE || cfg->pos_mode > DSD_POS_SIN) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: pos_mode must be one of DSD_POS_*");
+    if (cfg->ffn_act < DSD_FFN_GELU || cfg->ffn_act > DSD_FFN_SWIGLU) return fail(nullptr, DSD_EINVAL, "dsd_encoder_create: ffn_act must be one of DSD_FFN_*");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, DSD_EHIP, "dsd_encoder_create: no HIP device is visible (this library has no CPU path)");
@@ -1626,6 +1629,7 @@ int dsd_encoder_create(const dsd_encoder_config* cfg, dsd_handle** out) {
     h->cfg.kernel_size = cfg->ffn_kernel_size;
     h->cfg.device = cfg->device;
     h->ecfg = *cfg;
+    h->e_ffn_act = cfg->ffn_act;
     *out = h;
     return DSD_OK;
 }
@@ -1642,7 +1646,8 @@ static int enc_workspace(dsd_handle* h, int B, int L, int H, int Cd, hipStream_t
         off += (n + 63) / 64 * 64 + 64;
         return o;
     };
-    const size_t o_x = take(per * H), o_y = take(per * H), o_qkv = take(per * 3 * H), o_mid = take(per * 4 * H);
+    const size_t o_x = take(per * H), o_y = take(per * H), o_qkv = take(per * 3 * H),
+                 o_mid = take(per * (h->e_ffn_act == DSD_FFN_SWIGLU ? 8 : 4) * H);
     const size_t o_np = take(per), o_dur = take((size_t)B * L);
     const size_t o_da = take(per * Cd), o_db = take(per * Cd), o_di = take(Cd > 0 ? per * H : 0);
     off += kGuard;
@@ -1688,11 +1693,16 @@ static int run_fs2_layers(dsd_handle* h, int H, int NL, int heads, int ffn_ks, i
         ENC_OK(launch_enc_mask(h->e_x, h->e_nonpad, H, B, L, Ls, st), "mask");
         ENC_OK(launch_enc_layernorm(h->e_x, h->e_y, blob + h->e_ln2g[l], blob + h->e_ln2b[l], nullptr, H, B, L, Ls, 1e-5f, st),
                "layer_norm2");
-        // TransformerFFNLayer (common_layers.py:142-151): Conv1d(H, 4H, k) * k^-0.5 -> GELU -> Linear(4H, H)
+        // TransformerFFNLayer (common_layers.py:142-151): Conv1d(H, 4H, k) * k^-0.5 -> GELU | ReLU | SiLU -> Linear(4H, H);
+        // SwiGLU: Conv1d(H, 8H, k), then rows [0, 4H) *= silu(rows [4H, 8H)) in place (common_layers.py:107-117)
+        const int fa = h->e_ffn_act;
+        const long ms = (fa == DSD_FFN_SWIGLU ? 8 : 4) * xs;
         GemmCall f1 = make_gemm(h, h->g_ffn1[l], h->e_y, xs, Ls, B, L, ST_PLAIN, EP_BIAS_ACT, 1, ffn_ks > 1);
-        f1.p.act = ACT_GELU; f1.p.out = h->e_mid; f1.p.o_bstride = 4 * xs; f1.p.o_rstride = Ls;
+        f1.p.act = fa == DSD_FFN_GELU ? ACT_GELU : fa == DSD_FFN_RELU ? ACT_RELU : fa == DSD_FFN_SWISH ? ACT_SILU : ACT_NONE;
+        f1.p.out = h->e_mid; f1.p.o_bstride = ms; f1.p.o_rstride = Ls;
         if ((rc = run_gemm(h, f1, st))) return rc;
-        GemmCall f2 = make_gemm(h, h->g_ffn2[l], h->e_mid, 4 * xs, Ls, B, L, ST_PLAIN, EP_BIAS_RES, 0);
+        if (fa == DSD_FFN_SWIGLU) ENC_OK(launch_enc_swiglu(h->e_mid, 4 * H, ms, B, L, Ls, st), "swiglu");
+        GemmCall f2 = make_gemm(h, h->g_ffn2[l], h->e_mid, ms, Ls, B, L, ST_PLAIN, EP_BIAS_RES, 0);
         f2.p.aux = h->e_x; f2.p.aux_bstride = xs; f2.p.aux_rstride = Ls;
         f2.p.out = h->e_x; f2.p.o_bstride = xs; f2.p.o_rstride = Ls;
         if ((rc = run_gemm(h, f2, st))) return rc;
@@ -1783,6 +1793,8 @@ int dsd_token_encoder_create(const dsd_token_encoder_config* cfg, dsd_handle** o
     if (cfg->dur_layers > 0 && (cfg->dur_chans < 1 || cfg->dur_kernel_size < 1 || cfg->dur_kernel_size % 2 == 0 ||
                                 cfg->dur_kernel_size > 15))
         return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: duration predictor needs channels >= 1 and an odd kernel size <= 15");
+    if (cfg->ffn_act < DSD_FFN_GELU || cfg->ffn_act > DSD_FFN_SWIGLU)
+        return fail(nullptr, DSD_EINVAL, "dsd_token_encoder_create: ffn_act must be one of DSD_FFN_*");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, DSD_EHIP, "dsd_token_encoder_create: no HIP device is visible (this library has no CPU path)");
@@ -1803,6 +1815,7 @@ int dsd_token_encoder_create(const dsd_token_encoder_config* cfg, dsd_handle** o
     h->cfg.kernel_size = cfg->ffn_kernel_size;
     h->cfg.device = cfg->device;
     h->tcfg = *cfg;
+    h->e_ffn_act = cfg->ffn_act;
     *out = h;
     return DSD_OK;
 }

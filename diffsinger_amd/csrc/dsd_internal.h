@@ -18,7 +18,7 @@ static inline int padded_ts(int T) { return round_up(T, 64) + 32; }
 
 enum Stage { ST_PLAIN = 0, ST_FILM = 1, ST_LN = 2, ST_SCALE = 3, ST_LRELU = 4 };
 enum Epi { EP_BIAS_ACT = 0, EP_GATE = 1, EP_RESSKIP = 2, EP_LINCOMB = 3, EP_SWIGLU = 4, EP_BIAS_RES = 5, EP_SCATTER = 6, EP_LYNX_NEXT = 7 };
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3, ACT_LRELU = 4, ACT_TANH = 5 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3, ACT_LRELU = 4, ACT_TANH = 5, ACT_SILU = 6 };
 
 constexpr int kMaxTerms = 8;
 constexpr int kMaxOut = 3;
@@ -259,6 +259,8 @@ hipError_t launch_enc_embed(const long long* tokens, const long long* langs, con
 hipError_t launch_enc_layernorm(const float* x, float* y, const float* g, const float* beta, const float* mask, int C,
                                 int B, int L, int Ls, float eps, hipStream_t st);
 hipError_t launch_enc_mask(float* x, const float* mask, int C, int B, int L, int Ls, hipStream_t st);
+// SwiGLU between ffn_1 and ffn_2: x[b][c][l] *= silu(x[b][half + c][l]) for c < half (common_layers.py:107-117)
+hipError_t launch_enc_swiglu(float* x, int half, long bstride, int B, int L, int Ls, hipStream_t st);
 hipError_t launch_enc_rope(float* qkv, const float* freqs, int H, int head_dim, int B, int L, int Ls, hipStream_t st);
 hipError_t launch_enc_attention(const float* qkv, const float* nonpad, float* out, int H, int heads, int B, int L, int Ls,
                                 hipStream_t st);

@@ -137,6 +137,17 @@ __global__ void enc_mask_kernel(float* __restrict__ x, const float* __restrict__
     x[((long)b * C + c) * Ls + l] *= mask[(long)b * Ls + l];
 }
 
+// SwiGLU of TransformerFFNLayer (common_layers.py:107-117, 134): ffn_1 produced 2 * half rows; out = rows [0, half),
+// gate = rows [half, 2 half); x[b][c][l] = out * silu(gate), in place on the first half (ffn_2 reads those rows)
+__global__ void enc_swiglu_kernel(float* __restrict__ x, int half, long bstride, int L, int Ls) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    float* o = x + (long)b * bstride + (long)c * Ls + l;
+    const float g = o[(long)half * Ls];
+    *o = *o * (g / (1.f + expf(-g)));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Rotary embedding on the Q and K thirds of qkv[b][3H][Ls], in place (rotary_embedding_torch.py:35-75,174-188):
 // head-local channel pairs (2i, 2i+1) at position l are rotated by angle l * freqs[i]:
@@ -413,6 +424,11 @@ hipError_t launch_enc_layernorm(const float* x, float* y, const float* g, const 
 
 hipError_t launch_enc_mask(float* x, const float* mask, int C, int B, int L, int Ls, hipStream_t st) {
     hipLaunchKernelGGL(enc_mask_kernel, dim3((L + 63) / 64, C, B), dim3(64), 0, st, x, mask, C, L, Ls);
+    return hipGetLastError();
+}
+
+hipError_t launch_enc_swiglu(float* x, int half, long bstride, int B, int L, int Ls, hipStream_t st) {
+    hipLaunchKernelGGL(enc_swiglu_kernel, dim3((L + 63) / 64, half, B), dim3(64), 0, st, x, half, bstride, L, Ls);
     return hipGetLastError();
 }
 

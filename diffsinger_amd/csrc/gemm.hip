@@ -42,6 +42,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
         case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // exact GELU (lynxnet.py:106)
         case ACT_LRELU: return v >= 0.f ? v : v * 0.1f;                 // LRELU_SLOPE (nsf_hifigan/models.py:15)
         case ACT_TANH: return tanhf(v);
+        case ACT_SILU: return v / (1.f + expf(-v));                     // nn.SiLU ('swish', common_layers.py:130)
         default: return v;
     }
 }

@@ -64,6 +64,14 @@ def pos_mode_of(get):
     return _lib.POS_REL if get('rel_pos') else _lib.POS_SIN
 
 
+def ffn_act_of(get):
+    """DSD_FFN_* from `ffn_act`; the reference's error for anything else (common_layers.py:135-136)."""
+    act = get('ffn_act') or 'gelu'
+    if act not in _lib.FFN_ACTS:
+        raise ValueError(f'{act} is not a valid activation')
+    return _lib.FFN_ACTS[act]
+
+
 def rel_pos_div_term(h):
     """RelPositionalEncoding's frequency table, with the reference's own torch ops (espnet_positional_embedding.py:38-41)."""
     return torch.exp(torch.arange(0, h, 2, dtype=torch.float32) * -(math.log(10000.0) / h))
@@ -92,34 +100,35 @@ class _SinPos(nn.Module):
 
 
 class _FFN(nn.Module):
-    def __init__(self, h, ks):
+    def __init__(self, h, ks, ffn_act=0):
         super().__init__()
-        self.ffn_1 = nn.Conv1d(h, 4 * h, ks, padding=ks // 2)
+        # SwiGLU: ffn_1 produces out and gate, 2 * filter_size channels (common_layers.py:132-134)
+        self.ffn_1 = nn.Conv1d(h, (8 if ffn_act == _lib.FFN_ACTS["swiglu"] else 4) * h, ks, padding=ks // 2)
         self.ffn_2 = nn.Linear(4 * h, h)
 
 
 class _EncSALayer(nn.Module):
-    def __init__(self, h, ks, rotary):
+    def __init__(self, h, ks, rotary, ffn_act=0):
         super().__init__()
         self.layer_norm1 = nn.LayerNorm(h)
         self.self_attn = _SelfAttn(h, rotary) if rotary is not None else _SelfAttnPlain(h)
         self.layer_norm2 = nn.LayerNorm(h)
-        self.ffn = _FFN(h, ks)
+        self.ffn = _FFN(h, ks, ffn_act)
 
 
 class _Layer(nn.Module):
-    def __init__(self, h, ks, rotary):
+    def __init__(self, h, ks, rotary, ffn_act=0):
         super().__init__()
-        self.op = _EncSALayer(h, ks, rotary)
+        self.op = _EncSALayer(h, ks, rotary, ffn_act)
 
 
 class _Encoder(nn.Module):
     """Parameter holder with the names of FastSpeech2Encoder (tts_modules.py:353-383); never called."""
 
-    def __init__(self, h, layers, heads, ks, pos_mode=0):
+    def __init__(self, h, layers, heads, ks, pos_mode=0, ffn_act=0):
         super().__init__()
         rotary = _Rotary(h // heads) if pos_mode == _lib.POS_ROPE else None
-        self.layers = nn.ModuleList([_Layer(h, ks, rotary) for _ in range(layers)])
+        self.layers = nn.ModuleList([_Layer(h, ks, rotary, ffn_act) for _ in range(layers)])
         self.layer_norm = nn.LayerNorm(h)
         if pos_mode == _lib.POS_SIN:
             self.embed_positions = _SinPos()
@@ -130,8 +139,7 @@ class FastSpeech2Acoustic(_NativeBackbone):
         super().__init__()
         hp = hparams
         self.pos_mode = pos_mode_of(hp.get)
-        if hp.get('ffn_act', 'gelu') != 'gelu':
-            raise NotImplementedError(f"ffn_act={hp.get('ffn_act')!r}: only 'gelu' (configs/base.yaml:32) runs on the HIP path")
+        self.ffn_act = ffn_act_of(hp.get)
         h = self._hidden = hp['hidden_size']
         self.vocab_size = vocab_size
         self.enc_layers, self.num_heads = hp['enc_layers'], hp['num_heads']
@@ -141,7 +149,7 @@ class FastSpeech2Acoustic(_NativeBackbone):
         if self.use_lang_id:
             self.lang_embed = nn.Embedding(hp['num_lang'] + 1, h, padding_idx=0)
         self.dur_embed = nn.Linear(1, h)
-        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size, self.pos_mode)
+        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size, self.pos_mode, self.ffn_act)
         self.pitch_embed = nn.Linear(1, h)
         self.variance_embed_list = [v for v in VARIANCE_ORDER if hp.get(f'use_{v}_embed', False)]
         self.use_variance_embeds = len(self.variance_embed_list) > 0
@@ -165,7 +173,7 @@ class FastSpeech2Acoustic(_NativeBackbone):
         flags |= _lib.EMBED_FLAGS["speed"] if self.use_speed_embed else 0
         return _lib.DsdEncoderConfig(C.sizeof(_lib.DsdEncoderConfig), self.vocab_size, self._hidden, self.enc_layers,
                                      self.num_heads, self.ffn_kernel_size, self.num_spk, self.num_lang, flags,
-                                     self.pos_mode, device_index)
+                                     self.pos_mode, device_index, self.ffn_act)
 
     def _extra_weights(self):
         return positional_extra_weights(self.pos_mode, self._hidden)

@@ -103,7 +103,8 @@ def convnext_param_shapes(in_dims, out_dims, num_channels=512, num_layers=6, ker
 
 
 def fs2_acoustic_param_shapes(vocab_size, hidden_size=256, enc_layers=4, num_heads=2, ffn_kernel_size=3,
-                              num_spk=0, num_lang=0, variances=(), key_shift=False, speed=False, rope=True, sinpos=False):
+                              num_spk=0, num_lang=0, variances=(), key_shift=False, speed=False, rope=True, sinpos=False,
+                              ffn_act="gelu"):
     """state_dict of modules/fastspeech/acoustic_encoder.py:14-63 (FastSpeech2Acoustic) in its rotary-embedding
     configuration (`use_rope: true`): tts_modules.py:353-383, common_layers.py:120-234.  The rotary frequency
     table is an (untrained) nn.Parameter of the shared RotaryEmbedding and shows up once per layer.  `rope=False`:
@@ -128,8 +129,9 @@ def fs2_acoustic_param_shapes(vocab_size, hidden_size=256, enc_layers=4, num_hea
             shapes[p + "self_attn.out_proj.weight"] = (h, h)
         shapes[p + "layer_norm2.weight"] = (h,)
         shapes[p + "layer_norm2.bias"] = (h,)
-        shapes[p + "ffn.ffn_1.weight"] = (4 * h, h, ffn_kernel_size)
-        shapes[p + "ffn.ffn_1.bias"] = (4 * h,)
+        f1 = (8 if ffn_act == "swiglu" else 4) * h          # SwiGLU: out and gate halves (common_layers.py:132-134)
+        shapes[p + "ffn.ffn_1.weight"] = (f1, h, ffn_kernel_size)
+        shapes[p + "ffn.ffn_1.bias"] = (f1,)
         shapes[p + "ffn.ffn_2.weight"] = (h, 4 * h)
         shapes[p + "ffn.ffn_2.bias"] = (h,)
     shapes["encoder.layer_norm.weight"] = (h,)

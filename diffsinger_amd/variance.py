@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import _lib
 from .backbones import _NativeBackbone
 from .diffusion import (MultiVarianceDiffusion, MultiVarianceRectifiedFlow, PitchDiffusion, PitchRectifiedFlow)
-from .encoder import PAD_INDEX, _Encoder, pos_mode_of, positional_extra_weights
+from .encoder import PAD_INDEX, _Encoder, ffn_act_of, pos_mode_of, positional_extra_weights
 from .harness import length_regulator
 from .hparams import hparams
 from .toplevel import get_backbone_args
@@ -97,10 +97,8 @@ def _check_infer(module):
 
 
 def _check_encoder_hparams(get):
-    """-> DSD_POS_*; raises for what the HIP path does not implement."""
-    if (get('ffn_act') or 'gelu') != 'gelu':
-        raise NotImplementedError(f"ffn_act={get('ffn_act')!r}: only 'gelu' (configs/base.yaml:32) runs on the HIP path")
-    return pos_mode_of(get)
+    """-> (DSD_POS_*, DSD_FFN_*) as FastSpeech2Encoder.__init__ reads them (tts_modules.py:353-384)."""
+    return pos_mode_of(get), ffn_act_of(get)
 
 
 class _TokenEncoderBase(_NativeBackbone):
@@ -153,7 +151,7 @@ class FastSpeech2Variance(_TokenEncoderBase):
     def __init__(self, vocab_size):
         super().__init__()
         hp = hparams
-        self.pos_mode = _check_encoder_hparams(hp.get)
+        self.pos_mode, self.ffn_act = _check_encoder_hparams(hp.get)
         h = self._hidden = hp['hidden_size']
         self.predict_dur = hp['predict_dur']
         self.linguistic_mode = 'word' if self.predict_dur else 'phoneme'
@@ -167,7 +165,7 @@ class FastSpeech2Variance(_TokenEncoderBase):
             self.word_dur_embed = nn.Linear(1, h)
         else:
             self.ph_dur_embed = nn.Linear(1, h)
-        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size, self.pos_mode)
+        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size, self.pos_mode, self.ffn_act)
         if self.predict_dur:
             d = hp['dur_prediction_args']
             self.midi_embed = nn.Embedding(128, h)
@@ -179,7 +177,8 @@ class FastSpeech2Variance(_TokenEncoderBase):
         d = self.dur_predictor if self.predict_dur else None
         return _lib.DsdTokenEncoderConfig(C.sizeof(_lib.DsdTokenEncoderConfig), self._hidden, self.enc_layers, self.num_heads,
                                           self.ffn_kernel_size, 0, d.n_layers if d else 0, d.n_chans if d else 0,
-                                          d.kernel_size if d else 0, float(d.offset) if d else 0.0, self.pos_mode, device_index)
+                                          d.kernel_size if d else 0, float(d.offset) if d else 0.0, self.pos_mode, device_index,
+                                          self.ffn_act)
 
     def forward(self, txt_tokens, midi, ph2word, ph_dur=None, word_dur=None, spk_embed=None, languages=None, infer=True):
         """-> encoder_out [B, T_ph, H], ph_dur_pred [B, T_ph] or None (variance_encoder.py:52-99)."""
@@ -231,7 +230,7 @@ class MelodyEncoder(_TokenEncoderBase):
         def get(key):
             return enc_hparams.get(key, hparams.get(key))
 
-        self.pos_mode = _check_encoder_hparams(get)
+        self.pos_mode, self.ffn_act = _check_encoder_hparams(get)
         h = self._hidden = get('hidden_size')
         self.enc_layers, self.num_heads, self.ffn_kernel_size = get('enc_layers'), get('num_heads'), get('enc_ffn_kernel_size')
         self.note_midi_embed = nn.Linear(1, h)
@@ -240,13 +239,13 @@ class MelodyEncoder(_TokenEncoderBase):
         self.glide_embed_scale = hparams['glide_embed_scale']
         if self.use_glide_embed:
             self.note_glide_embed = nn.Embedding(len(hparams['glide_types']) + 1, h, padding_idx=0)      # 0: none, 1: up, 2: down
-        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size, self.pos_mode)
+        self.encoder = _Encoder(h, self.enc_layers, self.num_heads, self.ffn_kernel_size, self.pos_mode, self.ffn_act)
         self.out_dims = hparams['hidden_size']
         self.out_proj = nn.Linear(h, self.out_dims)
 
     def _config(self, device_index):
         return _lib.DsdTokenEncoderConfig(C.sizeof(_lib.DsdTokenEncoderConfig), self._hidden, self.enc_layers, self.num_heads,
-                                          self.ffn_kernel_size, self.out_dims, 0, 0, 0, 0.0, self.pos_mode, device_index)
+                                          self.ffn_kernel_size, self.out_dims, 0, 0, 0, 0.0, self.pos_mode, device_index, self.ffn_act)
 
     def forward(self, note_midi, note_rest, note_dur, glide=None):
         """note_midi float [B, T_n] (-1: padding), note_rest bool, note_dur int64, glide int64 -> [B, T_n, H]."""

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSD_API_VERSION 8
+#define DSD_API_VERSION 9
 
 /* error codes */
 #define DSD_OK 0
@@ -162,6 +162,11 @@ enum { DSD_POS_ROPE = 0,   /* use_pos_embed && use_rope: rotary embedding inside
                               exp(arange(H/2) * -(ln 10000 / (H/2 - 1))); the checkpoint's `encoder.embed_positions._float_tensor`
                               buffer is accepted and ignored */
 
+/* TransformerFFNLayer's activation between ffn_1 and ffn_2 (common_layers.py:126-136): GELU (exact erf), ReLU, SiLU
+   ('swish'), or SwiGLU - ffn_1 then has 2 * 4H output channels, `out * silu(gate)` with out = the first half
+   (common_layers.py:107-117) */
+enum { DSD_FFN_GELU = 0, DSD_FFN_RELU = 1, DSD_FFN_SWISH = 2, DSD_FFN_SWIGLU = 3 };
+
 typedef struct dsd_encoder_config {
     int32_t struct_size;      /* sizeof(dsd_encoder_config)                                          */
     int32_t vocab_size;       /* FastSpeech2Acoustic(vocab_size)                                     */
@@ -174,6 +179,7 @@ typedef struct dsd_encoder_config {
     uint32_t embed_flags;     /* DSD_EMBED_*: use_energy_embed ... use_speed_embed                   */
     int32_t pos_mode;         /* DSD_POS_*                                                           */
     int32_t device;
+    int32_t ffn_act;          /* DSD_FFN_*: hparams['ffn_act'] (TransformerFFNLayer, common_layers.py:120-151) */
 } dsd_encoder_config;
 
 /* Optional inputs of FastSpeech2Acoustic.forward (acoustic_encoder.py:82-88); NULL = not given.  All device pointers. */
@@ -224,6 +230,7 @@ typedef struct dsd_token_encoder_config {
     float dur_offset;         /* dur_prediction_args.log_offset                                       */
     int32_t pos_mode;         /* DSD_POS_*                                                            */
     int32_t device;
+    int32_t ffn_act;          /* DSD_FFN_*                                                            */
 } dsd_token_encoder_config;
 
 int dsd_token_encoder_create(const dsd_token_encoder_config* cfg, dsd_handle** out);

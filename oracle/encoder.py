@@ -89,8 +89,9 @@ def self_attention_rope(x, p, pre, num_heads, pad_mask, freqs=None):
     return (out @ p[pre + "out_proj.weight"].T).astype(F32)
 
 
-def ffn(x, p, pre):
-    w1, b1 = p[pre + "ffn_1.weight"], p[pre + "ffn_1.bias"]          # [4H, H, k]
+def ffn(x, p, pre, act="gelu"):
+    """TransformerFFNLayer.forward (common_layers.py:141-151); act: 'gelu' | 'relu' | 'swish' | 'swiglu' (:126-136)."""
+    w1, b1 = p[pre + "ffn_1.weight"], p[pre + "ffn_1.bias"]          # [4H, H, k]; SwiGLU: [8H, H, k]
     ks = w1.shape[2]
     pad = ks // 2
     bsz, seq, dim = x.shape
@@ -100,11 +101,22 @@ def ffn(x, p, pre):
     for j in range(ks):
         y += xp[:, j:j + seq] @ np.ascontiguousarray(w1[:, :, j]).T
     y = ((y + b1) * F32(ks ** -0.5)).astype(F32)
-    y = _gelu(y)
+    silu = lambda v: (v / (F32(1) + np.exp(-v, dtype=F32))).astype(F32)      # noqa: E731
+    if act == "gelu":
+        y = _gelu(y)
+    elif act == "relu":
+        y = np.maximum(y, F32(0))
+    elif act == "swish":
+        y = silu(y)
+    elif act == "swiglu":                    # out, gate = split in halves; out * silu(gate)  (common_layers.py:107-117)
+        half = y.shape[-1] // 2
+        y = (y[..., :half] * silu(y[..., half:])).astype(F32)
+    else:
+        raise ValueError(f"{act} is not a valid activation")
     return (y @ p[pre + "ffn_2.weight"].T + p[pre + "ffn_2.bias"]).astype(F32)
 
 
-def fs2_encoder(p, main_embed, extra_embed, pad_mask, num_heads, prefix="encoder.", pos="rope"):
+def fs2_encoder(p, main_embed, extra_embed, pad_mask, num_heads, prefix="encoder.", pos="rope", ffn_act="gelu"):
     """pos: 'rope' (rotation inside the attention), 'rel' (use_rope false, rel_pos true: x * sqrt(H) + table), 'sin'
     (rel_pos false: x + sinusoidal table of the non-padding positions), 'none'."""
     hidden = main_embed.shape[-1]
@@ -126,7 +138,7 @@ def fs2_encoder(p, main_embed, extra_embed, pad_mask, num_heads, prefix="encoder
         x = ((res + y) * nonpad).astype(F32)
         res = x
         y = _ln(x, p[pre + "layer_norm2.weight"], p[pre + "layer_norm2.bias"])
-        y = ffn(y, p, pre + "ffn.")
+        y = ffn(y, p, pre + "ffn.", ffn_act)
         x = ((res + y) * nonpad).astype(F32)
         l += 1
     return (_ln(x, p[prefix + "layer_norm.weight"], p[prefix + "layer_norm.bias"]) * nonpad).astype(F32)
@@ -138,7 +150,7 @@ def _lin1(v, p, name):
 
 
 def fs2_acoustic_forward(p, txt_tokens, mel2ph, f0, num_heads=2, key_shift=None, speed=None, spk_embed_id=None,
-                         languages=None, spk_mix_embed=None, pos="rope", **variances):
+                         languages=None, spk_mix_embed=None, pos="rope", ffn_act="gelu", **variances):
     """-> condition [B, T, H]."""
     txt_tokens, mel2ph = np.asarray(txt_tokens), np.asarray(mel2ph)
     txt_embed = p["txt_embed.weight"][txt_tokens]
@@ -146,7 +158,7 @@ def fs2_acoustic_forward(p, txt_tokens, mel2ph, f0, num_heads=2, key_shift=None,
     extra = _lin1(dur, p, "dur_embed")
     if "lang_embed.weight" in p:
         extra = (extra + p["lang_embed.weight"][np.asarray(languages)]).astype(F32)
-    enc = fs2_encoder(p, txt_embed, extra, txt_tokens == 0, num_heads, pos=pos)
+    enc = fs2_encoder(p, txt_embed, extra, txt_tokens == 0, num_heads, pos=pos, ffn_act=ffn_act)
     enc = np.concatenate([np.zeros_like(enc[:, :1]), enc], axis=1)
     cond = np.take_along_axis(enc, mel2ph[:, :, None].repeat(enc.shape[-1], axis=2), axis=1).astype(F32)
     if "spk_embed.weight" in p:

@@ -81,7 +81,8 @@ def fs2_variance_forward(p, hp, txt_tokens, midi, ph2word, ph_dur=None, word_dur
         extra = _lin1(np.asarray(ph_dur).astype(F32), p, "ph_dur_embed")
     if hp.get("use_lang_id"):
         extra = (extra + p["lang_embed.weight"][np.asarray(languages)]).astype(F32)
-    enc = fs2_encoder(p, txt_embed, extra, txt_tokens == 0, hp["num_heads"], pos=pos_mode(hp.get))
+    enc = fs2_encoder(p, txt_embed, extra, txt_tokens == 0, hp["num_heads"], pos=pos_mode(hp.get),
+                      ffn_act=hp.get("ffn_act") or "gelu")
     if not hp["predict_dur"]:
         return enc, None
     dur_cond = (enc + p["midi_embed.weight"][np.asarray(midi)]).astype(F32)
@@ -101,7 +102,7 @@ def melody_encoder(p, hp, note_midi, note_rest, note_dur, glide=None):
     if hp.get("use_glide_embed"):
         extra = (extra + p["note_glide_embed.weight"][np.asarray(glide)] * F32(hp["glide_embed_scale"])).astype(F32)
     enc = fs2_encoder(p, midi_embed, extra, note_midi < 0, args.get("num_heads", hp["num_heads"]),
-                      pos=pos_mode(lambda k: args.get(k, hp.get(k))))
+                      pos=pos_mode(lambda k: args.get(k, hp.get(k))), ffn_act=args.get("ffn_act", hp.get("ffn_act")) or "gelu")
     return (enc @ p["out_proj.weight"].T + p["out_proj.bias"]).astype(F32)
 
 

@@ -509,6 +509,11 @@ ENC_CASES = {
     "relpos": (40, dict(use_rope=False, rel_pos=True, enc_layers=2), dict(enc_layers=2, rope=False), 3, 15, 64, 84),
     "nopos": (40, dict(use_rope=False, use_pos_embed=False, enc_layers=2), dict(enc_layers=2, rope=False), 2, 11, 50, 85),
     "sinpos": (40, dict(use_rope=False, rel_pos=False, enc_layers=2), dict(enc_layers=2, rope=False, sinpos=True), 3, 13, 56, 86),
+    # the other feed-forward activations of TransformerFFNLayer (common_layers.py:126-136); SwiGLU doubles ffn_1
+    "relu": (40, dict(ffn_act="relu", enc_layers=2), dict(enc_layers=2), 2, 12, 48, 87),
+    "swish": (40, dict(ffn_act="swish", enc_layers=2), dict(enc_layers=2), 2, 12, 48, 88),
+    "swiglu": (40, dict(ffn_act="swiglu", enc_layers=2, enc_ffn_kernel_size=5), dict(enc_layers=2, ffn_kernel_size=5,
+                                                                                 ffn_act="swiglu"), 2, 14, 52, 89),
 }
 
 

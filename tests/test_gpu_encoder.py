@@ -28,6 +28,10 @@ CASES = {
     "relpos": (dict(use_rope=False, rel_pos=True, enc_layers=2), dict(rope=False)),
     "nopos": (dict(use_rope=False, use_pos_embed=False, enc_layers=2), dict(rope=False)),
     "sinpos": (dict(use_rope=False, rel_pos=False, enc_layers=2), dict(rope=False, sinpos=True)),
+    # TransformerFFNLayer's other activations (common_layers.py:126-136)
+    "relu": (dict(ffn_act="relu", enc_layers=2), dict()),
+    "swish": (dict(ffn_act="swish", enc_layers=2), dict()),
+    "swiglu": (dict(ffn_act="swiglu", enc_layers=2, enc_ffn_kernel_size=5), dict(ffn_act="swiglu")),
 }
 
 
@@ -119,8 +123,8 @@ def test_encoder_spk_mix_and_errors():
         m(tokens, mel2ph, f0, spk_embed_id=dev(g["full_spk_embed_id"]), **base)
     m.release_native()
     from diffsinger_amd.encoder import FastSpeech2Acoustic
-    set_hp(**dict(ENC_HP, ffn_act="swiglu"))
-    with pytest.raises(NotImplementedError):
+    set_hp(**dict(ENC_HP, ffn_act="tanh"))
+    with pytest.raises(ValueError, match="not a valid activation"):      # the reference's error (common_layers.py:135-136)
         FastSpeech2Acoustic(10)
 
 

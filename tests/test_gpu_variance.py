@@ -131,6 +131,53 @@ def test_melody_encoder_vs_oracle():
     model.melody_encoder.release_native()
 
 
+@pytest.mark.parametrize("act", ("relu", "swish", "swiglu"))
+def test_token_encoders_other_ffn_activations_vs_oracle(act):
+    """`ffn_act` other than gelu (TransformerFFNLayer, common_layers.py:126-136) through the variance model's two token
+    encoders - FastSpeech2Variance with its duration predictor and the MelodyEncoder (whose own `melody_encoder_args` may
+    override it) - against the oracle, whose activations are pinned by the G8 fixtures `relu` / `swish` / `swiglu`."""
+    from diffsinger_amd.variance import DiffSingerVariance
+    tag = "melody_ddim"
+    hp = vc.case_hparams(tag)
+    hp.update(ffn_act=act, predict_dur=True)
+    hp["melody_encoder_args"] = dict(hp["melody_encoder_args"], ffn_act="swiglu" if act == "relu" else act)
+    hparams.clear()
+    hparams.update(hp, infer=True)
+    c = vc.CASES[tag]
+    model = DiffSingerVariance(c["vocab"])
+    shapes = vc.sorted_param_shapes(model.named_parameters())
+    params = vc.synth_weights(shapes, c["seed"] + 1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    model = model.cuda().eval()
+    f1 = params["fs2.encoder.layers.0.op.ffn.ffn_1.weight"].shape[0]
+    assert f1 == (8 if act == "swiglu" else 4) * hp["hidden_size"]
+    inp = vc.case_inputs(tag)
+    want = ovar.melody_encoder(ovar.sub(params, "melody_encoder."), hp, inp["note_midi"], inp["note_rest"], inp["note_dur"],
+                               glide=inp["note_glide"])
+    with torch.no_grad():
+        got = model.melody_encoder(dev(inp["note_midi"]), dev(inp["note_rest"]), dev(inp["note_dur"]), glide=dev(inp["note_glide"]))
+    keep = (inp["note_midi"] >= 0)[:, :, None]
+    assert np.abs((got.cpu().numpy() - want) * keep).max() < 2e-4 * np.abs(want).max()
+    rng = np.random.Generator(np.random.PCG64(17))
+    bsz, n_ph = 2, 40
+    tokens = rng.integers(1, c["vocab"], (bsz, n_ph)).astype(np.int64)
+    tokens[1, 29:] = 0
+    ph2word = np.zeros((bsz, n_ph), np.int64)
+    for b, n in enumerate((40, 29)):
+        ph2word[b, :n] = np.cumsum(rng.random(n) < 0.4) + 1
+    midi = rng.integers(30, 90, (bsz, n_ph)).astype(np.int64)
+    word_dur = rng.integers(1, 40, (bsz, int(ph2word.max()))).astype(np.int64)
+    languages = rng.integers(1, 3, (bsz, n_ph)).astype(np.int64) * (tokens > 0)
+    want_enc, want_dur = ovar.fs2_variance_forward(ovar.sub(params, "fs2."), hp, tokens, midi, ph2word, word_dur=word_dur,
+                                                   languages=languages)
+    with torch.no_grad():
+        enc, dur = model.fs2(dev(tokens), midi=dev(midi), ph2word=dev(ph2word), word_dur=dev(word_dur), languages=dev(languages))
+    assert np.abs(enc.cpu().numpy() - want_enc).max() < 2e-4 * np.abs(want_enc).max()
+    assert np.abs(dur.cpu().numpy() - want_dur).max() < 2e-4 * max(1.0, np.abs(want_dur).max())
+    model.fs2.release_native()
+    model.melody_encoder.release_native()
+
+
 def test_cond_assemble_matches_torch_and_rejects_bad_arguments():
     from diffsinger_amd import _lib
     from diffsinger_amd.variance import assemble

@@ -353,8 +353,10 @@ ENC_SYNTH = {
     "full": dict(num_spk=3, num_lang=2, variances=("energy", "breathiness"), key_shift=True, speed=True),
     "k9": dict(),
     "relpos": dict(rope=False), "nopos": dict(rope=False), "sinpos": dict(rope=False, sinpos=True),
+    "relu": dict(), "swish": dict(), "swiglu": dict(ffn_act="swiglu"),
 }
 ENC_POS = {"relpos": "rel", "nopos": "none", "sinpos": "sin"}
+ENC_ACT = {"relu": "relu", "swish": "swish", "swiglu": "swiglu"}        # ffn_act: gelu unless listed
 
 
 def enc_case(g, tag):
@@ -373,7 +375,8 @@ def test_g8_fs2_acoustic_encoder(tag):
     (4 transformer layers: LayerNorm, RoPE attention, k-tap FFN; padded batches; every optional embedding)."""
     g = load("g8_encoder")
     params, heads, tokens, mel2ph, f0, extra = enc_case(g, tag)
-    cond = oe.fs2_acoustic_forward(params, tokens, mel2ph, f0, num_heads=heads, pos=ENC_POS.get(tag, "rope"), **extra)
+    cond = oe.fs2_acoustic_forward(params, tokens, mel2ph, f0, num_heads=heads, pos=ENC_POS.get(tag, "rope"),
+                                   ffn_act=ENC_ACT.get(tag, "gelu"), **extra)
     want = g[f"{tag}_cond"]
     if tag in ("default", "padded", "relpos", "nopos", "sinpos"):
         cond = cond[:, ::2]

@@ -41,8 +41,8 @@ def test_unsupported_configurations_raise():
     from diffsinger_amd.variance import DiffSingerVariance
     hparams.clear()
     hparams.update(vc.case_hparams("dur_only"), infer=True)
-    hparams["ffn_act"] = "swiglu"
-    with pytest.raises(NotImplementedError, match="ffn_act"):
+    hparams["ffn_act"] = "tanh"
+    with pytest.raises(ValueError, match="not a valid activation"):      # the reference's error (common_layers.py:135-136)
         DiffSingerVariance(10)
     hparams["ffn_act"] = "gelu"
     hparams["diffusion_type"] = "flow"
