@@ -69,6 +69,10 @@ struct dsd_handle {
     dsd_config cfg;
     std::string err;
     std::map<std::string, HostTensor> raw;
+    // WaveNet with a channel count that is not a multiple of 32: cfg.num_channels is the count the kernels run with
+    // (rounded up), c_user the caller's; `padded` holds the zero-extended tensors build_packed reads (pad_wavenet_weights)
+    std::map<std::string, HostTensor> padded;
+    int c_user = 0;
     bool finalized = false;
 
     // packed weights
@@ -498,7 +502,80 @@ PackedGemm pack_gemm(dsd_handle* h, int M, int Kreal, int taps, int pairC, const
     return g;
 }
 
-const HostTensor& W(dsd_handle* h, const std::string& n) { return h->raw.at(n); }
+const HostTensor& W(dsd_handle* h, const std::string& n) {
+    auto it = h->padded.find(n);
+    return it != h->padded.end() ? it->second : h->raw.at(n);
+}
+bool has_W(const dsd_handle* h, const std::string& n) { return h->padded.count(n) || h->raw.count(n); }
+
+// A WaveNet of C channels, C not a multiple of 32, as the network of Cp = round_up(C, 32) channels whose extra channels are
+// exactly zero everywhere: extra weight rows, columns and biases are zero, so the input projection gives relu(0) = 0 there,
+// the FiLM shift is 0, the gate sigmoid(0) * tanh(0) = 0, the residual (0 + 0) / sqrt(2) = 0 and the skip 0 (wavenet.py:33-48);
+// the real channels see only zero contributions from them.  Rows of the [2C] tensors are two halves (gate | filter,
+// residual | skip): each half is extended on its own.  SinusoidalPosEmb keeps the frequencies of the REAL C
+// (common_layers.py:275-276) in the first C/2 of Cp/2 slots; mlp.0's columns follow its [sin | cos] halves.
+void pad_wavenet_weights(dsd_handle* h) {
+    h->padded.clear();
+    const int C = h->c_user, Cp = h->cfg.num_channels, L = h->cfg.num_layers;
+    if (!is_wavenet(h) || C == 0 || C == Cp) return;
+    enum Map { SAME, PLAIN, HALVES, QUAD, SINCOS };
+    auto size_of = [&](Map m, int n) { return m == SAME ? n : m == PLAIN ? Cp : m == HALVES ? 2 * Cp : m == QUAD ? 4 * Cp : Cp; };
+    auto map_of = [&](Map m, int i) {
+        switch (m) {
+            case HALVES: return i < C ? i : Cp + (i - C);
+            case SINCOS: return i < C / 2 ? i : Cp / 2 + (i - C / 2);
+            default: return i;
+        }
+    };
+    auto pad = [&](const std::string& name, Map rm, Map cm) {
+        const HostTensor& t = h->raw.at(name);
+        const int rows = (int)t.shape[0], cols = t.shape.size() > 1 ? (int)t.shape[1] : 1;
+        const int taps = t.shape.size() > 2 ? (int)t.shape[2] : 1;
+        HostTensor o;
+        o.shape = t.shape;
+        o.shape[0] = size_of(rm, rows);
+        if (t.shape.size() > 1) o.shape[1] = size_of(cm, cols);
+        const int cp = t.shape.size() > 1 ? (int)o.shape[1] : 1;
+        o.data.assign((size_t)o.shape[0] * cp * taps, 0.f);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c)
+                for (int k = 0; k < taps; ++k)
+                    o.data[((size_t)map_of(rm, r) * cp + map_of(cm, c)) * taps + k] = t.data[((size_t)r * cols + c) * taps + k];
+        h->padded[name] = std::move(o);
+    };
+    pad("input_projection.weight", PLAIN, SAME);
+    pad("input_projection.bias", PLAIN, SAME);
+    pad("mlp.0.weight", QUAD, SINCOS);
+    pad("mlp.0.bias", QUAD, SAME);
+    pad("mlp.2.weight", PLAIN, QUAD);
+    pad("mlp.2.bias", PLAIN, SAME);
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "residual_layers." + std::to_string(l) + ".";
+        pad(p + "dilated_conv.weight", HALVES, PLAIN);
+        pad(p + "dilated_conv.bias", HALVES, SAME);
+        pad(p + "diffusion_projection.weight", PLAIN, PLAIN);
+        pad(p + "diffusion_projection.bias", PLAIN, SAME);
+        pad(p + "conditioner_projection.weight", HALVES, SAME);
+        pad(p + "conditioner_projection.bias", HALVES, SAME);
+        pad(p + "output_projection.weight", HALVES, PLAIN);
+        pad(p + "output_projection.bias", HALVES, SAME);
+    }
+    pad("skip_projection.weight", PLAIN, PLAIN);
+    pad("skip_projection.bias", PLAIN, SAME);
+    pad("output_projection.weight", SAME, PLAIN);
+    HostTensor f;                               // [Cp / 2]: the real C's table, then zeros (sin 0 = 0 and cos 0 = 1 meet zero columns)
+    f.shape = {Cp / 2};
+    f.data.assign((size_t)Cp / 2, 0.f);
+    const int half = C / 2;
+    if (h->raw.count("diffusion_embedding.freqs")) {
+        const auto& src = h->raw.at("diffusion_embedding.freqs").data;
+        for (int i = 0; i < half; ++i) f.data[i] = src[i];
+    } else {
+        const float step = -(float)(log(10000.0) / (half - 1));
+        for (int i = 0; i < half; ++i) f.data[i] = expf((float)i * step);
+    }
+    h->padded["diffusion_embedding.freqs"] = std::move(f);
+}
 
 // ConvNeXt aux decoder (convnext.py:17-85).  LayerNorm affine folded into pwconv1, the layer scale gamma folded
 // into pwconv2:  x + gamma * (W2 g + b2) = x + (diag(gamma) W2) g + gamma * b2.
@@ -766,6 +843,11 @@ int build_packed_voc(dsd_handle* h) {
 }
 
 std::vector<std::pair<std::string, std::vector<int64_t>>> expected_for(const dsd_handle* h) {
+    if (h->c_user && h->c_user != h->cfg.num_channels) {      // the state_dict has the caller's channel count
+        dsd_config c = h->cfg;
+        c.num_channels = h->c_user;
+        return expected_params(c);
+    }
     return is_enc(h) ? expected_params_enc(h->ecfg) : is_tok(h) ? expected_params_tok(h->tcfg)
          : is_voc(h) ? expected_params_voc(h->vcfg) : expected_params(h->cfg);
 }
@@ -778,9 +860,10 @@ int build_packed(dsd_handle* h) {
     const dsd_config& c = h->cfg;
     const int C = c.num_channels, M = FM_of(h), H = c.hidden_size, L = c.num_layers;
     h->blob_host.clear();
+    pad_wavenet_weights(h);
     // frequency table of SinusoidalPosEmb (common_layers.py:275-276)
     h->freqs_off = blob_reserve(h, (size_t)C / 2);
-    if (h->raw.count("diffusion_embedding.freqs")) {
+    if (has_W(h, "diffusion_embedding.freqs")) {
         const auto& f = W(h, "diffusion_embedding.freqs").data;
         for (int i = 0; i < C / 2; ++i) h->blob_host[h->freqs_off + i] = f[i];
     } else {
@@ -1444,9 +1527,15 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
         return fail(nullptr, DSD_EINVAL, "dsd_create: unknown backbone %d", cfg->backbone);
     if (cfg->in_dims < 1 || cfg->n_feats < 1 || cfg->num_layers < 1 || cfg->hidden_size < 1)
         return fail(nullptr, DSD_EINVAL, "dsd_create: non-positive dimension");
-    if (cfg->num_channels < 32 || cfg->num_channels % 32 != 0)
+    if (cfg->backbone == DSD_BACKBONE_WAVENET) {
+        // any even count the reference itself can run (SinusoidalPosEmb: two halves of C / 2, exponent / (C / 2 - 1),
+        // common_layers.py:275-279); not a multiple of 32: run as the next multiple with zero channels (pad_wavenet_weights)
+        if (cfg->num_channels < 4 || cfg->num_channels % 2 != 0)
+            return fail(nullptr, DSD_EINVAL, "dsd_create: WaveNet num_channels must be even and >= 4 (got %d)", cfg->num_channels);
+    } else if (cfg->num_channels < 32 || cfg->num_channels % 32 != 0) {
         return fail(nullptr, DSD_EINVAL, "dsd_create: num_channels must be a positive multiple of 32 (got %d)",
                     cfg->num_channels);
+    }
     if (cfg->backbone == DSD_AUX_CONVNEXT) {
         if (cfg->n_feats != 1) return fail(nullptr, DSD_EINVAL, "dsd_create: the aux decoder has n_feats == 1 (toplevel.py:50)");
         if (cfg->kernel_size < 1 || cfg->kernel_size % 2 == 0 || cfg->kernel_size > 15)
@@ -1475,6 +1564,10 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
     if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
     dsd_handle* h = new dsd_handle();
     h->cfg = *cfg;
+    if (cfg->backbone == DSD_BACKBONE_WAVENET) {      // the kernels run on a multiple of 32 channels (pad_wavenet_weights)
+        h->c_user = cfg->num_channels;
+        h->cfg.num_channels = (cfg->num_channels + 31) / 32 * 32;
+    }
     *out = h;
     return DSD_OK;
 }
@@ -1512,8 +1605,9 @@ int dsd_load_weight(dsd_handle* h, const char* name, const float* data, const in
     if ((is_enc(h) || is_tok(h)) && n == "encoder.embed_positions._float_tensor")
         return DSD_OK;       // SinusoidalPositionalEmbedding's device/dtype marker buffer (common_layers.py:59): carries no value
     if (n == "diffusion_embedding.freqs" && !is_enc(h) && !is_voc(h) && !is_tok(h)) {
-        if (ndim != 1 || shp[0] != h->cfg.num_channels / 2)
-            return fail(h, DSD_EINVAL, "diffusion_embedding.freqs must have shape [%d]", h->cfg.num_channels / 2);
+        const int cu = h->c_user ? h->c_user : h->cfg.num_channels;
+        if (ndim != 1 || shp[0] != cu / 2)
+            return fail(h, DSD_EINVAL, "diffusion_embedding.freqs must have shape [%d]", cu / 2);
         found = true;
     } else {
         for (auto& e : expected_for(h)) {
@@ -2408,7 +2502,7 @@ int dsd_set_lengths(dsd_handle* h, const int32_t* lengths, int32_t B, void* stre
 int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
     if (!h || !out) return DSD_EINVAL;
     memset(out, 0, sizeof(*out));
-    const int64_t C = C_of(h), M = FM_of(h), L = L_of(h);
+    const int64_t C = h->c_user ? h->c_user : C_of(h), M = FM_of(h), L = L_of(h);
     out->weight_bytes = (int64_t)h->blob_floats * 4;
     out->workspace_bytes = (int64_t)h->arena_floats * 4;
     if (is_enc(h) || is_tok(h)) {        // per TOKEN per encoder pass (attention excluded: it depends on the sequence length)

@@ -152,6 +152,9 @@ WAVENET_CASES = [
      [(2, 50, "long"), (3, 33, "one")], ()),
     ("wn_small", 32, 1, dict(num_layers=4, num_channels=64, dilation_cycle_length=2), 45,
      [(2, 50, "float")], ()),
+    # a channel count that is not a multiple of 32 (the library runs it zero-padded to 256)
+    ("wn_c250", 32, 1, dict(num_layers=5, num_channels=250, dilation_cycle_length=3), 46,
+     [(2, 70, "float"), (1, 33, "long")], ()),
 ]
 
 LYNX_CASES = [

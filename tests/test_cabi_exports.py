@@ -52,7 +52,10 @@ def test_bad_config_rejected():
     cfg = _lib.DsdConfig(C.sizeof(_lib.DsdConfig), 7, 128, 1, 20, 256, 256, 4, 0, 0, 0, 0, 0)
     h = C.c_void_p()
     assert _lib.lib().dsd_create(C.byref(cfg), C.byref(h)) == -1
-    cfg = _lib.DsdConfig(C.sizeof(_lib.DsdConfig), 0, 128, 1, 20, 250, 256, 4, 0, 0, 0, 0, 0)
+    cfg = _lib.DsdConfig(C.sizeof(_lib.DsdConfig), 0, 128, 1, 20, 251, 256, 4, 0, 0, 0, 0, 0)     # WaveNet: any EVEN count
+    assert _lib.lib().dsd_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"must be even" in _lib.lib().dsd_last_error(None)
+    cfg = _lib.DsdConfig(C.sizeof(_lib.DsdConfig), 1, 128, 1, 6, 250, 256, 0, 2, 31, 0, 0, 0)      # LYNXNet: LayerNorm over C
     assert _lib.lib().dsd_create(C.byref(cfg), C.byref(h)) == -1
     assert b"multiple of 32" in _lib.lib().dsd_last_error(None)
 

@@ -49,6 +49,7 @@ WN = {
     "wn_pitch": (64, 1, dict(num_layers=20, num_channels=256, dilation_cycle_length=5)),
     "wn_multivar": (24, 2, dict(num_layers=10, num_channels=192, dilation_cycle_length=4)),
     "wn_small": (32, 1, dict(num_layers=4, num_channels=64, dilation_cycle_length=2)),
+    "wn_c250": (32, 1, dict(num_layers=5, num_channels=250, dilation_cycle_length=3)),
 }
 
 
