@@ -333,7 +333,8 @@ def main():
         elif kind == "wavenet":
             kflops = 2 * 3 * Cc * 2 * Cc * vf                 # 786,432 FLOP/frame
             kbytes = (4 * Cc + 8 * Cc + 4 * Cc) * vf          # read x, read hoisted cond-proj, write gated z
-            kname = "gemm_kernel<ST_FILM,3,EP_GATE> (dilated conv k=3 + FiLM + sigmoid*tanh gate)"
+            kname = ("dilated conv k=3 + FiLM + sigmoid*tanh gate: wn_conv_rs_kernel (row-split pair, 32-frame tiles on "
+                     "one-utterance grids) or gemm_kernel<ST_FILM,3,EP_GATE> (other tile widths)")
         else:
             inner = Cc * bargs["expansion_factor"]
             kflops = 2 * Cc * 2 * inner * vf
@@ -347,6 +348,8 @@ def main():
             if ent:
                 traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
                 prof_ns, prof_split = ent.get("rocprof_avg_ns"), ent.get("rocprof_split_ns")
+                if ent.get("kernel"):        # the name rocprofv3 recorded for this very configuration
+                    kname += " | name in the committed rocprofv3 trace of this configuration: " + ent["kernel"]
         except Exception:
             pass
         sec = mean_ms.value / 1e3
