@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import os as _os0
 _os0.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+_os0.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between ranks needs it on this platform
 import argparse
 import json
 import os

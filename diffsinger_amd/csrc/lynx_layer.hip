@@ -218,6 +218,124 @@ __global__ __launch_bounds__(256, 1) void lx_pw1_kernel(const LxLayerP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// pw1, one workgroup per FRAME tile: the activation tile (and its LayerNorm) is staged ONCE and the workgroup loops over
+// the 2 * inner / 512 row tiles - lx_pw1_kernel stages the same 128 KiB tile in each of them (7 of 8 stagings, 262 of the
+// 467 MB a launch moves at C = 1024, B = 8) and synchronises its waves twice per tile.  The SwiGLU transpose tiles sit
+// BEHIND the activation tile (two halves of 32 channels per wave: 18 KiB), so after the prologue barrier the four waves
+// never meet again; the next row tile's first two weight steps are fetched under the epilogue.  For grids of about one
+// frame tile per CU (B = 8 at T = 1000); launch_lx_layer picks it by rounds.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KT, int RAG>
+__global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NS = KT / 16;
+    constexpr int NU = KT * (BN / 4) / 256;
+    float* xs = lds;                                 // [KT][32], odd rows half-swapped: lives for the whole kernel
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
+    const int ft = xcd_work();
+    const int rest = RAG ? p.cgmap[ft] : ft;
+    const int b = fdiv_floor(rest, p.inv_tiles_per_b);
+    const int t0 = (rest - b * p.tiles_per_b) * BN;
+    const int Ts = p.Ts;
+    const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
+    const int nmt = (2 * p.inner) / 512;                          // row tiles of 256 u channels (512 packed rows)
+
+    const int c4 = tid & 7;
+    const __amdgpu_buffer_rsrc_t r_s = rsrc(p.stats + (long)bu * 2 * Ts + t0u);
+    const f32x4 mean = ld4(r_s, c4 * 16, 0), rstd = ld4(r_s, c4 * 16, Ts * 4);
+    const __amdgpu_buffer_rsrc_t r_x = rsrc(p.xin + (long)bu * p.x_bstride + t0u);
+    const __amdgpu_buffer_rsrc_t r_w0 = rsrc(p.A1 + (long)(MBW * wave) * NS * 256);
+    int wk[MBW];
+#pragma unroll
+    for (int k = 0; k < MBW; ++k) wk[k] = lane * 16 + k * NS * 1024;
+    f32x4 W[3][MBW];
+    const int xv0 = ((tid >> 3) * Ts + c4 * 4) * 4;
+    constexpr int NB4 = 8;
+#pragma unroll
+    for (int u0 = 0; u0 < NU; u0 += NB4) {
+        f32x4 sv[NB4];
+#pragma unroll
+        for (int u = 0; u < NB4; ++u) sv[u] = ld4(r_x, xv0, (u0 + u) * 32 * Ts * 4);
+        if (u0 == 0) {
+#pragma unroll
+            for (int k = 0; k < MBW; ++k) {
+                W[0][k] = ld4(r_w0, wk[k], 0);
+                W[1][k] = ld4(r_w0, wk[k] + 1024, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB4; ++u) {
+            const int row = (tid >> 3) + 32 * (u0 + u);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (sv[u][e] - mean[e]) * rstd[e];        // LayerNorm (lynxnet.py:53), affine in W1 / b1
+            *reinterpret_cast<f32x4*>(&xs[row * BN + ((c4 * 4) ^ ((row & 1) << 4))]) = o;
+        }
+    }
+    __syncthreads();                                             // the only workgroup barrier
+
+    const int sw = (lrow & 1) << 4;
+    const float* zt0 = xs + lrow * BN + (lcol ^ sw);
+    const float* zt1 = xs + lrow * BN + ((16 + lcol) ^ sw);
+    const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias1);
+    float* ew = lds + KT * BN + wave * (32 * ES);                // wave-private [32 channels][ES], behind the activation tile
+    const int ev0 = ((lane >> 3) * Ts + (lane & 7) * 4) * 4;
+    constexpr long kMtBlocks = (long)MBW * 4 * NS * 256;         // floats of packed weights per row tile
+#pragma unroll 1
+    for (int mt = 0; mt < nmt; ++mt) {
+        const __amdgpu_buffer_rsrc_t r_w = rsrc(p.A1 + mt * kMtBlocks + (long)(MBW * wave) * NS * 256);
+        f32x4 acc[MBW][2];
+#pragma unroll
+        for (int k = 0; k < MBW; ++k) acc[k][0] = acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ch0 = 256 * mt + 64 * wave;                    // first u channel of this wave in this row tile
+        f32x4 bo[MBW];
+        k_phase<KT, 0, false>(acc, W, r_w, wk, 0, zt0, zt1, [&](int s) {
+            if (s < MBW) bo[s] = ld4(r_b, rq * 4, ((s & 1) * p.inner + ch0 + (s >> 1) * 16) * 4);
+        });
+        if (mt + 1 < nmt) {                                      // the next row tile's steps 0 and 1 land under the epilogue
+            const __amdgpu_buffer_rsrc_t r_n = rsrc(p.A1 + (mt + 1) * kMtBlocks + (long)(MBW * wave) * NS * 256);
+#pragma unroll
+            for (int k = 0; k < MBW; ++k) {
+                W[0][k] = ld4(r_n, wk[k], 0);
+                W[1][k] = ld4(r_n, wk[k] + 1024, 0);
+            }
+        }
+        // SwiGLU (common_layers.py:116-117: out * silu(gate)) in two halves of 32 channels through the wave's own tile
+        const __amdgpu_buffer_rsrc_t r_o = rsrc(p.u + (long)bu * p.u_bstride + (long)ch0 * Ts + t0u);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * hf + ii;
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u0 = acc[2 * i][n][r] + bo[2 * i][r];
+                        const float u1 = acc[2 * i + 1][n][r] + bo[2 * i + 1][r];
+                        ew[(ii * 16 + rq + r) * ES + n * 16 + lcol] = u0 * (u1 * sigmoid_f(u1));
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int idx = lane + 64 * m;
+                st4(*reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]), r_o, ev0, (hf * 32 + m * 8) * Ts * 4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                     // the tile is read before the next half overwrites it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // pw2: 1x1 inner -> C on the depthwise conv's output, + bias + residual, then the next layer's transition and the
 // LayerNorm partials of its input.  K = inner walked as NP = inner / 1024 resident phases of KT = 1024 channels (or one
 // phase of 512 / 1024).  Workgroup = 512 rows x 32 frames; wave w: rows [512 mtile + 128 w, +128) = 64-row tiles 2w, 2w+1.
@@ -399,6 +517,7 @@ __global__ __launch_bounds__(256, 1) void lx_pw2_kernel(const LxLayerP p) {
 #undef LX_SPREAD
 
 int lx_lds_bytes(int kt) { return (kt * 32 * 4 > 4 * 128 * 36 * 4 ? kt * 32 * 4 : 4 * 128 * 36 * 4) + 1024 * 4; }
+int lx_pw1p_lds_bytes(int kt) { return kt * 32 * 4 + 4 * 32 * ES * 4; }        // activation tile + the four waves' half tiles
 
 bool lx_layer_supported(int C, int inner) {
     // pw1 needs C = the resident K (512 / 1024) and 2 * inner rows in workgroups of 512; pw2 C rows in workgroups of 512 and
@@ -415,6 +534,38 @@ static thread_local hipEvent_t g_lx_ev0 = nullptr, g_lx_ev1 = nullptr;
 void lx_layer_set_timing_events(hipEvent_t start, hipEvent_t stop) {
     g_lx_ev0 = start;
     g_lx_ev1 = stop;
+}
+
+template <int KT, int RAG>
+static hipError_t lx_launch_pw1p(const LxLayerP& p, int nwg, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = lx_attr(lx_pw1p_kernel<KT, RAG>);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    if (nwg == 0) return hipSuccess;
+    const int ldsb = lx_pw1p_lds_bytes(KT);
+    if (g_lx_ev0 && g_lx_ev1)
+        hipExtLaunchKernelGGL((lx_pw1p_kernel<KT, RAG>), dim3(nwg), dim3(256), ldsb, st, g_lx_ev0, g_lx_ev1, 0, p);
+    else
+        hipLaunchKernelGGL((lx_pw1p_kernel<KT, RAG>), dim3(nwg), dim3(256), ldsb, st, p);
+    return hipGetLastError();
+}
+
+// pw1 as one workgroup per frame tile when that costs no more rounds of the chip than one per (frame tile, row tile):
+// ceil(nft / CUs) * mtiles row-tile times against ceil(nft * mtiles / CUs).  DSD_LYNX_PW1P=0/1 forces the choice.
+static bool lx_use_pw1p(int nft, int mtiles) {
+    static const int force = getenv("DSD_LYNX_PW1P") ? atoi(getenv("DSD_LYNX_PW1P")) : -1;
+    if (force >= 0) return force != 0;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const long per_ft = (long)((nft + cus - 1) / cus) * mtiles, per_wg = ((long)nft * mtiles + cus - 1) / cus;
+    return nft >= cus / 2 && per_ft <= per_wg;
 }
 
 template <int KT, int RAG>
@@ -448,6 +599,12 @@ hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st) 
     const int nft = p.cgmap ? p.ncg : p.nft;
     const int mtiles = which == 0 ? (2 * p.inner) / 512 : C / 512;
     const int nwg = nft * mtiles;
+    if (which == 0 && (nft == 0 || lx_use_pw1p(nft, mtiles))) {      // (nft == 0: attribute set-up of both forms at create)
+        hipError_t e = C == 1024 ? (p.cgmap ? lx_launch_pw1p<1024, 1>(p, nft, st) : lx_launch_pw1p<1024, 0>(p, nft, st))
+                     : C == 512 ? (p.cgmap ? lx_launch_pw1p<512, 1>(p, nft, st) : lx_launch_pw1p<512, 0>(p, nft, st))
+                                : hipErrorInvalidValue;
+        if (nft != 0 || e != hipSuccess) return e;
+    }
     if (C == 1024) return p.cgmap ? lx_launch<1024, 1>(p, which, nwg, st) : lx_launch<1024, 0>(p, which, nwg, st);
     if (C == 512) return p.cgmap ? lx_launch<512, 1>(p, which, nwg, st) : lx_launch<512, 0>(p, which, nwg, st);
     return hipErrorInvalidValue;
