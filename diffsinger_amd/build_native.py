@@ -17,6 +17,7 @@ SOURCES = ["gemm.hip", "wn_layer.hip", "wn_rowsplit.hip", "lynx_layer.hip", "aux
 HEADERS = [os.path.join(CSRC, "dsd_internal.h"), os.path.join(os.path.dirname(HERE), "include", "dsdenoise.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("DSD_EXTRA_HIPCC_FLAGS", "").split()      # diagnostic A/B builds (e.g. -DDSD_ST_AUX=0)
 
 
 def _stale(target, deps):

@@ -20,6 +20,15 @@ enum Stage { ST_PLAIN = 0, ST_FILM = 1, ST_LN = 2, ST_SCALE = 3, ST_LRELU = 4 };
 enum Epi { EP_BIAS_ACT = 0, EP_GATE = 1, EP_RESSKIP = 2, EP_LINCOMB = 3, EP_SWIGLU = 4, EP_BIAS_RES = 5, EP_SCATTER = 6, EP_LYNX_NEXT = 7 };
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3, ACT_LRELU = 4, ACT_TANH = 5, ACT_SILU = 6 };
 
+// Cache policy of the WaveNet layer kernels' 16-byte result stores (raw buffer intrinsics: bit 4 = sc1 = write-through).
+// A kernel boundary costs the bytes its predecessor left dirty in the L2s / ~6 TB/s (MI355X_MICROARCH.md, "boundary":
+// x + skip of a fused layer at B = 8 are 16 MB); write-through stores spread that over the kernel's own epilogues.
+// A/B on fresh boxes (tools/ab_bench.sh; -DDSD_ST_AUX=0 builds the plain form): 50-NFE loop 16.68 -> 16.55 ms at B = 1,
+// 26.21 -> 25.79 at B = 2, 70.07 -> 69.00 at B = 8, the variance pair 37.54 -> 36.92; LYNXNet's kernels keep plain stores.
+#ifndef DSD_ST_AUX
+#define DSD_ST_AUX 16
+#endif
+
 constexpr int kMaxTerms = 8;
 constexpr int kMaxOut = 3;
 

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ((add_pre ? pre[m][e] : 0.f) + a4[e]) * scale;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), r_o, ev0,
-                                                   m * 8 * Ts * 4, 0);
+                                                   m * 8 * Ts * 4, DSD_ST_AUX);
         }
     }
     WN_STAMP(6);

@@ -38,7 +38,7 @@ __device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, int voff, int sof
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 __device__ __forceinline__ void st4(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, soff, DSD_ST_AUX);
 }
 
 #ifdef DSD_STAMPS
