@@ -330,10 +330,97 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ s
     if (t0 + lane * 4 < rstride - 3) *reinterpret_cast<f32x4*>(d) = o;
 }
 
+// Row-streaming form for the kernel sizes the models use (31: LYNXNet, 7: ConvNeXt): ONE WAVE per (item, channel) row walks
+// the row in 256-frame segments.  A segment's 320-float window [t0 - 16, t0 + 304) arrives as 16-byte buffer loads whose
+// range check IS the zero padding (the descriptor covers exactly the item's valid frames: offsets before 0 wrap around and
+// offsets from Tb on read as 0, per dword), goes into the wave's own LDS row (two rows in turn: no workgroup barrier, the
+// four waves of a workgroup never meet), and the NEXT segment's loads are in flight while this one's taps run from
+// registers.  The first form above launches 16 k four-row workgroups of one segment each, stages with 4-byte loads and
+// meets at a barrier: 36.9 us per LYNXNet layer at B = 8 (131 MB at 3.5 TB/s) against this one's.
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          long bstride, int rstride, int C, int T, int nrows,
+                                                          const int* __restrict__ lens, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, int act,
+                                                          const float* __restrict__ prelu) {
+    constexpr int SEG = DW_TT, WIN = SEG + 64;                   // staged floats per segment (whole float4s, 16 before t0)
+    constexpr int OFF = 16 - KS / 2;                             // first tap of frame t0 + 4 lane sits at staged index 4 lane + OFF
+    constexpr int OA = OFF & ~3, O2 = OFF & 3;                   // ... read as aligned float4s from 4 lane + OA, taps from O2 in
+    constexpr int NW = (O2 + KS + 3 + 3) / 4 * 4;                // the lane's window, whole float4s
+    static_assert(KS / 2 <= 16 && 4 * 63 + OA + NW <= WIN, "window must stay inside the staged row");
+    __shared__ __attribute__((aligned(16))) float rows[4][2][WIN];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + wave;                       // (item, channel), wave-uniform
+    if (row >= nrows) return;                                    // (no workgroup barrier below)
+    const int b = row / C, c = row - b * C;
+    const int Tb = lens ? lens[b] : T;
+    const float* s = src + (long)b * bstride + (long)c * rstride;
+    // the descriptor's range = the valid frames: everything outside reads as zero = the convolution's zero padding
+    const __amdgpu_buffer_rsrc_t r_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s), 0, Tb * 4, 0x00020000);
+    float* d = dst + (long)b * bstride + (long)c * rstride;
+    const int nseg = (T + SEG - 1) / SEG;
+    float wr[KS];                                                // the row's taps, bias and slope: scalar loads
+#pragma unroll
+    for (int j = 0; j < KS; ++j) wr[j] = w[(long)c * KS + j];
+    const float bv = bias[c];
+    const float slope = (act == 0) ? prelu[c] : 0.f;
+    auto fetch = [&](int seg, f32x4& a, f32x4& e) {              // 80 float4 per segment: one per lane + one for lanes 0-15
+        const int base = (seg * SEG - 16) * 4;
+        a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_s, base + lane * 16, 0, 0));
+        e = lane < 16 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_s, base + (64 + lane) * 16, 0, 0))
+                      : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 na, ne;
+    fetch(0, na, ne);
+    for (int seg = 0; seg < nseg; ++seg) {
+        float* rw = rows[wave][seg & 1];
+        *reinterpret_cast<f32x4*>(&rw[lane * 4]) = na;
+        if (lane < 16) *reinterpret_cast<f32x4*>(&rw[(64 + lane) * 4]) = ne;
+        if (seg + 1 < nseg) fetch(seg + 1, na, ne);              // in flight under this segment's taps
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float win[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&rw[lane * 4 + OA + i]);
+            win[i] = v[0]; win[i + 1] = v[1]; win[i + 2] = v[2]; win[i + 3] = v[3];
+        }
+        float acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += wr[j] * win[O2 + j + e];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e];
+            if (act == 0) v = v >= 0.f ? v : v * slope;
+            else if (act == 1) v = v * (1.f / (1.f + expf(-v)));
+            else if (act == 2) v = fmaxf(v, 0.f);
+            o[e] = v;
+        }
+        const int t = seg * SEG + lane * 4;
+        if (t < rstride - 3) *reinterpret_cast<f32x4*>(&d[t]) = o;
+    }
+}
+
 hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride, int C, int B, int T, const int* lens,
                          const float* w, const float* bias, int ksz, int act, const float* prelu,
                          hipStream_t stream) {
     if (ksz > DW_MAXK || ksz < 1 || ksz % 2 == 0) return hipErrorInvalidValue;
+    static const int rows_env = getenv("DSD_DWCONV_ROWS") ? atoi(getenv("DSD_DWCONV_ROWS")) : -1;      // 0: the first form (A/B)
+    if (rows_env != 0 && (ksz == 31 || ksz == 7)) {
+        const int nrows = B * C;
+        if (ksz == 31)
+            hipLaunchKernelGGL(dwconv_rows_kernel<31>, dim3((nrows + 3) / 4), dim3(256), 0, stream, src, dst, bstride, rstride, C, T,
+                               nrows, lens, w, bias, act, prelu);
+        else
+            hipLaunchKernelGGL(dwconv_rows_kernel<7>, dim3((nrows + 3) / 4), dim3(256), 0, stream, src, dst, bstride, rstride, C, T,
+                               nrows, lens, w, bias, act, prelu);
+        return hipGetLastError();
+    }
     dim3 grid((T + DW_TT - 1) / DW_TT, (C + 3) / 4, B);
     if (ksz == 31)
         hipLaunchKernelGGL(dwconv_kernel<31>, grid, dim3(256), 0, stream, src, dst, bstride, rstride, C, T, lens, w, bias, ksz,
