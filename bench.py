@@ -325,7 +325,7 @@ def main():
         mean_ms = raw_ms
         _lib.check(h, _lib.lib().dsd_kernel_timing(h, 0), "dsd_kernel_timing")
         Cc = bargs["num_channels"]
-        fused = kind == "wavenet" and stats["kernels_per_nfe"] == bargs["num_layers"] + 3
+        fused = kind == "wavenet" and stats["kernels_per_nfe"] in (bargs["num_layers"] + 1, bargs["num_layers"] + 3)   # one launch per layer
         vf = (sum(my_lens) if my_lens else B * T)             # frames one launch covers on this rank
         if fused:
             kflops = 2 * (3 * Cc * 2 * Cc + Cc * 2 * Cc) * vf     # conv 786,432 + out-proj 262,144 FLOP/frame

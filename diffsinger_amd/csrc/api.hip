@@ -73,6 +73,8 @@ struct dsd_handle {
     // (rounded up), c_user the caller's; `padded` holds the zero-extended tensors build_packed reads (pad_wavenet_weights)
     std::map<std::string, HostTensor> padded;
     int c_user = 0;
+    // wn_edge.hip: the state buffer whose input projection the previous evaluation's edge kernel already wrote into xh
+    const float* edge_xh_src = nullptr;
     bool finalized = false;
 
     // packed weights
@@ -1265,7 +1267,7 @@ int run_step_tables(dsd_handle* h, int ncols, hipStream_t st) {
 // One backbone evaluation on the internal-layout input `xin_state` ([B][F*M][Ts]); the last GEMM's
 // epilogue writes the `nout` linear combinations `lo` (LinTerm.ptr == nullptr = model output).
 int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_colb, const LinOut* lo, int nout,
-                 hipStream_t st) {
+                 hipStream_t st, const float* next_xin = nullptr) {
     const int B = h->B, T = h->T, Ts = h->Ts, C = C_of(h), FM = FM_of(h), L = L_of(h), Ns = h->Ns;
     const long xs = (long)C * Ts;
     int rc;
@@ -1314,7 +1316,10 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             g.p.film = h->D + (long)next * C * Ns; g.p.film_cstride = Ns; g.p.film_col0 = film_col0; g.p.film_colb = film_colb;
         }
     };
-    {   // input projection (+ReLU for WaveNet, wavenet.py:86-88; GELU unless strong_cond for LYNXNet, lynxnet.py:141-143)
+    // WaveNet: the previous evaluation's edge kernel (wn_edge.hip) may already have projected this very input into xh
+    const bool inproj_done = !lynx && h->edge_xh_src != nullptr && h->edge_xh_src == xin_state;
+    h->edge_xh_src = nullptr;
+    if (!inproj_done) {   // input projection (+ReLU for WaveNet, wavenet.py:86-88; GELU unless strong_cond for LYNXNet, lynxnet.py:141-143)
         GemmCall g = make_gemm(h, h->g_inproj, xin_state, (long)FM * Ts, Ts, B, T, ST_PLAIN,
                                lynx ? EP_LYNX_NEXT : EP_BIAS_ACT, 0);
         g.p.act = is_wavenet(h) ? ACT_RELU : (h->cfg.strong_cond ? ACT_NONE : ACT_GELU);
@@ -1395,6 +1400,49 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             o.p.C = C; o.p.x = h->xh; o.p.skip = h->skip; o.p.first_layer = (l == 0);
             o.p.o_bstride = xs; o.p.o_rstride = Ts;
             if ((rc = run_gemm(h, o, st))) return rc;
+        }
+        // skip projection -> output projection + solver update (-> the next evaluation's input projection) in one launch with
+        // one workgroup per frame tile (wn_edge.hip); DSD_EDGE=0: the three GEMMs of gemm.hip
+        static const int edge_env = getenv("DSD_EDGE") ? atoi(getenv("DSD_EDGE")) : -1;
+        const bool e_ragged = h->use_cg && !h->lens_host.empty();
+        const long e_t32 = e_ragged ? (long)h->cg_n[1] : (long)B * ((T + 31) / 32);       // 32-frame tiles = workgroups
+        if (edge_env != 0 && wn_edge_supported(C, FM) && nout >= 1 && nout <= kMaxOut && (edge_env == 1 || e_t32 >= 128)) {
+            const bool ragged = e_ragged;
+            const int ncb = 2;
+            const int bnw = 16 * ncb;
+            WnEdgeP p;
+            memset(&p, 0, sizeof(p));
+            p.A1 = h->blob + h->g_tail1.a_off; p.b1 = h->blob + h->g_tail1.bias_off;
+            p.A2 = h->blob + h->g_out.a_off; p.b2 = h->blob + h->g_out.bias_off;
+            p.A3 = h->blob + h->g_inproj.a_off; p.b3 = h->blob + h->g_inproj.bias_off;
+            p.skip = h->skip; p.xh = h->xh; p.x_bstride = xs; p.Ts = Ts; p.T = T; p.FM = FM;
+            p.in_scale = sqrtf((float)L);
+            p.tiles_per_b = (T + bnw - 1) / bnw; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
+            p.nout = nout;
+            bool fits = true;
+            for (int i = 0; i < nout; ++i) {
+                p.dst[i] = lo[i].dst;
+                for (int k = 0; k < lo[i].nterms; ++k) {
+                    const LinTerm& tm = lo[i].t[k];
+                    if (tm.ptr == nullptr) { p.cm[i] += tm.coef; continue; }
+                    if (p.nq == kEdgeMaxTerms || tm.ext) { fits = false; break; }      // (caller-noise terms: the GEMM path)
+                    EdgeTerm& q = p.q[p.nq++];
+                    q.ptr = tm.ptr; q.bstride = tm.bstride; q.rstride = tm.rstride; q.ext = tm.ext; q.coef = tm.coef; q.out = i;
+                }
+            }
+            p.o_bstride = (long)FM * Ts; p.o_rstride = Ts;
+            p.next_src = -1;
+            if (next_xin)
+                for (int i = 0; i < nout; ++i)
+                    if (lo[i].dst == next_xin) p.next_src = i;
+            int nwg = B * p.tiles_per_b;
+            if (ragged) { p.cgmap = h->cg_dev[ncb == 2 ? 1 : 0]; p.ncg = h->cg_n[ncb == 2 ? 1 : 0]; nwg = p.ncg; }
+            if (fits) {      // (more state terms than the kernel holds at once: the three GEMMs below)
+                hipError_t ee = launch_wn_edge(p, C, ncb, nwg, st);
+                if (ee != hipSuccess) return fail(h, DSD_EHIP, "WaveNet edge-kernel launch failed: %s", hipGetErrorString(ee));
+                if (p.next_src >= 0) h->edge_xh_src = next_xin;
+                return DSD_OK;
+            }
         }
         GemmCall t1 = make_gemm(h, h->g_tail1, h->skip, xs, Ts, B, T, ST_SCALE, EP_BIAS_ACT, 0);
         t1.p.in_scale = sqrtf((float)L);      // staged value is DIVIDED by in_scale (wavenet.py:96)
@@ -1560,6 +1608,7 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
     hipError_t ie = gemm_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_layer_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_rowsplit_init_all();
+    if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_edge_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_LYNXNET) ie = lx_layer_init_all();
     if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
     dsd_handle* h = new dsd_handle();
@@ -2385,6 +2434,7 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
     const long ext_b = (long)FM * T;
     auto body = [&](hipStream_t s) -> int {
         int r = DSD_OK;
+        h->edge_xh_src = nullptr;
         if (prog->n_evals > 0 && (r = run_step_tables(h, prog->n_evals, s))) return r;
         for (int i = 0; i < prog->n_evals; ++i) {
             const dsd_eval& ev = prog->evals[i];
@@ -2411,7 +2461,8 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
                     }
                 }
             }
-            if ((r = run_backbone(h, state_buf(h, ev.x_buf), i, 0, lo, ev.n_out, s))) return r;
+            const float* next_xin = i + 1 < prog->n_evals ? state_buf(h, prog->evals[i + 1].x_buf) : nullptr;
+            if ((r = run_backbone(h, state_buf(h, ev.x_buf), i, 0, lo, ev.n_out, s, next_xin))) return r;
         }
         return r;
     };
@@ -2519,7 +2570,13 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
         // 2*(M*C + L*(3*C*2C + C*2C) + C*C + C*M); bytes L*24C + 2*4*M
         out->flops_per_frame_nfe = 2 * (M * C + L * (3 * C * 2 * C + C * 2 * C) + C * C + C * M);
         out->bytes_per_frame_nfe = L * 24 * C + 8 * M;
-        out->kernels_per_nfe = 1 + (h->arena && wn_use_fused(h) ? 1 : 2) * (int)L + 2;    // fused: one launch per layer
+        // around the layers: the edge kernel (skip projection, output projection + solver update, the next evaluation's input
+        // projection; wn_edge.hip) or the three GEMMs of gemm.hip
+        static const int edge_env = getenv("DSD_EDGE") ? atoi(getenv("DSD_EDGE")) : -1;
+        long t32 = (long)h->B * ((h->T + 31) / 32);
+        if (!h->lens_host.empty()) { t32 = 0; for (int v : h->lens_host) t32 += (v + 31) / 32; }
+        const bool edge = edge_env != 0 && wn_edge_supported(C_of(h), FM_of(h)) && h->arena && (edge_env == 1 || t32 >= 128);
+        out->kernels_per_nfe = (h->arena && wn_use_fused(h) ? 1 : 2) * (int)L + (edge ? 1 : 3);    // fused: one launch per layer
     } else {
         const int64_t inner = inner_of(h), ks = h->cfg.kernel_size;
         out->flops_per_frame_nfe = 2 * (M * C + L * (C * 2 * inner + ks * inner + inner * C) + C * M);

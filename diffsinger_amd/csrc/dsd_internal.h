@@ -162,6 +162,44 @@ hipError_t wn_rowsplit_init_all();
 bool wn_rowsplit_supported(int C, int dil);
 void wn_rowsplit_set_timing_events(hipEvent_t start, hipEvent_t stop);
 
+// wn_edge.hip: the WaveNet's small GEMMs around the residual layers (skip projection -> output projection + solver update ->
+// the next evaluation's input projection) as one launch with one workgroup per frame tile
+constexpr int kEdgeMaxTerms = 8;      // state-buffer / noise terms of all outputs of one evaluation together
+struct EdgeTerm {
+    const float* ptr;       // state buffer (internal layout)
+    long bstride;
+    int rstride, ext;
+    float coef;
+    int out;                // the output this term belongs to
+};
+struct WnEdgeP {
+    const float* A1;        // packed skip_projection [C x C], bias b1
+    const float* b1;
+    const float* A2;        // packed output_projection [F*M x C], bias b2
+    const float* b2;
+    const float* A3;        // packed input_projection [C x F*M], bias b3 (used when next_src >= 0)
+    const float* b3;
+    const float* skip;      // running skip sum [B][C][Ts]
+    float* xh;              // the next evaluation's layer-0 input [B][C][Ts]
+    long x_bstride;
+    int Ts, T, FM;
+    float in_scale;         // sqrt(L): the staged skip sum is divided by it (wavenet.py:96)
+    int tiles_per_b;
+    float inv_tiles_per_b;
+    int nout, next_src;     // solver outputs; which of them is the next evaluation's input (-1: none - no input projection)
+    float* dst[kMaxOut];    // output o = cm[o] * eps + sum of its terms (in the program's order)
+    float cm[kMaxOut];
+    int nq;
+    EdgeTerm q[kEdgeMaxTerms];
+    long o_bstride;         // state buffers: floats between batch items / rows
+    int o_rstride;
+    const int* cgmap;       // ragged batches: the (item, frame tile) list of this tile width
+    int ncg;
+};
+hipError_t launch_wn_edge(const WnEdgeP& p, int C, int ncb, int nwg, hipStream_t st);
+hipError_t wn_edge_init_all();
+bool wn_edge_supported(int C, int FM);
+
 // lynx_layer.hip: LYNXNet's two pointwise GEMMs with the whole K extent of a 32-frame tile resident in LDS (batched grids)
 struct LxLayerP {
     const float* A1;        // packed pw1 weights (PackedGemm, pairC = inner; LayerNorm affine folded in)

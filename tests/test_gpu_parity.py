@@ -574,14 +574,14 @@ def test_config4_per_gpu_share_all_50_steps_vs_oracle():
     out = d(dev(cond), infer=True, noise=dev(noise))
     forced = os.environ.get("DSD_FUSED_LAYER")                      # diagnostic override of the per-shape choice
     stats = d.denoise_fn.stats()
-    assert forced == "0" or stats["kernels_per_nfe"] == 20 + 3, stats      # one launch per layer: the fused path really ran
+    assert forced == "0" or stats["kernels_per_nfe"] in (20 + 1, 20 + 3), stats      # one launch per layer: the fused path really ran
     params = synth_params("wavenet", 128, 1, args, 42)
     fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=4)   # noqa: E731
     o = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
     want = o.forward(cond, noise, diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
     check(out, want, TOL_SAMPLER, what="8 x 1000 frames, 50 NFE, fused layers")
     one = d(dev(cond[3:4]), infer=True, noise=dev(noise[3:4]))
-    assert forced == "1" or d.denoise_fn.stats()["kernels_per_nfe"] == 2 * 20 + 3
+    assert forced == "1" or d.denoise_fn.stats()["kernels_per_nfe"] in (2 * 20 + 1, 2 * 20 + 3)
     check(one, want[3:4], TOL_SAMPLER, what="utterance 3 alone, two GEMMs per layer")
     d.denoise_fn.release_native()
 

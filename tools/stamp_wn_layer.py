@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "diffsinger_amd", "csrc")
 OUT = os.path.join(ROOT, "diffsinger_amd", "libdsdenoise_stamps.so")
-srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "wn_layer.hip", "wn_rowsplit.hip", "lynx_layer.hip", "aux_kernels.hip", "encoder_kernels.hip",
+srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "wn_layer.hip", "wn_rowsplit.hip", "wn_edge.hip", "lynx_layer.hip", "aux_kernels.hip", "encoder_kernels.hip",
                                         "vocoder_kernels.hip", "tconv.hip", "api.hip")]
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DDSD_STAMPS",
