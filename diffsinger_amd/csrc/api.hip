@@ -1246,6 +1246,13 @@ bool wn_use_fused(const dsd_handle* h) {
     return tiles >= 128 && fused < split;
 }
 
+// DSD_EDGE: 0 = never the edge kernel (wn_edge.hip), 1 = on every grid, unset = by grid size.  Read per call: tests/
+// test_gpu_edge.py switches it between two handles of one process.
+inline int edge_choice() {
+    const char* ev = getenv("DSD_EDGE");
+    return ev ? atoi(ev) : -1;
+}
+
 // step tables: E = sinemb(t) -> Hd = act(W0 E + b0) -> E2 = W1 Hd + b1 -> D[l*C + c][col] = Wd_l E2 + bd_l
 int run_step_tables(dsd_handle* h, int ncols, hipStream_t st) {
     const int C = C_of(h), Ns = h->Ns;
@@ -1403,7 +1410,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
         }
         // skip projection -> output projection + solver update (-> the next evaluation's input projection) in one launch with
         // one workgroup per frame tile (wn_edge.hip); DSD_EDGE=0: the three GEMMs of gemm.hip
-        static const int edge_env = getenv("DSD_EDGE") ? atoi(getenv("DSD_EDGE")) : -1;
+        const int edge_env = edge_choice();
         const bool e_ragged = h->use_cg && !h->lens_host.empty();
         const long e_t32 = e_ragged ? (long)h->cg_n[1] : (long)B * ((T + 31) / 32);       // 32-frame tiles = workgroups
         if (edge_env != 0 && wn_edge_supported(C, FM) && nout >= 1 && nout <= kMaxOut && (edge_env == 1 || e_t32 >= 128)) {
@@ -2572,7 +2579,7 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
         out->bytes_per_frame_nfe = L * 24 * C + 8 * M;
         // around the layers: the edge kernel (skip projection, output projection + solver update, the next evaluation's input
         // projection; wn_edge.hip) or the three GEMMs of gemm.hip
-        static const int edge_env = getenv("DSD_EDGE") ? atoi(getenv("DSD_EDGE")) : -1;
+        const int edge_env = edge_choice();
         long t32 = (long)h->B * ((h->T + 31) / 32);
         if (!h->lens_host.empty()) { t32 = 0; for (int v : h->lens_host) t32 += (v + 31) / 32; }
         const bool edge = edge_env != 0 && wn_edge_supported(C_of(h), FM_of(h)) && h->arena && (edge_env == 1 || t32 >= 128);
