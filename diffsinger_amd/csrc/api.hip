@@ -1486,8 +1486,6 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
     const bool lx_res = lx_res1;
     for (int l = 0; l < L; ++l) {
         if (lx_res) {
-            hipError_t me = launch_ln_merge(h->lnpart, ln_tiles, C, B, T, Ts, 1e-5f, h->stats, st);
-            if (me != hipSuccess) return fail(h, DSD_EHIP, "LayerNorm merge launch failed: %s", hipGetErrorString(me));
             LxLayerP p;
             memset(&p, 0, sizeof(p));
             p.A1 = h->blob + h->g_pw1[l].a_off; p.bias1 = h->blob + h->g_pw1[l].bias_off;
@@ -1500,6 +1498,11 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             p.inv_nft = 1.0f / (float)std::max(1, lx_ragged ? p.ncg : p.nft);
             p.strong = h->cfg.strong_cond;
             p.lnpart = h->lnpart; p.lnpart_ts = Ts; p.ln_tiles = ln_tiles;
+            p.lnpart_in = h->lnpart;        // (read by pw1 before pw2 of this layer replaces it with the next layer's partials)
+            if (!lx_pw1_merges_stats(p, C)) {      // one workgroup per frame tile merges its own frames' partials itself
+                hipError_t me = launch_ln_merge(h->lnpart, ln_tiles, C, B, T, Ts, 1e-5f, h->stats, st);
+                if (me != hipSuccess) return fail(h, DSD_EHIP, "LayerNorm merge launch failed: %s", hipGetErrorString(me));
+            }
             const int next = l + 1;
             p.xin_out = next < L ? h->xin : nullptr;
             if (next < L) {

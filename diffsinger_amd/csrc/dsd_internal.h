@@ -207,7 +207,8 @@ struct LxLayerP {
     const float* A2;        // packed pw2 weights
     const float* bias2;     // [C]
     const float* xin;       // pw1 input: the layer's pre-LayerNorm activations [B][C][Ts]
-    const float* stats;     // [B][2][Ts]: mean, rstd per frame (ln_merge_kernel)
+    const float* stats;     // [B][2][Ts]: mean, rstd per frame (ln_merge_kernel) - lx_pw1_kernel
+    const float* lnpart_in; // the producer's LayerNorm partials of xin (same layout as lnpart) - lx_pw1p_kernel merges them itself
     float* u;               // pw1 output [B][inner][Ts]
     const float* v;         // pw2 input (depthwise conv output) [B][inner][Ts]
     float* x;               // residual stream [B][C][Ts]: read and replaced by pw2
@@ -227,6 +228,7 @@ struct LxLayerP {
 hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st);      // which: 0 = pw1, 1 = pw2
 bool lx_layer_supported(int C, int inner);
 hipError_t lx_layer_init_all();
+bool lx_pw1_merges_stats(const LxLayerP& p, int C);
 void lx_layer_set_timing_events(hipEvent_t start, hipEvent_t stop);
 
 // aux_kernels.hip

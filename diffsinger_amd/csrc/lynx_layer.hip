@@ -245,8 +245,34 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
     const int nmt = (2 * p.inner) / 512;                          // row tiles of 256 u channels (512 packed rows)
 
     const int c4 = tid & 7;
-    const __amdgpu_buffer_rsrc_t r_s = rsrc(p.stats + (long)bu * 2 * Ts + t0u);
-    const f32x4 mean = ld4(r_s, c4 * 16, 0), rstd = ld4(r_s, c4 * 16, Ts * 4);
+    // LayerNorm statistics of the tile's frames: this workgroup is the only reader of its 32 frames, so it merges the
+    // producer's per-64-row partials (mean_i, M2_i) itself - ln_merge_kernel's arithmetic in ln_merge_kernel's order (tiles
+    // in ascending order; parallel-variance formula), every thread for its own four frames - and no merge launch runs
+    // between the layers
+    f32x4 mean, rstd;
+    {
+        constexpr int NT = KT / 64;                              // 64-row tiles of xin (= p.ln_tiles)
+        const __amdgpu_buffer_rsrc_t r_p = rsrc(p.lnpart_in + (long)bu * NT * 2 * p.lnpart_ts + t0u);
+        f32x4 pm[NT], pq[NT];                                    // every partial in flight at once: one memory latency
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            pm[i] = ld4(r_p, c4 * 16, i * 2 * p.lnpart_ts * 4);
+            pq[i] = ld4(r_p, c4 * 16, (i * 2 + 1) * p.lnpart_ts * 4);
+        }
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NT; ++i) s += 64.f * pm[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mean[e] = s[e] / (float)KT;
+        f32x4 m2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const f32x4 d = pm[i] - mean;
+            m2 += pq[i] + 64.f * d * d;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(m2[e] / (float)KT + 1e-5f);
+    }
     const __amdgpu_buffer_rsrc_t r_x = rsrc(p.xin + (long)bu * p.x_bstride + t0u);
     const __amdgpu_buffer_rsrc_t r_w0 = rsrc(p.A1 + (long)(MBW * wave) * NS * 256);
     int wk[MBW];
@@ -608,6 +634,13 @@ hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st) 
     if (C == 1024) return p.cgmap ? lx_launch<1024, 1>(p, which, nwg, st) : lx_launch<1024, 0>(p, which, nwg, st);
     if (C == 512) return p.cgmap ? lx_launch<512, 1>(p, which, nwg, st) : lx_launch<512, 0>(p, which, nwg, st);
     return hipErrorInvalidValue;
+}
+
+// true: launch_lx_layer(p, 0, ...) will take lx_pw1p_kernel, which merges the LayerNorm partials itself (p.lnpart_in): the
+// caller skips the ln_merge launch for this layer
+bool lx_pw1_merges_stats(const LxLayerP& p, int C) {
+    const int nft = p.cgmap ? p.ncg : p.nft;
+    return nft > 0 && (C == 512 || C == 1024) && lx_use_pw1p(nft, (2 * p.inner) / 512);
 }
 
 hipError_t lx_layer_init_all() {
