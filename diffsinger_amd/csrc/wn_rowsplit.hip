@@ -40,6 +40,15 @@ __device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, int voff, int sof
 __device__ __forceinline__ void st4(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, soff, DSD_ST_AUX);
 }
+// The conv's z is read back by the very next launch: kept in L2 (plain).  Same-box A/B of the 50-NFE loop at B = 1, three runs
+// each (tools/ab_store.sh): x / skip write-through + z plain 16.52 ms, both write-through 16.55, x / skip plain + z
+// write-through 16.70, both plain 16.67.
+#ifndef DSD_ST_AUX_Z
+#define DSD_ST_AUX_Z 0
+#endif
+__device__ __forceinline__ void st4z(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, soff, DSD_ST_AUX_Z);
+}
 
 #ifdef DSD_STAMPS
 // [kernel 0 = conv, 1 = out][workgroup][0..6]: s_memtime at the phase boundaries; [8], [9]: s_memrealtime at the first / last
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = sigmoid_fast(g[e] + cpg[e]) * tanh_fast(f[e] + cpf[e]);      // wavenet.py:41-42
         const __amdgpu_buffer_rsrc_t r_z = rsrc(p.z + (long)bu * p.x_bstride + t0u);
-        st4(z, r_z, (gch * Ts + c4 * 4) * 4, 0);
+        st4z(z, r_z, (gch * Ts + c4 * 4) * 4, 0);
     }
     RS_STAMP(0, 4);
     RS_STAMP(0, 5);
