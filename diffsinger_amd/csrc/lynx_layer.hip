@@ -540,6 +540,202 @@ __global__ __launch_bounds__(256, 1) void lx_pw2_kernel(const LxLayerP p) {
         }
     }
 }
+// pw2 with the staging HIDDEN: K = inner is walked as NP half-phases of 512 channels through TWO 64 KiB LDS buffers; while
+// half-phase i runs from one buffer, half-phase i + 1 is fetched (one 16-byte load per thread and step over the first 16
+// steps) and written to the other (one LDS store per step over the last 16) inside the walk, so only the first 64 KiB are
+// staged with the MFMA pipe idle - lx_pw2_kernel stages 2 x 128 KiB that way, between two barriers each.
+template <int NP, int RAG>
+__global__ __launch_bounds__(256, 1) void lx_pw2d_kernel(const LxLayerP p) {
+    constexpr int KT = 512;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NS = KT / 16;
+    constexpr int NU = KT * (BN / 4) / 256;
+    float* xs = lds;                                             // (the epilogue tiles)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
+    const int work = xcd_work();
+    const int nft = RAG ? p.ncg : p.nft;
+    const int mtile = fdiv_floor(work, p.inv_nft);
+    const int ft = work - mtile * nft;
+    const int rest = RAG ? p.cgmap[ft] : ft;
+    const int b = fdiv_floor(rest, p.inv_tiles_per_b);
+    const int t0 = (rest - b * p.tiles_per_b) * BN;
+    const int Ts = p.Ts;
+    const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
+    const int mu = __builtin_amdgcn_readfirstlane(mtile);
+    constexpr int NSA = NP * KT / 16;                            // k16 steps of the whole weight stream (inner = NP * 512)
+    float* xb[2] = {lds, lds + KT * BN};                         // the two half-phase buffers
+
+    const int c4 = tid & 7;
+    const __amdgpu_buffer_rsrc_t r_v = rsrc(p.v + (long)bu * p.u_bstride + t0u);
+    const __amdgpu_buffer_rsrc_t r_w = rsrc(p.A2 + (long)(MBW * 4 * mu + MBW * wave) * NSA * 256);
+    int wk[MBW];
+#pragma unroll
+    for (int k = 0; k < MBW; ++k) wk[k] = lane * 16 + k * NSA * 1024;
+    f32x4 W[3][MBW];
+    const int xv0 = ((tid >> 3) * Ts + c4 * 4) * 4;
+    constexpr int NB4 = 8;
+    static_assert(NU == 16 && NS == 32, "one staging load per step over the first half of a walk, one store over the second");
+    auto stage0 = [&]() {                                        // half-phase 0: the only staging outside a walk
+#pragma unroll
+        for (int u0 = 0; u0 < NU; u0 += NB4) {
+            f32x4 sv[NB4];
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) sv[u] = ld4(r_v, xv0, (u0 + u) * 32 * Ts * 4);
+            if (u0 == 0) {
+#pragma unroll
+                for (int k = 0; k < MBW; ++k) {
+                    W[0][k] = ld4(r_w, wk[k], 0);
+                    W[1][k] = ld4(r_w, wk[k] + 1024, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) {
+                const int row = (tid >> 3) + 32 * (u0 + u);
+                *reinterpret_cast<f32x4*>(&xb[0][row * BN + ((c4 * 4) ^ ((row & 1) << 4))]) = sv[u];
+            }
+        }
+    };
+    f32x4 nx[NU];                                                // the next half-phase on its way through registers
+    // bias and the next layer's step-projection scalar of the workgroup's 512 rows -> LDS tables behind the tiles
+    constexpr int TBL = 2 * KT * BN;                             // behind both buffers (>= the epilogue tiles' 4 * 128 * ES)
+    static_assert(TBL >= 4 * 128 * ES, "the epilogue tiles go over the two buffers");
+    {
+        const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias2 + 512 * mu);
+        const float b0 = ld1(r_b, tid * 4, 0), b1 = ld1(r_b, tid * 4, 1024);
+        float f0 = 0.f, f1 = 0.f;
+        if (p.film) {
+            const __amdgpu_buffer_rsrc_t r_f = rsrc(p.film + p.film_col0 + bu * p.film_colb + (long)512 * mu * p.film_cstride);
+            f0 = ld1(r_f, tid * p.film_cstride * 4, 0);
+            f1 = ld1(r_f, (tid + 256) * p.film_cstride * 4, 0);
+        }
+        lds[TBL + tid] = b0;
+        lds[TBL + 256 + tid] = b1;
+        lds[TBL + 512 + tid] = f0;
+        lds[TBL + 768 + tid] = f1;
+    }
+    stage0();
+    __syncthreads();
+
+    f32x4 acc[MBW][2];
+#pragma unroll
+    for (int k = 0; k < MBW; ++k) acc[k][0] = acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sw = (lrow & 1) << 4;
+    const float* za0 = xb[0] + lrow * BN + (lcol ^ sw);
+    const float* za1 = xb[0] + lrow * BN + ((16 + lcol) ^ sw);
+    const float* zb0 = za0 + KT * BN;
+    const float* zb1 = za1 + KT * BN;
+    // epilogue operands, row-major float4 over the wave's 128 rows (lane -> row (lane >> 3) + 8 m, frames 4 (lane & 7)):
+    // residual x, the next layer's conditioner projection; and per row its bias and step-projection scalar
+    const int row0 = 512 * mu + 128 * wave;
+    const int ev0 = ((lane >> 3) * Ts + (lane & 7) * 4) * 4;
+    const __amdgpu_buffer_rsrc_t r_a = rsrc(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    const __amdgpu_buffer_rsrc_t r_c = rsrc((p.cpn ? p.cpn : p.x) + (long)bu * (p.cpn ? p.cpn_bstride : p.x_bstride) + (long)row0 * Ts + t0u);
+    f32x4 aux[16], cpv[16];
+    auto tail_loads = [&](int s) {
+        if (s < 16) aux[s] = ld4(r_a, ev0, s * 8 * Ts * 4);
+        else if (s < 32) cpv[s - 16] = ld4(r_c, ev0, (s - 16) * 8 * Ts * 4);
+    };
+    // half-phase ph + 1 travels inside half-phase ph's walk: loads over steps 0..15, LDS stores over steps 16..31
+    auto carry = [&](int ph, int s) {
+        if (s < NU) {
+            nx[s] = ld4(r_v, xv0, ((ph + 1) * KT + s * 32) * Ts * 4);
+        } else {
+            const int u = s - NU;
+            const int row = (tid >> 3) + 32 * u;
+            *reinterpret_cast<f32x4*>(&xb[(ph + 1) & 1][row * BN + ((c4 * 4) ^ ((row & 1) << 4))]) = nx[u];
+        }
+    };
+    // (the weight rotation continues across the half-phases: ROT = 32 ph mod 3)
+    k_phase<KT, 0, true>(acc, W, r_w, wk, 0, za0, za1, [&](int s) { carry(0, s); });
+    __syncthreads();                                             // buffer 1 complete; every wave is done with buffer 0
+    if (NP == 2) {
+        k_phase<KT, 2, false>(acc, W, r_w, wk, NS, zb0, zb1, tail_loads);
+    } else {
+        k_phase<KT, 2, true>(acc, W, r_w, wk, NS, zb0, zb1, [&](int s) { carry(1, s); });
+        __syncthreads();
+        k_phase<KT, 1, true>(acc, W, r_w, wk, 2 * NS, za0, za1, [&](int s) { carry(2, s); });
+        __syncthreads();
+        k_phase<KT, 0, false>(acc, W, r_w, wk, 3 * NS, zb0, zb1, tail_loads);
+    }
+    __syncthreads();                                             // the buffers are dead: the epilogue tiles go over them
+    const float* tb = lds + TBL;                                 // bias and step-projection scalar of the workgroup's 512 rows
+    const float* tf = tb + 512;
+
+    // ---------------- transition (gemm.hip EP_LYNX_NEXT; lynxnet.py:76-84 of the next layer), row-major ----------------
+    float* ew = xs + wave * (128 * ES);                          // wave-private [128 rows][ES]: 18 KiB x 4 waves
+#pragma unroll
+    for (int k = 0; k < MBW; ++k)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ew[(k * 16 + rq + r) * ES + n * 16 + lcol] = acc[k][n][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const __amdgpu_buffer_rsrc_t r_xo = rsrc(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    const __amdgpu_buffer_rsrc_t r_xi = rsrc((p.xin_out ? p.xin_out : p.x) + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    f32x4 xi[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int idx = lane + 64 * m;
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]);
+        const float brow = tb[128 * wave + (idx >> 3)], frow = tf[128 * wave + (idx >> 3)];
+        f32x4 xo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = (a4[e] + brow) + aux[m][e];              // + bias, + residual (lynxnet.py:86)
+            float o = v, in = v;
+            if (p.cpn) {
+                in = v + cpv[m][e];
+                if (p.strong) o = in;
+            }
+            if (p.film) in = in + frow;
+            xo[e] = o;
+            xi[m][e] = in;
+        }
+        st4(xo, r_xo, ev0, m * 8 * Ts * 4);
+        if (p.xin_out) st4(xi[m], r_xi, ev0, m * 8 * Ts * 4);
+    }
+    // LayerNorm partials of xin per 64-row tile (tiles 2w, 2w + 1 of this workgroup's 8): two passes over the registers.
+    // A frame's 64 rows sit in 8 slots m of the 8 lanes with equal (lane & 7): sum over m, then over lanes 8, 16, 32 apart.
+    if (p.lnpart) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 8; ++m) s += xi[8 * h + m];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += __shfl_xor(s[e], 8, 64);
+                s[e] += __shfl_xor(s[e], 16, 64);
+                s[e] += __shfl_xor(s[e], 32, 64);
+            }
+            const f32x4 mu4 = s * (1.f / 64.f);
+            f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const f32x4 d = xi[8 * h + m] - mu4;
+                q += d * d;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                q[e] += __shfl_xor(q[e], 8, 64);
+                q[e] += __shfl_xor(q[e], 16, 64);
+                q[e] += __shfl_xor(q[e], 32, 64);
+            }
+            if (lane < 8) {
+                const int tile = 8 * mu + 2 * wave + h;
+                float* lp = p.lnpart + ((long)bu * p.ln_tiles + tile) * 2 * p.lnpart_ts + t0u + lane * 4;
+                *reinterpret_cast<f32x4*>(lp) = mu4;
+                *reinterpret_cast<f32x4*>(lp + p.lnpart_ts) = q;
+            }
+        }
+    }
+}
 #undef LX_SPREAD
 
 int lx_lds_bytes(int kt) { return (kt * 32 * 4 > 4 * 128 * 36 * 4 ? kt * 32 * 4 : 4 * 128 * 36 * 4) + 1024 * 4; }
@@ -620,6 +816,19 @@ static hipError_t lx_launch(const LxLayerP& p, int which, int nwg, hipStream_t s
     return hipGetLastError();
 }
 
+template <int NP, int RAG>
+static hipError_t lx_launch_pw2d(const LxLayerP& p, int nwg, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = lx_attr(lx_pw2d_kernel<NP, RAG>);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    if (nwg == 0) return hipSuccess;
+    hipLaunchKernelGGL((lx_pw2d_kernel<NP, RAG>), dim3(nwg), dim3(256), (2 * 512 * 32 + 1024) * 4, st, p);
+    return hipGetLastError();
+}
+
 // which = 0: pw1 (LayerNorm -> C -> 2 inner -> SwiGLU);  1: pw2 (inner -> C + residual + next-layer transition)
 hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st) {
     const int nft = p.cgmap ? p.ncg : p.nft;
@@ -630,6 +839,13 @@ hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st) 
                      : C == 512 ? (p.cgmap ? lx_launch_pw1p<512, 1>(p, nft, st) : lx_launch_pw1p<512, 0>(p, nft, st))
                                 : hipErrorInvalidValue;
         if (nft != 0 || e != hipSuccess) return e;
+    }
+    // pw2 with double-buffered 512-channel half-phases (inner = 1024 or 2048); DSD_LYNX_PW2D=0: the two-phase form
+    static const int pw2d = getenv("DSD_LYNX_PW2D") ? atoi(getenv("DSD_LYNX_PW2D")) : -1;
+    if (which == 1 && pw2d != 0 && (p.inner == 2048 || p.inner == 1024) && (C == 1024 || C == 512)) {
+        hipError_t e = p.inner == 2048 ? (p.cgmap ? lx_launch_pw2d<4, 1>(p, nwg, st) : lx_launch_pw2d<4, 0>(p, nwg, st))
+                                       : (p.cgmap ? lx_launch_pw2d<2, 1>(p, nwg, st) : lx_launch_pw2d<2, 0>(p, nwg, st));
+        if (nwg != 0 || e != hipSuccess) return e;
     }
     if (C == 1024) return p.cgmap ? lx_launch<1024, 1>(p, which, nwg, st) : lx_launch<1024, 0>(p, which, nwg, st);
     if (C == 512) return p.cgmap ? lx_launch<512, 1>(p, which, nwg, st) : lx_launch<512, 0>(p, which, nwg, st);
