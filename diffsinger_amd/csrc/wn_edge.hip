@@ -20,6 +20,24 @@ namespace dsd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef DSD_STAMPS
+// [launch with / without a fused input projection][workgroup][0..9]: s_memtime at the phase boundaries (wave 0)
+__device__ unsigned long long g_edge_stamps[2][4096][16];
+#define EDGE_STAMP(i)                                                                          \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            g_edge_stamps[p.next_src >= 0 ? 1 : 0][blockIdx.x][i] = __builtin_amdgcn_s_memtime(); \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+        }                                                                                      \
+    } while (0)
+extern "C" int dsd_dbg_read_edge_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_edge_stamps), sizeof(g_edge_stamps));
+}
+#else
+#define EDGE_STAMP(i)
+#endif
+
 namespace {
 
 __device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
@@ -127,6 +145,7 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
     const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
     auto swz = [](int row) { return NCB == 2 ? ((row & 1) << 4) : 0; };
     const int wl = lane * 16;
+    EDGE_STAMP(0);
 
     // ---------------- prologue loads: the skip tile, the first product's first weight steps, the solver's state terms ----------------
     const __amdgpu_buffer_rsrc_t r_s = rsrc(p.skip + (long)bu * p.x_bstride + t0u);
@@ -146,12 +165,40 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
     // The solver's linear combinations (gemm.hip EP_LINCOMB) WITHOUT their model term: sums over the state buffers / noise
     // tensors as they are BEFORE this evaluation (a destination may be another output's source), formed here from whole-line
     // 16-byte loads that fly under the first product, kept row-major in LDS; eps joins after the second product.
+    // (every descriptor the kernel will need is copied out of the argument block in ONE batch of scalar loads here: fetched
+    // where they are used - inside uniform branches - each cost its own round trip; the stamps showed 9 k cycles of prologue)
+    EdgeTerm tq[kEdgeMaxTerms];
+#pragma unroll
+    for (int q = 0; q < kEdgeMaxTerms; ++q) tq[q] = p.q[q];
+    float cmv[kMaxOut];
+    float* dstv[kMaxOut];
+#pragma unroll
+    for (int o = 0; o < kMaxOut; ++o) {
+        cmv[o] = p.cm[o];
+        dstv[o] = p.dst[o];
+    }
+    const int nq = p.nq, nout = p.nout, next_src = p.next_src;
+    // (pinned: an empty asm that takes the values in SGPRs here - otherwise the compiler sinks each scalar load back to its
+    // use inside the branch and waits for it there, eight round trips in a row)
+#pragma unroll
+    for (int q = 0; q < kEdgeMaxTerms; ++q)
+        asm volatile("" ::"s"(tq[q].ptr), "s"(tq[q].bstride), "s"(tq[q].rstride), "s"(tq[q].coef), "s"(tq[q].out));
+#pragma unroll
+    for (int o = 0; o < kMaxOut; ++o) asm volatile("" ::"s"(cmv[o]), "s"(dstv[o]));
+    asm volatile("" ::"s"(nq), "s"(nout), "s"(next_src));
+    // the output projection's bias in the accumulator layout (F*M is a whole number of 16-row blocks)
+    f32x4 b2v[MB2];
+    {
+        const __amdgpu_buffer_rsrc_t r_b2 = rsrc(p.b2);
+#pragma unroll
+        for (int k = 0; k < MB2; ++k) b2v[k] = ld4(r_b2, (min((wave * MB2 + k) * 16, p.FM - 16) + rq) * 4, 0);
+    }
     {
         f32x4 tv[kEdgeMaxTerms][NP];
 #pragma unroll
         for (int q = 0; q < kEdgeMaxTerms; ++q) {
-            if (q < p.nq) {                                      // workgroup-uniform
-                const EdgeTerm tm = p.q[q];
+            if (q < nq) {                                        // workgroup-uniform
+                const EdgeTerm tm = tq[q];
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
                     const int idx = tid + 256 * u;
@@ -169,9 +216,9 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
             for (int u = 0; u < NP; ++u) ps[o][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < kEdgeMaxTerms; ++q) {
-            if (q < p.nq) {
-                const float cf = p.q[q].coef;
-                const int o = p.q[q].out;
+            if (q < nq) {
+                const float cf = tq[q].coef;
+                const int o = tq[q].out;
 #pragma unroll
                 for (int oo = 0; oo < kMaxOut; ++oo)
                     if (oo == o) {
@@ -182,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
         }
 #pragma unroll
         for (int o = 0; o < kMaxOut; ++o) {
-            if (o < p.nout) {
+            if (o < nout) {
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
                     const int idx = tid + 256 * u;
@@ -191,6 +238,7 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
             }
         }
     }
+    EDGE_STAMP(1);
     // skip / sqrt(L) (wavenet.py:96; the division of gemm.hip's ST_SCALE stage) -> LDS
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -201,6 +249,7 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
         *reinterpret_cast<f32x4*>(&sT[row * BNW + ((c4s * 4) ^ swz(row))]) = o;
     }
     __syncthreads();
+    EDGE_STAMP(2);
     const int sw = swz(lrow);
     const float* zs[NCB];
     const float* zh[NCB];
@@ -230,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
 #pragma unroll
         for (int k = 0; k < MB1; ++k) bo[k] = ld4(r_b, ((wave * MB1 + k) * 16 + rq) * 4, 0);
         edge_walk<MB1, NS1, NCB, D1>(acc, W1, r_w1, wk1, zs);
+        EDGE_STAMP(3);
         if (act2) edge_prefetch<MB2, D2>(W2, r_w2, wk2);
 #pragma unroll
         for (int k = 0; k < MB1; ++k)
@@ -242,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
                 }
     }
     __syncthreads();                                             // h complete; the skip tile is dead
+    EDGE_STAMP(4);
 
     // the third product's weight stream (first steps fetched under the solver update)
     const __amdgpu_buffer_rsrc_t r_w3 = rsrc(p.A3);
@@ -258,11 +309,12 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
 #pragma unroll
             for (int n = 0; n < NCB; ++n) acc[k][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         edge_walk<MB2, NS1, NCB, D2>(acc, W2, r_w2, wk2, zh);
-        if (p.next_src >= 0) edge_prefetch<MB1, D3>(W3, r_w3, wk3);
+        EDGE_STAMP(5);
+        if (next_src >= 0) edge_prefetch<MB1, D3>(W3, r_w3, wk3);
 #pragma unroll
         for (int o = 0; o < kMaxOut; ++o) {
-            if (o < p.nout) {
-                const float cm = p.cm[o];
+            if (o < nout) {
+                const float cm = cmv[o];
                 float* po = pT + o * K3 * PS;
 #pragma unroll
                 for (int k = 0; k < MB2; ++k)
@@ -271,11 +323,11 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = (wave * MB2 + k) * 16 + rq + r;
-                            const float ev = acc[k][n][r] + (row < p.FM ? p.b2[min(row, p.FM - 1)] : 0.f);
+                            const float ev = acc[k][n][r] + b2v[k][r];
                             float* q = &po[row * PS + n * 16 + lcol];
-                            const float v = row < p.FM ? *q + cm * ev : 0.f;
+                            const float v = *q + cm * ev;
                             *q = v;
-                            if (o == p.next_src) sT[row * BNW + ((n * 16 + lcol) ^ swz(row))] = v;      // rows >= F*M: zero (padded K)
+                            if (o == next_src) sT[row * BNW + ((n * 16 + lcol) ^ swz(row))] = v;
                         }
             }
         }
@@ -285,9 +337,9 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
         constexpr int NE2 = MB2 * 16 * W4 / 64;                  // float4 per lane over the wave's F*M rows
 #pragma unroll
         for (int o = 0; o < kMaxOut; ++o) {
-            if (o < p.nout) {
+            if (o < nout) {
                 const float* po = pT + (o * K3 + wave * MB2 * 16) * PS;
-                const __amdgpu_buffer_rsrc_t r_d = rsrc(p.dst[o] + (long)bu * p.o_bstride + (long)(wave * MB2 * 16) * p.o_rstride + t0u);
+                const __amdgpu_buffer_rsrc_t r_d = rsrc(dstv[o] + (long)bu * p.o_bstride + (long)(wave * MB2 * 16) * p.o_rstride + t0u);
 #pragma unroll
                 for (int m = 0; m < NE2; ++m) {
                     const int idx = lane + 64 * m;
@@ -297,11 +349,13 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
                 }
             }
         }
-    } else if (p.next_src >= 0) {
+    } else if (next_src >= 0) {
         edge_prefetch<MB1, D3>(W3, r_w3, wk3);
     }
-    if (p.next_src < 0) return;                                  // (workgroup-uniform) no input projection to fuse
-    __syncthreads();                                             // x' complete; every wave is past the h tile and the LDS sums
+    EDGE_STAMP(6);
+    if (next_src < 0) return;                                  // (workgroup-uniform) no input projection to fuse
+    __syncthreads();
+    EDGE_STAMP(7);                                             // x' complete; every wave is past the h tile and the LDS sums
 
     // ---------------- x0 = relu(W3 x' + b3): the next evaluation's layer-0 input ----------------
     {
@@ -315,6 +369,7 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
 #pragma unroll
         for (int k = 0; k < MB1; ++k) bo[k] = ld4(r_b, ((wave * MB1 + k) * 16 + rq) * 4, 0);
         edge_walk<MB1, NS3, NCB, D3>(acc, W3, r_w3, wk3, zs);
+        EDGE_STAMP(8);
         // accumulators -> the wave's own rows of a row-major tile over the dead h tile -> 16-byte stores of whole row pieces
         float* ew = hT + wave * (MB1 * 16) * PS;
 #pragma unroll
@@ -336,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
             st4(*reinterpret_cast<const f32x4*>(&ew[row * PS + cc]), r_xo, (row * Ts + cc) * 4, 0);
         }
     }
+    EDGE_STAMP(9);
 }
 
 int wn_edge_lds_bytes(int C, int fmb, int ncb) {

@@ -46,6 +46,34 @@ with torch.no_grad():
     for _ in range(20):         # the stamps of the LAST layer launch survive; the chip is warm by then
         net(x, t, c)
 torch.cuda.synchronize()
+if "--edge" in sys.argv:        # whole sampler loops: every evaluation but the last fuses the next one's input projection
+    from diffsinger_amd.diffusion import GaussianDiffusion
+    hparams.update(schedule_type="linear", use_shallow_diffusion=False, diff_accelerator="ddim", diff_speedup=500, K_step_infer=1000)
+    dd = GaussianDiffusion(128, 1, backbone_type="wavenet", backbone_args=bargs, spec_min=[-12.0], spec_max=[0.0])
+    dd.denoise_fn.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    dd = dd.cuda().eval()
+    dd.use_graph = False
+    cond = torch.randn(B, T, 256, device="cuda")
+    dd(cond, infer=True)
+    torch.cuda.synchronize()
+if "--edge" in sys.argv:
+    # wn_edge_kernel, the launch around the layers (batched grids): the last launch of each kind survives
+    buf3 = np.zeros((2, 4096, 16), dtype=np.uint64)
+    assert _lib.lib().dsd_dbg_read_edge_stamps(buf3.ctypes.data_as(C.c_void_p)) == 0
+    labels = ["prologue: loads issued, solver sums formed -> LDS", "skip tile / sqrt(L) -> LDS, barrier", "product 1 (C x C)",
+              "relu + bias -> h tile, barrier", "product 2 (F*M x C)", "outputs = sums + c eps, x' -> LDS, row stores",
+              "barrier", "product 3 (C x F*M)", "relu + bias -> tile -> row stores"]
+    for kind, n in ((1, 10), (0, 7)):
+        st = buf3[kind].astype(np.int64)
+        st = st[st[:, 0] > 0]
+        if not len(st):
+            continue
+        d = np.diff(st[:, :n], axis=1)
+        life = st[:, n - 1] - st[:, 0]
+        print(f"wn_edge_kernel {'with' if kind else 'without'} the next input projection: {len(st)} workgroups; mean life {life.mean():.0f} cycles")
+        for lb, m, mn, mx in zip(labels, d.mean(axis=0), d.min(axis=0), d.max(axis=0)):
+            print(f"    {lb:58s} mean {m:8.0f}  min {mn:8.0f}  max {mx:8.0f}")
+    sys.exit(0)
 if ROWSPLIT:
     buf2 = np.zeros((2, 4096, 10), dtype=np.uint64)
     assert _lib.lib().dsd_dbg_read_rs_stamps(buf2.ctypes.data_as(C.c_void_p)) == 0
