@@ -23,6 +23,16 @@ namespace dsd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef DSD_STAMPS
+// lx_pw1p_kernel, wave 0 of each workgroup: [0] start, [1] activation tile staged (after the barrier), [2] sum over the row
+// tiles of the walk's cycles, [3] sum of the epilogues' cycles, [4] end
+__device__ unsigned long long g_lx_stamps[4096][8];
+extern "C" int dsd_dbg_read_lx_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lx_stamps), sizeof(g_lx_stamps));
+}
+#define LX_T() ([]() { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); return t_; }())
+#endif
+
 namespace {
 
 __device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
@@ -250,6 +260,9 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
     const int Ts = p.Ts;
     const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
     const int nmt = (2 * p.inner) / 512;                          // row tiles of 256 u channels (512 packed rows)
+#ifdef DSD_STAMPS
+    unsigned long long st0 = LX_T(), st1 = 0, swalk = 0, sepi = 0;
+#endif
 
     const int c4 = tid & 7;
     // LayerNorm statistics of the tile's frames: this workgroup is the only reader of its 32 frames, so it merges the
@@ -310,6 +323,9 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
         }
     }
     __syncthreads();                                             // the only workgroup barrier
+#ifdef DSD_STAMPS
+    st1 = LX_T();
+#endif
 
     const int sw = (lrow & 1) << 4;
     const float* zt0 = xs + lrow * BN + (lcol ^ sw);
@@ -326,9 +342,16 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
         for (int k = 0; k < MBW; ++k) acc[k][0] = acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int ch0 = 256 * mt + 64 * wave;                    // first u channel of this wave in this row tile
         f32x4 bo[MBW];
+#ifdef DSD_STAMPS
+        const unsigned long long ta = LX_T();
+#endif
         k_phase<KT, 0, false>(acc, W, r_w, wk, 0, zt0, zt1, [&](int s) {
             if (s < MBW) bo[s] = ld4(r_b, rq * 4, ((s & 1) * p.inner + ch0 + (s >> 1) * 16) * 4);
         });
+#ifdef DSD_STAMPS
+        const unsigned long long tb = LX_T();
+        swalk += tb - ta;
+#endif
         if (mt + 1 < nmt) {                                      // the next row tile's steps 0 and 1 land under the epilogue
             const __amdgpu_buffer_rsrc_t r_n = rsrc(p.A1 + (mt + 1) * kMtBlocks + (long)(MBW * wave) * NS * 256);
 #pragma unroll
@@ -365,7 +388,19 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
             __builtin_amdgcn_wave_barrier();                     // the tile is read before the next half overwrites it
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+#ifdef DSD_STAMPS
+        sepi += LX_T() - tb;
+#endif
     }
+#ifdef DSD_STAMPS
+    if (tid == 0 && blockIdx.x < 4096) {
+        g_lx_stamps[blockIdx.x][0] = st0;
+        g_lx_stamps[blockIdx.x][1] = st1;
+        g_lx_stamps[blockIdx.x][2] = swalk;
+        g_lx_stamps[blockIdx.x][3] = sepi;
+        g_lx_stamps[blockIdx.x][4] = LX_T();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
