@@ -20,6 +20,12 @@ enum Stage { ST_PLAIN = 0, ST_FILM = 1, ST_LN = 2, ST_SCALE = 3, ST_LRELU = 4 };
 enum Epi { EP_BIAS_ACT = 0, EP_GATE = 1, EP_RESSKIP = 2, EP_LINCOMB = 3, EP_SWIGLU = 4, EP_BIAS_RES = 5, EP_SCATTER = 6, EP_LYNX_NEXT = 7 };
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3, ACT_LRELU = 4, ACT_TANH = 5, ACT_SILU = 6 };
 
+// lx_pw1_kernel (LYNXNet pw1, one workgroup per (frame tile, row tile)) merges the LayerNorm partials in its prologue like
+// lx_pw1p_kernel does (1) or reads ln_merge_kernel's statistics (0: A/B builds)
+#ifndef DSD_LX_PW1_MERGE
+#define DSD_LX_PW1_MERGE 1
+#endif
+
 // Cache policy of the WaveNet layer kernels' 16-byte result stores (raw buffer intrinsics: bit 4 = sc1 = write-through).
 // A kernel boundary costs the bytes its predecessor left dirty in the L2s / ~6 TB/s (MI355X_MICROARCH.md, "boundary":
 // x + skip of a fused layer at B = 8 are 16 MB); write-through stores spread that over the kernel's own epilogues.

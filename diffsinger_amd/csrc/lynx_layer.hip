@@ -130,6 +130,34 @@ __device__ __forceinline__ void k_phase(f32x4 (&acc)[MBW][2], f32x4 (&W)[3][MBW]
 
 }  // namespace
 
+// LayerNorm statistics of a tile's 32 frames from the producer's per-64-row partials (mean_i, M2_i): ln_merge_kernel's arithmetic
+// in ln_merge_kernel's order (tiles ascending; parallel-variance formula), every thread for its own four frames c4 * 4 .. + 3,
+// all 2 * KT / 64 partial vectors in flight at once (a run-time loop here serialised 48 load round trips: + 1.4 % on config 3)
+template <int KT>
+__device__ __forceinline__ void lx_merge_stats(const LxLayerP& p, int bu, int t0u, int c4, f32x4& mean, f32x4& rstd) {
+    constexpr int NT = KT / 64;                                  // 64-row tiles of xin (= p.ln_tiles)
+    const __amdgpu_buffer_rsrc_t r_p = rsrc(p.lnpart_in + (long)bu * NT * 2 * p.lnpart_ts + t0u);
+    f32x4 pm[NT], pq[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        pm[i] = ld4(r_p, c4 * 16, i * 2 * p.lnpart_ts * 4);
+        pq[i] = ld4(r_p, c4 * 16, (i * 2 + 1) * p.lnpart_ts * 4);
+    }
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NT; ++i) s += 64.f * pm[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mean[e] = s[e] / (float)KT;
+    f32x4 m2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const f32x4 d = pm[i] - mean;
+        m2 += pq[i] + 64.f * d * d;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(m2[e] / (float)KT + 1e-5f);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // pw1: LayerNorm -> 1x1 C -> 2 * inner -> SwiGLU.  KT = C (512 or 1024); packed rows: pairs (out row r, gate row r + inner)
 // interleaved per 16-row block (PackedGemm with pairC = inner): even block = out, odd = gate of 16 channels.
@@ -159,8 +187,17 @@ __global__ __launch_bounds__(256, 1) void lx_pw1_kernel(const LxLayerP p) {
 
     // ---------------- prologue: LayerNorm statistics of the tile's frames, the activation tile, two weight steps ----------------
     const int c4 = tid & 7;                                      // the thread's frames 4 c4 .. 4 c4 + 3, for every staged row
-    const __amdgpu_buffer_rsrc_t r_s = rsrc(p.stats + (long)bu * 2 * Ts + t0u);
-    const f32x4 mean = ld4(r_s, c4 * 16, 0), rstd = ld4(r_s, c4 * 16, Ts * 4);
+    // (the 2 * inner / 512 row-tile workgroups of a frame tile each repeat this small merge: cheaper than a launch of its own)
+    f32x4 mean, rstd;
+#if DSD_LX_PW1_MERGE
+    lx_merge_stats<KT>(p, bu, t0u, c4, mean, rstd);
+#else
+    {
+        const __amdgpu_buffer_rsrc_t r_s = rsrc(p.stats + (long)bu * 2 * Ts + t0u);
+        mean = ld4(r_s, c4 * 16, 0);
+        rstd = ld4(r_s, c4 * 16, Ts * 4);
+    }
+#endif
     const __amdgpu_buffer_rsrc_t r_x = rsrc(p.xin + (long)bu * p.x_bstride + t0u);
     const __amdgpu_buffer_rsrc_t r_w = rsrc(p.A1 + (long)(MBW * 4 * mu + MBW * wave) * NS * 256);
     int wk[MBW];
@@ -269,30 +306,10 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
     // producer's per-64-row partials (mean_i, M2_i) itself - ln_merge_kernel's arithmetic in ln_merge_kernel's order (tiles
     // in ascending order; parallel-variance formula), every thread for its own four frames - and no merge launch runs
     // between the layers
+    // LayerNorm statistics of the tile's frames: this workgroup is the only reader of its 32 frames and merges the producer's
+    // partials itself - no merge launch runs between the layers
     f32x4 mean, rstd;
-    {
-        constexpr int NT = KT / 64;                              // 64-row tiles of xin (= p.ln_tiles)
-        const __amdgpu_buffer_rsrc_t r_p = rsrc(p.lnpart_in + (long)bu * NT * 2 * p.lnpart_ts + t0u);
-        f32x4 pm[NT], pq[NT];                                    // every partial in flight at once: one memory latency
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            pm[i] = ld4(r_p, c4 * 16, i * 2 * p.lnpart_ts * 4);
-            pq[i] = ld4(r_p, c4 * 16, (i * 2 + 1) * p.lnpart_ts * 4);
-        }
-        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NT; ++i) s += 64.f * pm[i];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mean[e] = s[e] / (float)KT;
-        f32x4 m2 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const f32x4 d = pm[i] - mean;
-            m2 += pq[i] + 64.f * d * d;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(m2[e] / (float)KT + 1e-5f);
-    }
+    lx_merge_stats<KT>(p, bu, t0u, c4, mean, rstd);
     const __amdgpu_buffer_rsrc_t r_x = rsrc(p.xin + (long)bu * p.x_bstride + t0u);
     const __amdgpu_buffer_rsrc_t r_w0 = rsrc(p.A1 + (long)(MBW * wave) * NS * 256);
     int wk[MBW];
@@ -898,6 +915,7 @@ hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st) 
 // caller skips the ln_merge launch for this layer
 bool lx_pw1_merges_stats(const LxLayerP& p, int C) {
     const int nft = p.cgmap ? p.ncg : p.nft;
+    if (DSD_LX_PW1_MERGE) return C == 512 || C == 1024;          // both forms of pw1 merge the partials in their prologue
     return nft > 0 && (C == 512 || C == 1024) && lx_use_pw1p(nft, (2 * p.inner) / 512);
 }
 
