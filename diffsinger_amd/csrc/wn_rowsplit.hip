@@ -67,6 +67,21 @@ __device__ unsigned long long g_rs_stamps[2][4096][10];
 #define RS_STAMP(K, i)
 #endif
 
+// Every field of the argument block in SGPRs behind ONE batch of scalar loads at the top of the kernel: left to itself the
+// compiler fetches them in two or three dependent batches (each a cold scalar-cache round trip) before the first vector load
+// can issue - on kernels whose whole life is 8-20 k cycles.  -DDSD_RS_PIN_ARGS=0: A/B build.
+#ifndef DSD_RS_PIN_ARGS
+#define DSD_RS_PIN_ARGS 1
+#endif
+__device__ __forceinline__ void rs_pin_args(const WnLayerP& p) {
+#if DSD_RS_PIN_ARGS
+    asm volatile("" ::"s"(p.Aconv), "s"(p.Aout), "s"(p.bias_out), "s"(p.xin), "s"(p.xout), "s"(p.skip), "s"(p.z), "s"(p.x_bstride),
+                 "s"(p.Ts), "s"(p.cp), "s"(p.cp_bstride), "s"(p.film), "s"(p.film_cstride), "s"(p.film_col0), "s"(p.film_colb),
+                 "s"(p.dil), "s"(p.T), "s"(p.tiles_per_b), "s"(p.first_layer), "s"(p.inv_tiles_per_b),
+                 "s"((int)gridDim.x));                           // (the grid size is an implicit argument: same segment)
+#endif
+}
+
 constexpr int DEPTH = 6;        // weight fragments in rotation: step s runs from W[s % 6], step s + 5 is in flight
 
 // XCD-aware bijective remap (speed only): an XCD takes a contiguous range of work items, row tile fastest, so the row
@@ -108,6 +123,7 @@ constexpr int NCH = 4, C = 256, MT = 8, BN = 32, ES = 36;
 template <int SW, int RAG>
 __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    rs_pin_args(p);
     constexpr int HL = SW == 48 ? 8 : 16;
     constexpr int W4 = (BN + 2 * HL) / 4;
     constexpr int NE = 128 * W4 / 512;              // float4 per thread of two 64-channel chunks: 3 (SW 48), 4 (SW 80)
@@ -260,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
 template <int RAG>
 __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    rs_pin_args(p);
     constexpr int SZ = 48;
     constexpr int NZ = C * (BN / 4) / 512;          // staged float4 per thread: 4
     constexpr int NS = NCH * 4;
