@@ -123,7 +123,9 @@ constexpr int NCH = 4, C = 256, MT = 8, BN = 32, ES = 36;
 template <int SW, int RAG>
 __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    RS_STAMP(0, 6);                                              // (diagnostic builds: before any argument is touched ...
     rs_pin_args(p);
+    RS_STAMP(0, 7);                                              //  ... and with all of them in SGPRs)
     constexpr int HL = SW == 48 ? 8 : 16;
     constexpr int W4 = (BN + 2 * HL) / 4;
     constexpr int NE = 128 * W4 / 512;              // float4 per thread of two 64-channel chunks: 3 (SW 48), 4 (SW 80)

@@ -93,6 +93,10 @@ if ROWSPLIT:
               f"{np.median(life / np.maximum(real, 1e-12) / 1e9):.3f} GHz -> {np.median(real) * 1e6:.2f} us per workgroup")
         for lb, m, mn, mx in zip(labels, d.mean(axis=0), d.min(axis=0), d.max(axis=0)):
             print(f"    {lb:62s} mean {m:8.0f}  min {mn:8.0f}  max {mx:8.0f}")
+        if k == 0 and (st[:, 7] > 0).all():
+            e = st[:, 7] - st[:, 6]
+            print(f"    kernel entry -> every argument in SGPRs (one batch of scalar loads): mean {e.mean():6.0f}  min {e.min():6.0f}  max {e.max():6.0f};"
+                  f"  then {np.mean(st[:, 0] - st[:, 7]):6.0f} until the first phase stamp")
     sys.exit(0)
 buf = np.zeros((4096, 10), dtype=np.uint64)
 rc = _lib.lib().dsd_dbg_read_wn_stamps(buf.ctypes.data_as(C.c_void_p))
