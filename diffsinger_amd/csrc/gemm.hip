@@ -31,6 +31,10 @@
 
 #include "dsd_internal.h"
 
+#ifndef DSD_GEMM_PIN_ARGS
+#define DSD_GEMM_PIN_ARGS 1
+#endif
+
 namespace dsd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -130,6 +134,17 @@ __device__ __forceinline__ void ring_load_s(f32x4& dst, unsigned voff, unsigned 
 template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2, int RAG = 0>
 __global__ __launch_bounds__(256, (SW > 0 && NB * WN == 4) ? 3 : 1) void gemm_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#if DSD_GEMM_PIN_ARGS
+    // the header of the ~1 KB argument block in SGPRs behind ONE batch of scalar loads (as wn_rowsplit.hip's rs_pin_args: left
+    // alone the fields arrive in several dependent, cold round trips before the first vector load - on 5 us kernels)
+    asm volatile("" ::"s"(p.A), "s"(p.bias), "s"(p.M), "s"(p.C), "s"(p.B), "s"(p.b_bstride), "s"(p.b_rstride), "s"(p.K), "s"(p.T),
+                 "s"(p.tiles_per_b), "s"(p.mtiles), "s"(p.inv_mtiles), "s"(p.inv_tiles_per_b), "s"(p.inv_w4), "s"(p.gm_shift),
+                 "s"(p.lpr_shift), "s"(p.dil), "s"(p.HL), "s"(p.in_scale), "s"(p.film), "s"(p.film_cstride), "s"(p.film_col0),
+                 "s"(p.film_colb), "s"(p.act), "s"(p.out), "s"(p.o_bstride), "s"(p.o_rstride), "s"((int)gridDim.x));
+    if (EPI == EP_GATE || EPI == EP_BIAS_RES || EPI == EP_LYNX_NEXT) asm volatile("" ::"s"(p.aux), "s"(p.aux_bstride), "s"(p.aux_rstride));
+    if (EPI == EP_RESSKIP) asm volatile("" ::"s"(p.x), "s"(p.skip), "s"(p.first_layer));
+    if (EPI == EP_LINCOMB) asm volatile("" ::"s"(p.nout));
+#endif
     static_assert(WN == 2 || (WN == 1 && SW > 0 && EPI != EP_SWIGLU && STAGE != ST_LN), "4x1 wave layout: fast path only");
     static_assert(SW == 0 || (STAGE != ST_LRELU && EPI != EP_SCATTER), "leaky-ReLU staging / scatter epilogue: generic path");
     static_assert(EPI != EP_LYNX_NEXT || WN == 2, "LYNXNet transition epilogue: 2 x 2 wave layout");
