@@ -70,6 +70,9 @@ __device__ unsigned long long g_rs_stamps[2][4096][10];
 // Every field of the argument block in SGPRs behind ONE batch of scalar loads at the top of the kernel: left to itself the
 // compiler fetches them in two or three dependent batches (each a cold scalar-cache round trip) before the first vector load
 // can issue - on kernels whose whole life is 8-20 k cycles.  -DDSD_RS_PIN_ARGS=0: A/B build.
+#ifndef DSD_RS_FILM4
+#define DSD_RS_FILM4 1
+#endif
 #ifndef DSD_RS_PIN_ARGS
 #define DSD_RS_PIN_ARGS 1
 #endif
@@ -153,7 +156,12 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
     // ---------------- prologue: the chunks the first 12 steps of either half read (0 and 2), FiLM vector, weights ----------------
     const __amdgpu_buffer_rsrc_t r_x = rsrc(p.xin + (long)bu * p.x_bstride + (t0u - HL));
     const __amdgpu_buffer_rsrc_t r_f = rsrc(p.film + p.film_col0 + bu * p.film_colb);
+#if DSD_RS_FILM4
+    float fmine = 0.f;                                           // 256 values: the first four waves fetch them (wave-uniform branch)
+    if (wave < 4) fmine = ld1(r_f, tid * p.film_cstride * 4, 0);
+#else
     const float fmine = ld1(r_f, (tid & 255) * p.film_cstride * 4, 0);
+#endif
     // staging slot u of a thread: float4 (row, c4) of a 128-row set; `late` = 0: chunks 0 and 2 (rows [0,64) + [128,192)),
     // 1: chunks 1 and 3 - fetched one float4 per step behind the first steps' MFMAs, written to LDS after step 11
     auto x_row = [&](int u, int late) {
@@ -175,7 +183,11 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
 #pragma unroll
     for (int s = 0; s < DEPTH - 1; ++s) W[s] = ld4(r_w, wl + (s & 3) * 1024, (s >> 2) * 4096);
     RS_STAMP(0, 1);
+#if DSD_RS_FILM4
+    if (wave < 4) et[tid] = fmine;
+#else
     et[tid & 255] = fmine;
+#endif
     __syncthreads();
     auto stage_write = [&](const f32x4& v, int u, int late) {    // FiLM add, then the zero padding (wavenet.py:36-38), then LDS
         const int row = x_row(u, late), c4 = x_c4(u);
