@@ -148,6 +148,7 @@ struct dsd_handle {
     float* emb_arena = nullptr;
     int emb_cols = 0, Ns = 0;
     float *t_dev = nullptr, *E = nullptr, *Hd = nullptr, *E2 = nullptr, *D = nullptr;
+    float* Dt = nullptr;            // D transposed: [step column][L * C rows] - what the layer kernels read their FiLM vectors from
     std::vector<float> t_host;
 
     std::map<std::string, GraphEntry> graphs;
@@ -1099,6 +1100,7 @@ int ensure_emb(dsd_handle* h, int ncols) {
         return o;
     };
     const size_t o_t = take(Ns), o_E = take(C * Ns), o_H = take(4 * C * Ns), o_E2 = take(C * Ns), o_D = take(L * C * Ns);
+    const size_t o_Dt = take(L * C * Ns);
     off += kGuard;
     float* a = nullptr;
     if (hipMalloc(&a, off * sizeof(float)) != hipSuccess) return fail(h, DSD_ENOMEM, "hipMalloc(step tables) failed");
@@ -1107,6 +1109,7 @@ int ensure_emb(dsd_handle* h, int ncols) {
     h->emb_cols = cap;
     h->Ns = Ns;
     h->t_dev = a + o_t; h->E = a + o_E; h->Hd = a + o_H; h->E2 = a + o_E2; h->D = a + o_D;
+    h->Dt = a + o_Dt;
     return DSD_OK;
 }
 
@@ -1253,6 +1256,18 @@ inline int edge_choice() {
     return ev ? atoi(ev) : -1;
 }
 
+// Layer `layer`'s FiLM vector d[c] for step column col0 (+ colb per batch item): kernels read film[c * cstride + c0 + b * cb].
+// From the transposed table Dt [step][L * C] that is C contiguous floats (DSD_FILM_T=0: from D [L * C][Ns], one line per row - A/B)
+inline void film_of(const dsd_handle* h, int layer, int col0, int colb, const float*& film, int& cstride, int& c0, int& cb) {
+    static const int transposed = getenv("DSD_FILM_T") ? atoi(getenv("DSD_FILM_T")) : 1;
+    const int C = C_of(h), LC = L_of(h) * C;
+    if (transposed) {
+        film = h->Dt + (long)layer * C; cstride = 1; c0 = col0 * LC; cb = colb * LC;
+    } else {
+        film = h->D + (long)layer * C * h->Ns; cstride = h->Ns; c0 = col0; cb = colb;
+    }
+}
+
 // step tables: E = sinemb(t) -> Hd = act(W0 E + b0) -> E2 = W1 Hd + b1 -> D[l*C + c][col] = Wd_l E2 + bd_l
 int run_step_tables(dsd_handle* h, int ncols, hipStream_t st) {
     const int C = C_of(h), Ns = h->Ns;
@@ -1268,7 +1283,14 @@ int run_step_tables(dsd_handle* h, int ncols, hipStream_t st) {
     if (rc) return rc;
     GemmCall g2 = make_gemm(h, h->g_dproj, h->E2, 0, Ns, 1, ncols, ST_PLAIN, EP_BIAS_ACT, 0);
     g2.p.act = ACT_NONE; g2.p.out = h->D; g2.p.o_rstride = Ns;
-    return run_gemm(h, g2, st);
+    if ((rc = run_gemm(h, g2, st))) return rc;
+    // ... and transposed: a layer's FiLM vector for one step is then C contiguous floats.  Read from D it is a gather of one
+    // cache line per channel (256 lines per workgroup of the one-utterance conv kernel: halving the waves that issue it
+    // alone was worth 2.2 % of the 50-NFE loop)
+    const int LC = (int)L_of(h) * C;
+    hipError_t te = launch_transpose(h->D, LC, ncols, Ns, h->Dt, LC, st);
+    if (te != hipSuccess) return fail(h, DSD_EHIP, "step-table transpose launch failed: %s", hipGetErrorString(te));
+    return DSD_OK;
 }
 
 // One backbone evaluation on the internal-layout input `xin_state` ([B][F*M][Ts]); the last GEMM's
@@ -1320,7 +1342,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
         g.p.strong = h->cfg.strong_cond;
         if (next < L) {
             g.p.cpn = h->cp + (long)next * C * Ts; g.p.cpn_bstride = (long)L * C * Ts; g.p.cpn_rstride = Ts;
-            g.p.film = h->D + (long)next * C * Ns; g.p.film_cstride = Ns; g.p.film_col0 = film_col0; g.p.film_colb = film_colb;
+            film_of(h, next, film_col0, film_colb, g.p.film, g.p.film_cstride, g.p.film_col0, g.p.film_colb);
         }
     };
     // WaveNet: the previous evaluation's edge kernel (wn_edge.hip) may already have projected this very input into xh
@@ -1351,7 +1373,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                 p.xin = xi; p.xout = xo; p.skip = h->skip;
                 p.x_bstride = xs; p.Ts = Ts;
                 p.cp = h->cp + (long)l * 2 * C * Ts; p.cp_bstride = cps;
-                p.film = h->D + (long)l * C * Ns; p.film_cstride = Ns; p.film_col0 = film_col0; p.film_colb = film_colb;
+                film_of(h, l, film_col0, film_colb, p.film, p.film_cstride, p.film_col0, p.film_colb);
                 p.dil = 1 << (l % h->cfg.dilation_cycle_length);
                 p.T = T; p.tiles_per_b = (T + 31) / 32; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
                 p.first_layer = (l == 0);
@@ -1382,7 +1404,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                 p.xin = h->xh; p.xout = h->xh; p.skip = h->skip; p.z = h->z;
                 p.x_bstride = xs; p.Ts = Ts;
                 p.cp = h->cp + (long)l * 2 * C * Ts; p.cp_bstride = cps;
-                p.film = h->D + (long)l * C * Ns; p.film_cstride = Ns; p.film_col0 = film_col0; p.film_colb = film_colb;
+                film_of(h, l, film_col0, film_colb, p.film, p.film_cstride, p.film_col0, p.film_colb);
                 p.dil = dil;
                 p.T = T; p.tiles_per_b = (T + 31) / 32; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
                 p.first_layer = (l == 0);
@@ -1396,7 +1418,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                 if (le != hipSuccess) return fail(h, DSD_EHIP, "row-split WaveNet layer launch failed: %s", hipGetErrorString(le));
                 continue;
             }
-            g.p.film = h->D + (long)l * C * Ns; g.p.film_cstride = Ns; g.p.film_col0 = film_col0; g.p.film_colb = film_colb;
+            film_of(h, l, film_col0, film_colb, g.p.film, g.p.film_cstride, g.p.film_col0, g.p.film_colb);
             g.p.aux = h->cp + (long)l * 2 * C * Ts; g.p.aux_bstride = cps; g.p.aux_rstride = Ts;
             g.p.out = h->z; g.p.o_bstride = xs; g.p.o_rstride = Ts;
             timed_begin();
@@ -1507,7 +1529,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             p.xin_out = next < L ? h->xin : nullptr;
             if (next < L) {
                 p.cpn = h->cp + (long)next * C * Ts; p.cpn_bstride = (long)L * C * Ts;
-                p.film = h->D + (long)next * C * Ns; p.film_cstride = Ns; p.film_col0 = film_col0; p.film_colb = film_colb;
+                film_of(h, next, film_col0, film_colb, p.film, p.film_cstride, p.film_col0, p.film_colb);
             }
             timed_begin();
             if (timed_now) lx_layer_set_timing_events(h->ev_pool[h->ev_used].first, h->ev_pool[h->ev_used].second);

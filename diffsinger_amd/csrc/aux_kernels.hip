@@ -117,6 +117,32 @@ __global__ __launch_bounds__(256) void sinemb_kernel(const float* __restrict__ t
     dst[(long)(half + i) * colstride + col] = c;
 }
 
+// dst[c][r] = src[r][c] for r < rows, c < cols (32 x 32 tiles through LDS): the step table D [L*C rows][steps] -> Dt
+// [steps][L*C], so that a layer's FiLM vector for one step is L*C / ... contiguous floats instead of one cache line per row
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int rows, int cols, int src_stride,
+                                                        float* __restrict__ dst, int dst_stride) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(long)r * src_stride + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(long)c * dst_stride + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+hipError_t launch_transpose(const float* src, int rows, int cols, int src_stride, float* dst, int dst_stride, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, src, rows, cols, src_stride, dst,
+                       dst_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const float* freqs, int C, float* dst,
                          hipStream_t stream) {
     const int n = (C / 2) * colstride;

@@ -242,6 +242,7 @@ hipError_t launch_pack(const float* src, long sb, long sr, long st, float* dst, 
                        hipStream_t stream);
 hipError_t launch_unpack(const float* src, int Ts, float* dst, int B, int F, int M, int T, int transpose,
                          const float* scale, const float* shift, hipStream_t stream);
+hipError_t launch_transpose(const float* src, int rows, int cols, int src_stride, float* dst, int dst_stride, hipStream_t st);
 hipError_t launch_sinemb(const float* t_dev, int ncols, int colstride, const float* freqs, int C, float* dst,
                          hipStream_t stream);
 hipError_t launch_lynx_pre(float* x, float* xin, const float* cp, long cp_bstride, const float* film,
