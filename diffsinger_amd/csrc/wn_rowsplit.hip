@@ -10,7 +10,8 @@
 //     blocks.  The 2 x 2 layout of gemm.hip has the two waves of a row pair stream the same weight blocks (twice the
 //     vector-memory instructions - and at B = 1 a CU's loop is bound by how many of them its memory pipe takes, ~1 per 50
 //     cycles - plus 8 over-read blocks per ring); here every weight block is loaded once: 48 per wave for the conv.
-//   * the weight stream runs 5 steps (1.3 k cycles) ahead through a 6-deep register rotation: a k16 step is only 8 MFMAs.
+//   * the weight stream runs DEPTH - 1 steps ahead through a register rotation (a k16 step is only 8 MFMAs); DEPTH = 3: see
+//     its definition - the first version's 6 put five blocks per wave into the latency-critical prologue burst.
 //   * gate / filter rows of a channel sit in different waves: the gate runs after an LDS transpose of the accumulators,
 //     row-major, with the conditioner projection fetched as float4 during the K walk.
 #include <hip/hip_ext.h>
@@ -85,7 +86,19 @@ __device__ __forceinline__ void rs_pin_args(const WnLayerP& p) {
 #endif
 }
 
-constexpr int DEPTH = 6;        // weight fragments in rotation: step s runs from W[s % 6], step s + 5 is in flight
+// Weight fragments in rotation: step s runs from W[s % DEPTH], step s + DEPTH - 1 is in flight.  The prologue of these short
+// kernels is bound by how many wave-level loads a CU can issue before the walk starts, and DEPTH - 1 blocks per wave are part of
+// that burst: same-box scan of the 50-NFE loop at the headline (tools/ab_flags.sh) - depth 8: 16.08 ms, 6: 15.73, 5: 15.73,
+// 4: 15.37, 3: 15.28, 2: 15.55; with separate depths for the two kernels (3, 3) 15.29, (3, 2) 15.36, (4, 3) 15.31, (3, 4) 15.33;
+// depth 3 also wins at B = 2 (24.72 -> 24.02), T = 2048 (24.69 -> 23.96), T = 900 and on the pitch network (tools/ab_depth.sh).
+#ifndef DSD_RS_DEPTH
+#define DSD_RS_DEPTH 3
+#endif
+#ifndef DSD_RS_DEPTH_OUT
+#define DSD_RS_DEPTH_OUT DSD_RS_DEPTH
+#endif
+constexpr int DEPTH_OUT = DSD_RS_DEPTH_OUT;   // ... of the out-proj kernel (8 steps per wave)
+constexpr int DEPTH = DSD_RS_DEPTH;           // ... of the conv kernel (24 steps per wave)
 
 // XCD-aware bijective remap (speed only): an XCD takes a contiguous range of work items, row tile fastest, so the row
 // tiles of a frame tile - which stage the same activations - share an L2
@@ -324,9 +337,9 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     const int orow = 64 * mtile + 16 * w;                        // this wave's 16 output rows (of 2C)
     const __amdgpu_buffer_rsrc_t r_w = rsrc(p.Aout + ((long)(4 * mtile + w) * NS + NH * kh) * 256);
     const int wl = lane * 16;
-    f32x4 W[DEPTH];
+    f32x4 W[DEPTH_OUT];
 #pragma unroll
-    for (int s = 0; s < DEPTH - 1; ++s) W[s] = ld4(r_w, wl + (s & 3) * 1024, (s >> 2) * 4096);
+    for (int s = 0; s < DEPTH_OUT - 1; ++s) W[s] = ld4(r_w, wl + (s & 3) * 1024, (s >> 2) * 4096);
     const f32x4 bo = ld4(rsrc(p.bias_out + orow), rq * 4, 0);
     // residual stream (row tiles of the first C rows) or running skip sum (the other half), row-major float4:
     // thread (of the first 256) -> rows (tid >> 3) and 32 + (tid >> 3) of the tile, frames 4 * (tid & 7)
@@ -359,14 +372,14 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     RS_PIN();
 #pragma unroll
     for (int s = 0; s < NH; ++s) {
-        const f32x4 wv = W[s % DEPTH];
+        const f32x4 wv = W[s % DEPTH_OUT];
         float (&bc)[4][2] = bq[s & 1];
         float (&bn)[4][2] = bq[(s + 1) & 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bc[j][0], acc[0], 0, 0, 0);
-            if (j == 0 && s + DEPTH - 1 < NH)
-                W[(s + DEPTH - 1) % DEPTH] = ld4(r_w, wl + ((s + DEPTH - 1) & 3) * 1024, ((s + DEPTH - 1) >> 2) * 4096);
+            if (j == 0 && s + DEPTH_OUT - 1 < NH)
+                W[(s + DEPTH_OUT - 1) % DEPTH_OUT] = ld4(r_w, wl + ((s + DEPTH_OUT - 1) & 3) * 1024, ((s + DEPTH_OUT - 1) >> 2) * 4096);
             if (j == 0 && s + 1 < NH) {          // the next step's 4 LDS read pairs in one burst: spread one per MFMA pair
 #pragma unroll                                   // they cost the walk 12 % more (measured 5.0 k vs 4.45 k cycles)
                 for (int jj = 0; jj < 4; ++jj) {
