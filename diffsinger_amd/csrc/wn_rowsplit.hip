@@ -94,6 +94,9 @@ __device__ __forceinline__ void rs_pin_args(const WnLayerP& p) {
 #ifndef DSD_RS_DEPTH
 #define DSD_RS_DEPTH 3
 #endif
+#ifndef DSD_RS_ONE_BARRIER
+#define DSD_RS_ONE_BARRIER 1
+#endif
 #ifndef DSD_RS_DEPTH_OUT
 #define DSD_RS_DEPTH_OUT DSD_RS_DEPTH
 #endif
@@ -271,6 +274,18 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
     RS_STAMP(0, 3);
 
     // ---------------- the two K halves' sums; accumulators -> LDS tile (rows [0, 32): gate, [32, 64): filter) ----------------
+#if DSD_RS_ONE_BARRIER
+    // each half transposes its own accumulators into its own tile; ONE barrier; the gate's threads add the two tiles
+    {
+        float* tk = kh == 0 ? et : red;
+        const int trow = (w & 1) * 32 + (w >> 1) * 16 + rq;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tk[(trow + r) * ES + n * 16 + lcol] = acc[n][r];
+    }
+    __syncthreads();
+#else
     if (kh == 1) {
         *reinterpret_cast<f32x4*>(&red[((w * 2 + 0) * 64 + lane) * 4]) = acc[0];
         *reinterpret_cast<f32x4*>(&red[((w * 2 + 1) * 64 + lane) * 4]) = acc[1];
@@ -286,10 +301,17 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
         }
     }
     __syncthreads();
+#endif
     if (tid < 256) {
         const int cw = tid >> 3, c4 = tid & 7;
+#if DSD_RS_ONE_BARRIER
+        const f32x4 g = *reinterpret_cast<const f32x4*>(&et[cw * ES + c4 * 4]) + *reinterpret_cast<const f32x4*>(&red[cw * ES + c4 * 4]);
+        const f32x4 f = *reinterpret_cast<const f32x4*>(&et[(32 + cw) * ES + c4 * 4]) +
+                        *reinterpret_cast<const f32x4*>(&red[(32 + cw) * ES + c4 * 4]);
+#else
         const f32x4 g = *reinterpret_cast<const f32x4*>(&et[cw * ES + c4 * 4]);
         const f32x4 f = *reinterpret_cast<const f32x4*>(&et[(32 + cw) * ES + c4 * 4]);
+#endif
         f32x4 z;
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = sigmoid_fast(g[e] + cpg[e]) * tanh_fast(f[e] + cpf[e]);      // wavenet.py:41-42
@@ -397,6 +419,16 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     RS_STAMP(1, 3);
 
     // ---------------- the two K halves' sums; residual / skip (wavenet.py:45-48), row-major ----------------
+#if DSD_RS_ONE_BARRIER
+    {
+        float* tk = kh == 0 ? et : red;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tk[(16 * w + rq + r) * ES + n * 16 + lcol] = acc[n][r];
+    }
+    __syncthreads();
+#else
     if (kh == 1) {
         *reinterpret_cast<f32x4*>(&red[((w * 2 + 0) * 64 + lane) * 4]) = acc[0];
         *reinterpret_cast<f32x4*>(&red[((w * 2 + 1) * 64 + lane) * 4]) = acc[1];
@@ -411,13 +443,19 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
         }
     }
     __syncthreads();
+#endif
     if (tid < 256) {
         const __amdgpu_buffer_rsrc_t r_o = rsrc((const float*)(is_res ? xo : sa) + eoff);
         const float scale = is_res ? 0.70710678118654752440f : 1.f;     // (x + o) / sqrt(2): times the fp32 reciprocal
         const bool add_pre = is_res || !p.first_layer;                  // the first layer's skip sum is its own output
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+#if DSD_RS_ONE_BARRIER
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&et[((tid >> 3) + 32 * k) * ES + (tid & 7) * 4]) +
+                             *reinterpret_cast<const f32x4*>(&red[((tid >> 3) + 32 * k) * ES + (tid & 7) * 4]);
+#else
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(&et[((tid >> 3) + 32 * k) * ES + (tid & 7) * 4]);
+#endif
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ((add_pre ? pre[k][e] : 0.f) + a4[e]) * scale;
@@ -429,8 +467,8 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
 }
 #undef RS_PIN
 
-int wn_rs_conv_lds_bytes(int sw) { return (256 * sw + 64 * 36 + 4 * 2 * 64 * 4) * 4; }
-int wn_rs_out_lds_bytes() { return (256 * 48 + 64 * 36 + 4 * 2 * 64 * 4) * 4; }
+int wn_rs_conv_lds_bytes(int sw) { return (256 * sw + 2 * 64 * 36) * 4; }       // x tile + the two K halves' transpose tiles
+int wn_rs_out_lds_bytes() { return (256 * 48 + 2 * 64 * 36) * 4; }
 
 bool wn_rowsplit_supported(int C, int dil) { return C == 256 && dil >= 1 && dil <= 16; }
 
