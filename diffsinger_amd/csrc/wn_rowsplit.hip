@@ -100,6 +100,27 @@ __device__ __forceinline__ void rs_pin_args(const WnLayerP& p) {
 #ifndef DSD_RS_DEPTH_OUT
 #define DSD_RS_DEPTH_OUT DSD_RS_DEPTH
 #endif
+// Conv: the late chunks go to LDS after local step DSD_RS_LATE_W and the workgroup meets after step DSD_RS_LATE_B; step 12 is
+// the first to read them and its operands are fetched during step 11 like any other step's.  (11, 11) is the first version:
+// write, barrier and step 12's LDS reads back to back, all of it exposed.  DSD_RS_FA_BATCH: the FiLM values of a thread's
+// staging rows are read from LDS in one batch (left inline, every ds_write_b128 waited for its own ds_read_b32 round trip).
+// Same-box A/B at the headline (tools/ab_flags.sh, ms per 50-NFE loop): first version 15.08; batch alone 14.99; batch +
+// (W, B) = (5, 10) 14.96, (8, 10) 14.97, (6, 7) 14.97, (4, 5) 14.97, (8, 8) 15.00.
+#ifndef DSD_RS_LATE_W
+#define DSD_RS_LATE_W 5
+#endif
+#ifndef DSD_RS_LATE_B
+#define DSD_RS_LATE_B 10
+#endif
+#ifndef DSD_RS_FA_BATCH
+#define DSD_RS_FA_BATCH 1
+#endif
+// Out-proj (1 = A/B build): only the two 64-channel chunks that the first four steps of either K half read staged before the
+// walk, the other two written after step 1 behind a barrier after step 2.  Not kept: the walk is 8 steps and the extra
+// barrier costs what the earlier start gains (14.99 against 14.97 ms).
+#ifndef DSD_RS_OUT_LATE
+#define DSD_RS_OUT_LATE 0
+#endif
 constexpr int DEPTH_OUT = DSD_RS_DEPTH_OUT;   // ... of the out-proj kernel (8 steps per wave)
 constexpr int DEPTH = DSD_RS_DEPTH;           // ... of the conv kernel (24 steps per wave)
 
@@ -205,9 +226,21 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
     et[tid & 255] = fmine;
 #endif
     __syncthreads();
+#if DSD_RS_FA_BATCH
+    float fa0[NE], fa1[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        fa0[u] = et[x_row(u, 0)];
+        fa1[u] = et[x_row(u, 1)];
+    }
+#endif
     auto stage_write = [&](const f32x4& v, int u, int late) {    // FiLM add, then the zero padding (wavenet.py:36-38), then LDS
         const int row = x_row(u, late), c4 = x_c4(u);
+#if DSD_RS_FA_BATCH
+        const float fa = late ? fa1[u] : fa0[u];
+#else
         const float fa = et[row];
+#endif
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -251,8 +284,8 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bc[j][0], acc[0], 0, 0, 0);
             if (j == 0 && s + DEPTH - 1 < NH)
                 W[(s + DEPTH - 1) % DEPTH] = ld4(r_w, wl + ((s + DEPTH - 1) & 3) * 1024, ((s + DEPTH - 1) >> 2) * 4096);
-            if (j == 0 && s != 11 && s + 1 < NH) {               // the next step's 4 LDS read pairs in one burst (step 12 reads
-#pragma unroll                                                   // the late chunks: fetched behind the barrier below)
+            if (j == 0 && !(DSD_RS_LATE_B == 11 && s == 11) && s + 1 < NH) {      // the next step's 4 LDS read pairs in one burst
+#pragma unroll
                 for (int jj = 0; jj < 4; ++jj) read_b1(bn, s + 1, jj);
             }
             RS_PIN();
@@ -262,15 +295,21 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
             if (j == 0 && s == 13) cpf = ld4(r_c, ((gch + C) * Ts + (tid & 7) * 4) * 4, 0);
             RS_PIN();
         }
-        if (s == 11) {
+        if (s == DSD_RS_LATE_W) {
 #pragma unroll
             for (int u = 0; u < NE; ++u) stage_write(svl[u], u, 1);
+            RS_PIN();
+        }
+        if (s == DSD_RS_LATE_B) {
             __syncthreads();
+            if (DSD_RS_LATE_B == 11) {                           // (first version: step 12's operands behind the barrier)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) read_b1(bn, 12, j);
+                for (int j = 0; j < 4; ++j) read_b1(bn, 12, j);
+            }
             RS_PIN();
         }
     }
+    static_assert(DSD_RS_LATE_W >= 3 && DSD_RS_LATE_W <= DSD_RS_LATE_B && DSD_RS_LATE_B <= 11, "late chunks: read from step 12 on");
     RS_STAMP(0, 3);
 
     // ---------------- the two K halves' sums; accumulators -> LDS tile (rows [0, 32): gate, [32, 64): filter) ----------------
@@ -350,12 +389,23 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
 
     // ---------------- prologue: z tile (all C channels), the first weight blocks, bias ----------------
     const __amdgpu_buffer_rsrc_t r_z = rsrc(p.z + (long)bu * p.x_bstride + t0u);
+    // staging slot u of a thread = float4 (idx & 7) of row idx >> 3, idx = tid + 512 u: slot u lies in 64-channel chunk u
     f32x4 sv[NZ];
-#pragma unroll
-    for (int u = 0; u < NZ; ++u) {
+    auto z_load = [&](int u) {
         const int idx = tid + 512 * u;
         sv[u] = ld4(r_z, ((idx >> 3) * Ts + (idx & 7) * 4) * 4, 0);
-    }
+    };
+    auto z_write = [&](int u) {
+        const int idx = tid + 512 * u;
+        *reinterpret_cast<f32x4*>(&zs[(idx >> 3) * SZ + (idx & 7) * 4]) = sv[u];
+    };
+#if DSD_RS_OUT_LATE
+    z_load(0);
+    z_load(2);
+#else
+#pragma unroll
+    for (int u = 0; u < NZ; ++u) z_load(u);
+#endif
     const int orow = 64 * mtile + 16 * w;                        // this wave's 16 output rows (of 2C)
     const __amdgpu_buffer_rsrc_t r_w = rsrc(p.Aout + ((long)(4 * mtile + w) * NS + NH * kh) * 256);
     const int wl = lane * 16;
@@ -363,6 +413,10 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
 #pragma unroll
     for (int s = 0; s < DEPTH_OUT - 1; ++s) W[s] = ld4(r_w, wl + (s & 3) * 1024, (s >> 2) * 4096);
     const f32x4 bo = ld4(rsrc(p.bias_out + orow), rq * 4, 0);
+#if DSD_RS_OUT_LATE
+    z_load(1);
+    z_load(3);
+#endif
     // residual stream (row tiles of the first C rows) or running skip sum (the other half), row-major float4:
     // thread (of the first 256) -> rows (tid >> 3) and 32 + (tid >> 3) of the tile, frames 4 * (tid & 7)
     const bool is_res = mtile < NCH;                             // workgroup-uniform
@@ -372,11 +426,13 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     const int ev0 = (((tid & 255) >> 3) * Ts + (tid & 7) * 4) * 4;
     f32x4 pre[2];
     RS_STAMP(1, 1);
+#if DSD_RS_OUT_LATE
+    z_write(0);
+    z_write(2);
+#else
 #pragma unroll
-    for (int u = 0; u < NZ; ++u) {
-        const int idx = tid + 512 * u;
-        *reinterpret_cast<f32x4*>(&zs[(idx >> 3) * SZ + (idx & 7) * 4]) = sv[u];
-    }
+    for (int u = 0; u < NZ; ++u) z_write(u);
+#endif
     __syncthreads();
     RS_STAMP(1, 2);
 
@@ -415,6 +471,17 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
             if (j == 0 && s == 2) pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
             RS_PIN();
         }
+#if DSD_RS_OUT_LATE
+        if (s == 1) {
+            z_write(1);
+            z_write(3);
+            RS_PIN();
+        }
+        if (s == 2) {
+            __syncthreads();
+            RS_PIN();
+        }
+#endif
     }
     RS_STAMP(1, 3);
 
