@@ -1122,7 +1122,7 @@ struct GemmCall {
 };
 
 GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b_bstride, int b_rstride, int batch,
-                   int T, int stage, int epi, int dil, bool generic_only = false) {
+                   int T, int stage, int epi, int dil, bool generic_only = false, bool rs_pair = false) {
     GemmCall c;
     memset(&c.p, 0, sizeof(c.p));
     GemmP& p = c.p;
@@ -1171,7 +1171,11 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
         // 552 16-frame ones, three per CU at most, 48 frames (measured at B = 1: 22.2 instead of 26.7 ms for T in (1024, 1536])
         const long wg16 = (long)batch * ((T + 15) / 16) * mtiles;
         const long load16 = (wg16 + 255) / 256 * 16, load32 = (wg32 + 255) / 256 * 32;
-        if (ok && !generic_only && (force == 1 || (force != 0 && (wg32 <= 192 || (wg32 <= 768 && load16 < load32))))) c.nb = 0;
+        // rs_pair: the caller runs 32-frame tiles as the row-split pair (wn_rowsplit.hip), ~15 ms per 50-NFE loop for any grid of
+        // <= 256 workgroups; narrow tiles beat that only while they too are one round (T <= 512 at B = 1: 13.0 ms; T = 768 took
+        // 16.9 ms as 384 narrow workgroups)
+        const bool small = rs_pair ? wg16 <= 256 : wg32 <= 192;
+        if (ok && !generic_only && (force == 1 || (force != 0 && (small || (wg32 <= 768 && load16 < load32))))) c.nb = 0;
     }
     const int BN = c.nb == 0 ? 16 : 32 * c.nb;
     p.tiles_per_b = (T + BN - 1) / BN;
@@ -1390,11 +1394,12 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
         } else
         for (int l = 0; l < L; ++l) {
             const int dil = 1 << (l % h->cfg.dilation_cycle_length);
-            GemmCall g = make_gemm(h, h->g_conv[l], h->xh, xs, Ts, B, T, ST_FILM, EP_GATE, dil);
             // 32-frame tiles on a grid of about one workgroup per CU (one utterance of ~1000 frames): the row-split pair
             // of wn_rowsplit.hip - every weight block loaded once, compiler-counted waits - instead of the two GEMMs
             static const int rs_env = getenv("DSD_ROWSPLIT") ? atoi(getenv("DSD_ROWSPLIT")) : -1;
-            if (rs_env != 0 && g.nb == 1 && g.fast && wn_rowsplit_supported(C, dil)) {
+            const bool rs_ok = rs_env != 0 && wn_rowsplit_supported(C, dil);
+            GemmCall g = make_gemm(h, h->g_conv[l], h->xh, xs, Ts, B, T, ST_FILM, EP_GATE, dil, false, rs_ok);
+            if (rs_ok && g.nb == 1 && g.fast) {
                 const bool ragged = h->use_cg && !h->lens_host.empty();
                 WnLayerP p;
                 memset(&p, 0, sizeof(p));
