@@ -1397,7 +1397,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             // 32-frame tiles on a grid of about one workgroup per CU (one utterance of ~1000 frames): the row-split pair
             // of wn_rowsplit.hip - every weight block loaded once, compiler-counted waits - instead of the two GEMMs
             static const int rs_env = getenv("DSD_ROWSPLIT") ? atoi(getenv("DSD_ROWSPLIT")) : -1;
-            const bool rs_ok = rs_env != 0 && wn_rowsplit_supported(C, dil);
+            const bool rs_ok = rs_env != 0 && wn_rowsplit_supported(C, dil, Ts);
             GemmCall g = make_gemm(h, h->g_conv[l], h->xh, xs, Ts, B, T, ST_FILM, EP_GATE, dil, false, rs_ok);
             if (rs_ok && g.nb == 1 && g.fast) {
                 const bool ragged = h->use_cg && !h->lens_host.empty();

@@ -165,7 +165,7 @@ void wn_layer_set_timing_events(hipEvent_t start, hipEvent_t stop);
 // when xout == xin)
 hipError_t launch_wn_rowsplit(const WnLayerP& p, int which, int C, int batch, hipStream_t st);
 hipError_t wn_rowsplit_init_all();
-bool wn_rowsplit_supported(int C, int dil);
+bool wn_rowsplit_supported(int C, int dil, long Ts);
 void wn_rowsplit_set_timing_events(hipEvent_t start, hipEvent_t stop);
 
 // wn_edge.hip: the WaveNet's small GEMMs around the residual layers (skip projection -> output projection + solver update ->

@@ -16,6 +16,8 @@
 //     row-major, with the conditioner projection fetched as float4 during the K walk.
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "dsd_internal.h"
 
 namespace dsd {
@@ -27,6 +29,10 @@ namespace {
 __device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 __device__ __forceinline__ float tanh_fast(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * v)); }
 __device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+// byte offset of a row as a 24-bit multiply (rows < 512; the host keeps Ts below 2^22): a 32-bit `row * Ts + c` compiles to
+// v_mad_u64_u32, whose 64-bit addend has an undefined high half - the register allocator parked it on a register with a load
+// in flight (the FiLM value) and the hardware dependency put an s_waitcnt vmcnt(0) in front of the x-tile loads.
+__device__ __forceinline__ int row_ts(int row, int Ts) { return (int)__umul24((unsigned)row, (unsigned)(Ts * 4)); }   // BYTES
 
 constexpr unsigned kRange = 0x7FFFFFF0u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* ptr) {
@@ -53,7 +59,7 @@ __device__ __forceinline__ void st4z(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff
 
 #ifdef DSD_STAMPS
 // [kernel 0 = conv, 1 = out][workgroup][0..6]: s_memtime at the phase boundaries; [8], [9]: s_memrealtime at the first / last
-__device__ unsigned long long g_rs_stamps[2][4096][10];
+__device__ unsigned long long g_rs_stamps[2][4096][40];      // [10 + s]: after local step s of the conv walk
 #define RS_STAMP(K, i)                                                                          \
     do {                                                                                        \
         if (threadIdx.x == 0 && blockIdx.x < 4096) {                                            \
@@ -121,8 +127,46 @@ __device__ __forceinline__ void rs_pin_args(const WnLayerP& p) {
 #ifndef DSD_RS_OUT_LATE
 #define DSD_RS_OUT_LATE 0
 #endif
+// 1 (A/B build): the loads that the first version spreads over the walk's first steps (the late x chunks, the conditioner
+// projection, the out-proj's residual / skip operand) issued in the prologue, right behind the first weight blocks.  Not kept:
+// 15.44 against 14.98 ms per loop - ten more wave-level loads per wave in the burst before the walk.
+#ifndef DSD_RS_EARLY
+#define DSD_RS_EARLY 0
+#endif
+// The conv's ring RAMPS: DEPTH - 1 blocks per wave in the prologue burst, then two blocks per step until DSD_RS_DEPTH_MAX - 1
+// are in flight (= DEPTH: no ramp).
+#ifndef DSD_RS_DEPTH_MAX
+#define DSD_RS_DEPTH_MAX DSD_RS_DEPTH
+#endif
+// TIMING-ONLY diagnostic builds of the conv walk (wrong results): bit 0 no weight loads inside the walk, bit 1 no B-fragment
+// LDS reads inside the walk, bit 2 no late chunks (loads, LDS writes, barrier), bit 3 no conditioner-projection loads
+#ifndef DSD_RS_DIAG
+#define DSD_RS_DIAG 0
+#endif
 constexpr int DEPTH_OUT = DSD_RS_DEPTH_OUT;   // ... of the out-proj kernel (8 steps per wave)
 constexpr int DEPTH = DSD_RS_DEPTH;           // ... of the conv kernel (24 steps per wave)
+constexpr int DMAX = DSD_RS_DEPTH_MAX;
+static_assert(DMAX >= DEPTH, "the ring ramps up, not down");
+// blocks issued before local step s of an n-step walk: DEPTH - 1 in the prologue, then at most two per step and never past
+// block s + DMAX - 1 (whose slot the step before freed)
+constexpr int rs_issued_before(int s, int n) {
+    int c = DEPTH - 1;
+    for (int i = 0; i < s; ++i) {
+        int lim = i + DMAX;
+        if (lim > n) lim = n;
+        c = c + 2 < lim ? c + 2 : lim;
+    }
+    return c < n ? c : n;
+}
+
+// the walk's steps with their index a constant expression (ring slots, the issue plan above)
+template <int I, int N, typename F>
+__device__ __forceinline__ void rs_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        rs_static_for<I + 1, N>(f);
+    }
+}
 
 // XCD-aware bijective remap (speed only): an XCD takes a contiguous range of work items, row tile fastest, so the row
 // tiles of a frame tile - which stage the same activations - share an L2
@@ -212,13 +256,29 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
     };
     f32x4 sv[NE], svl[NE];
 #pragma unroll
-    for (int u = 0; u < NE; ++u) sv[u] = ld4(r_x, (x_row(u, 0) * Ts + x_c4(u) * 4) * 4, 0);
+    for (int u = 0; u < NE; ++u) sv[u] = ld4(r_x, row_ts(x_row(u, 0), Ts) + x_c4(u) * 16, 0);
+    RS_PIN();                                                    // (issue order = return order: what the walk needs first, first)
     // this wave's row block: packed block 4 * mtile + w (even: gate rows, odd: filter rows of 16 channels), steps [NH kh, +NH)
     const __amdgpu_buffer_rsrc_t r_w = rsrc(p.Aconv + ((long)(4 * mtile + w) * NS + NH * kh) * 256);
     const int wl = lane * 16;
-    f32x4 W[DEPTH];
+    f32x4 W[DMAX];
 #pragma unroll
     for (int s = 0; s < DEPTH - 1; ++s) W[s] = ld4(r_w, wl + (s & 3) * 1024, (s >> 2) * 4096);
+    RS_PIN();
+    // the hoisted conditioner projection (+ biases) of this tile's 32 channels, row-major float4 for the gate below:
+    // thread (of the first 256) -> channel tid >> 3, frames 4 * (tid & 7)
+    const int gch = 32 * mtile + ((tid & 255) >> 3);
+    const __amdgpu_buffer_rsrc_t r_c = rsrc(p.cp + (long)bu * p.cp_bstride + t0u);
+    f32x4 cpg = f32x4{0.f, 0.f, 0.f, 0.f}, cpf = cpg;
+#if DSD_RS_EARLY
+#pragma unroll
+    for (int u = 0; u < NE; ++u) svl[u] = ld4(r_x, row_ts(x_row(u, 1), Ts) + x_c4(u) * 16, 0);
+    if (wave < 4) {
+        cpg = ld4(r_c, row_ts(gch, Ts) + (tid & 7) * 16, 0);
+        cpf = ld4(r_c, row_ts(gch + C, Ts) + (tid & 7) * 16, 0);
+    }
+    RS_PIN();
+#endif
     RS_STAMP(0, 1);
 #if DSD_RS_FILM4
     if (wave < 4) et[tid] = fmine;
@@ -266,41 +326,38 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
         bv[j][0] = base[0];
         bv[j][1] = base[16];
     };
-    // the hoisted conditioner projection (+ biases) of this tile's 32 channels, row-major float4 for the gate below:
-    // thread (of the first 256) -> channel tid >> 3, frames 4 * (tid & 7)
-    const int gch = 32 * mtile + ((tid & 255) >> 3);
-    const __amdgpu_buffer_rsrc_t r_c = rsrc(p.cp + (long)bu * p.cp_bstride + t0u);
-    f32x4 cpg, cpf;
 #pragma unroll
     for (int j = 0; j < 4; ++j) read_b1(bq[0], 0, j);
     RS_PIN();
-#pragma unroll
-    for (int s = 0; s < NH; ++s) {
-        const f32x4 wv = W[s % DEPTH];
-        float (&bc)[4][2] = bq[s & 1];
+    rs_static_for<0, NH>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        const f32x4 wv = W[(DSD_RS_DIAG & 1) ? s % (DEPTH - 1) : s % DMAX];
+        float (&bc)[4][2] = bq[(DSD_RS_DIAG & 2) ? 0 : s & 1];
         float (&bn)[4][2] = bq[(s + 1) & 1];
+        constexpr int nb0 = rs_issued_before(s, NH), nb1 = rs_issued_before(s + 1, NH);     // this step issues blocks [nb0, nb1)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bc[j][0], acc[0], 0, 0, 0);
-            if (j == 0 && s + DEPTH - 1 < NH)
-                W[(s + DEPTH - 1) % DEPTH] = ld4(r_w, wl + ((s + DEPTH - 1) & 3) * 1024, ((s + DEPTH - 1) >> 2) * 4096);
-            if (j == 0 && !(DSD_RS_LATE_B == 11 && s == 11) && s + 1 < NH) {      // the next step's 4 LDS read pairs in one burst
+            if (!(DSD_RS_DIAG & 1) && j < 2 && nb0 + j < nb1) W[(nb0 + j) % DMAX] = ld4(r_w, wl + ((nb0 + j) & 3) * 1024, ((nb0 + j) >> 2) * 4096);
+            if (!(DSD_RS_DIAG & 2) && j == 0 && !(DSD_RS_LATE_B == 11 && s == 11) && s + 1 < NH) {      // the next step's 4 LDS read pairs in one burst
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) read_b1(bn, s + 1, jj);
             }
             RS_PIN();
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bc[j][1], acc[1], 0, 0, 0);
-            if (j == 0 && s < NE) svl[s] = ld4(r_x, (x_row(s, 1) * Ts + x_c4(s) * 4) * 4, 0);
-            if (j == 0 && s == 12) cpg = ld4(r_c, (gch * Ts + (tid & 7) * 4) * 4, 0);
-            if (j == 0 && s == 13) cpf = ld4(r_c, ((gch + C) * Ts + (tid & 7) * 4) * 4, 0);
+#if !DSD_RS_EARLY
+            if (!(DSD_RS_DIAG & 4) && j == 0 && s < NE) svl[s] = ld4(r_x, row_ts(x_row(s, 1), Ts) + x_c4(s) * 16, 0);
+            if (!(DSD_RS_DIAG & 8) && j == 0 && s == 12) cpg = ld4(r_c, row_ts(gch, Ts) + (tid & 7) * 16, 0);
+            if (!(DSD_RS_DIAG & 8) && j == 0 && s == 13) cpf = ld4(r_c, row_ts(gch + C, Ts) + (tid & 7) * 16, 0);
+#endif
             RS_PIN();
         }
-        if (s == DSD_RS_LATE_W) {
+        if (!(DSD_RS_DIAG & 4) && s == DSD_RS_LATE_W) {
 #pragma unroll
             for (int u = 0; u < NE; ++u) stage_write(svl[u], u, 1);
             RS_PIN();
         }
-        if (s == DSD_RS_LATE_B) {
+        if (!(DSD_RS_DIAG & 4) && s == DSD_RS_LATE_B) {
             __syncthreads();
             if (DSD_RS_LATE_B == 11) {                           // (first version: step 12's operands behind the barrier)
 #pragma unroll
@@ -308,7 +365,8 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
             }
             RS_PIN();
         }
-    }
+        RS_STAMP(0, 10 + s);
+    });
     static_assert(DSD_RS_LATE_W >= 3 && DSD_RS_LATE_W <= DSD_RS_LATE_B && DSD_RS_LATE_B <= 11, "late chunks: read from step 12 on");
     RS_STAMP(0, 3);
 
@@ -355,7 +413,199 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = sigmoid_fast(g[e] + cpg[e]) * tanh_fast(f[e] + cpf[e]);      // wavenet.py:41-42
         const __amdgpu_buffer_rsrc_t r_z = rsrc(p.z + (long)bu * p.x_bstride + t0u);
-        st4z(z, r_z, (gch * Ts + c4 * 4) * 4, 0);
+        st4z(z, r_z, row_ts(gch, Ts) + c4 * 16, 0);
+    }
+    RS_STAMP(0, 4);
+    RS_STAMP(0, 5);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Conv, second wave layout (DSD_RS_CONV_Q = 1): 8 waves = four K QUARTERS (one 64-channel chunk each) x two row waves of 32 rows -
+// the gate AND the filter rows of 16 channels.  What the walk of the first layout loses over its MFMAs is the issue of its
+// B-fragment LDS reads (timing-only builds at the headline: no reads in the walk -0.54 us per layer, no weight loads -0.09,
+// no late chunks -0.20, no conditioner loads -0.13); here a fragment read feeds FOUR MFMAs instead of two, a wave walks 12 steps
+// of 16 MFMAs instead of 24 of 8, and every wave streams two row blocks' weights (the loads are free).  Price: four partial
+// sums per output instead of two meet in LDS at the end.  Step order inside a quarter: [32-channel half][tap][k16 of the half],
+// so the first six steps read only the first 32 channels of each chunk - those 128 rows are staged before the walk, the
+// others are fetched behind the first two steps' MFMAs, written after step 3, barrier after step 4.  The ring holds three
+// steps but only step 0's two blocks are in the prologue burst; step 0 issues steps 1 and 2.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SW, int RAG>
+__global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    RS_STAMP(0, 6);
+    rs_pin_args(p);
+    RS_STAMP(0, 7);
+    constexpr int HL = SW == 48 ? 8 : 16;
+    constexpr int W4 = (BN + 2 * HL) / 4;
+    constexpr int NE = 128 * W4 / 512;              // float4 per thread of 128 rows: 3 (SW 48), 4 (SW 80)
+    constexpr int NS = NCH * 12;                    // weight blocks per packed row block: [chunk][tap][k16 in chunk]
+    constexpr int NQ = 12;                          // steps per wave (one chunk)
+    constexpr int LW = 3, LB = 4;                   // late rows: written after step LW, barrier after step LB, read from step 6 on
+    static_assert(NE <= 4, "the late rows are fetched two per step during steps 0 and 1");
+    float* xs = lds;                                 // [C][SW]
+    float* et = lds + C * SW;                        // [4 quarters][64][ES]: FiLM vector first, the quarters' accumulators last
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = wave >> 1, wr = wave & 1;
+    const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
+    const int work = xcd_work();
+    const int rest0 = work / MT, mtile = work - rest0 * MT;
+    const int rest = RAG ? p.cgmap[rest0] : rest0;
+    const int b = fdiv_floor(rest, p.inv_tiles_per_b);
+    const int t0 = (rest - b * p.tiles_per_b) * BN;
+    const int Tb = (RAG && p.lens) ? p.lens[b] : p.T;
+    const int Ts = p.Ts;
+    const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
+    RS_STAMP(0, 0);
+
+    // ---------------- prologue: the first 32 channels of every chunk, FiLM vector, step 0's weights ----------------
+    const __amdgpu_buffer_rsrc_t r_x = rsrc(p.xin + (long)bu * p.x_bstride + (t0u - HL));
+    const __amdgpu_buffer_rsrc_t r_f = rsrc(p.film + p.film_col0 + bu * p.film_colb);
+    float fmine = 0.f;                                           // 256 values: the first four waves fetch them (wave-uniform branch)
+    if (wave < 4) fmine = ld1(r_f, tid * p.film_cstride * 4, 0);
+    // staging slot u of a thread: float4 (row, c4) of a 128-row set; late = 0: channels [0, 32) of each chunk, 1: [32, 64)
+    auto x_row = [&](int u, int late) {
+        const int e = tid + 512 * u;
+        const int re = e / W4;
+        return (re >> 5) * 64 + (re & 31) + 32 * late;
+    };
+    auto x_c4 = [&](int u) {
+        const int e = tid + 512 * u;
+        return e - (e / W4) * W4;
+    };
+    f32x4 sv[NE], svl[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) sv[u] = ld4(r_x, row_ts(x_row(u, 0), Ts) + x_c4(u) * 16, 0);
+    RS_PIN();
+    // this wave's two row blocks: packed blocks 4 mtile + 2 wr (gate rows) and + 1 (filter rows) of the same 16 channels;
+    // local step t of quarter kq = block 12 kq + tap * 4 + k16 of either
+    const __amdgpu_buffer_rsrc_t r_w = rsrc(p.Aconv + ((long)(4 * mtile + 2 * wr) * NS + 12 * kq) * 256);
+    const int wl = lane * 16;
+    auto blk = [](int t) { return ((t % 6) / 2) * 4 + (t / 6) * 2 + (t % 2); };
+    f32x4 W[3][2];
+    auto w_load = [&](int t, int rb) {
+        const int g = blk(t);
+        W[t % 3][rb] = ld4(r_w, wl + (g & 3) * 1024, (g >> 2) * 4096 + rb * NS * 1024);
+    };
+    w_load(0, 0);
+    w_load(0, 1);
+    RS_PIN();
+    // the hoisted conditioner projection (+ biases) of this tile's 32 channels, row-major float4 for the gate below:
+    // thread (of the first 256) -> channel tid >> 3, frames 4 * (tid & 7)
+    const int gch = 32 * mtile + ((tid & 255) >> 3);
+    const __amdgpu_buffer_rsrc_t r_c = rsrc(p.cp + (long)bu * p.cp_bstride + t0u);
+    f32x4 cpg = f32x4{0.f, 0.f, 0.f, 0.f}, cpf = cpg;
+    RS_STAMP(0, 1);
+    if (wave < 4) et[tid] = fmine;
+    __syncthreads();
+    float fa0[NE], fa1[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        fa0[u] = et[x_row(u, 0)];
+        fa1[u] = et[x_row(u, 1)];
+    }
+    auto stage_write = [&](const f32x4& v, int u, int late) {    // FiLM add, then the zero padding (wavenet.py:36-38), then LDS
+        const int row = x_row(u, late), c4 = x_c4(u);
+        const float fa = late ? fa1[u] : fa0[u];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = t0 - HL + c4 * 4 + e;
+            o[e] = (t >= 0 && t < Tb) ? v[e] + fa : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(&xs[row * SW + c4 * 4]) = o;
+    };
+    // (the FiLM values are in registers: the barrier below also orders these reads before the tail's writes to `et`)
+#pragma unroll
+    for (int u = 0; u < NE; ++u) stage_write(sv[u], u, 0);
+    __syncthreads();
+    RS_STAMP(0, 2);
+
+    // ---------------- K walk ----------------
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[rb][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* bt0 = xs + (kq * 64 + lrow) * SW + HL + lcol - p.dil;
+    const float* bt1 = bt0 + p.dil;
+    const float* bt2 = bt1 + p.dil;
+    float bq[2][4][2];
+    auto read_b1 = [&](float (&bv)[4][2], int t, int j) {        // both column blocks of k4 step j of local step t
+        const int tap = (t % 6) / 2, k16 = (t / 6) * 2 + (t % 2);
+        const float* base = (tap == 0 ? bt0 : (tap == 1 ? bt1 : bt2)) + (k16 * 16 + j * 4) * SW;
+        bv[j][0] = base[0];
+        bv[j][1] = base[16];
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) read_b1(bq[0], 0, j);
+    RS_PIN();
+    rs_static_for<0, NQ>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        const f32x4 wv0 = W[t % 3][0], wv1 = W[t % 3][1];
+        float (&bc)[4][2] = bq[t & 1];
+        float (&bn)[4][2] = bq[(t + 1) & 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv0[j], bc[j][0], acc[0][0], 0, 0, 0);
+            if (t == 0) w_load(1 + j / 2, j & 1);                // step 0 issues steps 1 and 2 ...
+            else if (j < 2 && t + 2 < NQ) w_load(t + 2, j);      // ... step t >= 1 issues step t + 2
+            if (j == 0 && t + 1 < NQ) {                          // the next step's 4 LDS read pairs in one burst
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) read_b1(bn, t + 1, jj);
+            }
+            RS_PIN();
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv0[j], bc[j][1], acc[0][1], 0, 0, 0);
+            if (j < 2 && t < 2 && 2 * t + j < NE) svl[2 * t + j] = ld4(r_x, row_ts(x_row(2 * t + j, 1), Ts) + x_c4(2 * t + j) * 16, 0);
+            if (j == 0 && t == 7) cpg = ld4(r_c, row_ts(gch, Ts) + (tid & 7) * 16, 0);
+            if (j == 0 && t == 8) cpf = ld4(r_c, row_ts(gch + C, Ts) + (tid & 7) * 16, 0);
+            RS_PIN();
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv1[j], bc[j][0], acc[1][0], 0, 0, 0);
+            RS_PIN();
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv1[j], bc[j][1], acc[1][1], 0, 0, 0);
+            RS_PIN();
+        }
+        if (t == LW) {
+#pragma unroll
+            for (int u = 0; u < NE; ++u) stage_write(svl[u], u, 1);
+            RS_PIN();
+        }
+        if (t == LB) {
+            __syncthreads();
+            RS_PIN();
+        }
+    });
+    RS_STAMP(0, 3);
+
+    // ---------------- the four quarters' sums: every wave transposes its accumulators into its quarter's tile (rows [0, 32):
+    // gate, [32, 64): filter), ONE barrier, the gate's threads add the four tiles ----------------
+    {
+        float* tk = et + kq * (64 * ES);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tk[(rb * 32 + wr * 16 + rq + r) * ES + n * 16 + lcol] = acc[rb][n][r];
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int cw = tid >> 3, c4 = tid & 7;
+        f32x4 g = *reinterpret_cast<const f32x4*>(&et[cw * ES + c4 * 4]);
+        f32x4 f = *reinterpret_cast<const f32x4*>(&et[(32 + cw) * ES + c4 * 4]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            g += *reinterpret_cast<const f32x4*>(&et[q * (64 * ES) + cw * ES + c4 * 4]);
+            f += *reinterpret_cast<const f32x4*>(&et[q * (64 * ES) + (32 + cw) * ES + c4 * 4]);
+        }
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = sigmoid_fast(g[e] + cpg[e]) * tanh_fast(f[e] + cpf[e]);      // wavenet.py:41-42
+        const __amdgpu_buffer_rsrc_t r_z = rsrc(p.z + (long)bu * p.x_bstride + t0u);
+        st4z(z, r_z, row_ts(gch, Ts) + c4 * 16, 0);
     }
     RS_STAMP(0, 4);
     RS_STAMP(0, 5);
@@ -393,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     f32x4 sv[NZ];
     auto z_load = [&](int u) {
         const int idx = tid + 512 * u;
-        sv[u] = ld4(r_z, ((idx >> 3) * Ts + (idx & 7) * 4) * 4, 0);
+        sv[u] = ld4(r_z, row_ts(idx >> 3, Ts) + (idx & 7) * 16, 0);
     };
     auto z_write = [&](int u) {
         const int idx = tid + 512 * u;
@@ -406,13 +656,15 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
 #pragma unroll
     for (int u = 0; u < NZ; ++u) z_load(u);
 #endif
+    RS_PIN();                                                    // (issue order = return order: what the walk needs first, first)
     const int orow = 64 * mtile + 16 * w;                        // this wave's 16 output rows (of 2C)
     const __amdgpu_buffer_rsrc_t r_w = rsrc(p.Aout + ((long)(4 * mtile + w) * NS + NH * kh) * 256);
     const int wl = lane * 16;
     f32x4 W[DEPTH_OUT];
+    const f32x4 bo = ld4(rsrc(p.bias_out + orow), rq * 4, 0);
 #pragma unroll
     for (int s = 0; s < DEPTH_OUT - 1; ++s) W[s] = ld4(r_w, wl + (s & 3) * 1024, (s >> 2) * 4096);
-    const f32x4 bo = ld4(rsrc(p.bias_out + orow), rq * 4, 0);
+    RS_PIN();
 #if DSD_RS_OUT_LATE
     z_load(1);
     z_load(3);
@@ -423,8 +675,15 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     const long eoff = (long)bu * p.x_bstride + (long)(is_res ? 64 * mtile : 64 * mtile - C) * Ts + t0u;
     const unsigned long long xa = (unsigned long long)p.xin, sa = (unsigned long long)p.skip, xo = (unsigned long long)p.xout;
     const __amdgpu_buffer_rsrc_t r_e = rsrc((const float*)(is_res ? xa : sa) + eoff);
-    const int ev0 = (((tid & 255) >> 3) * Ts + (tid & 7) * 4) * 4;
+    const int ev0 = row_ts((tid & 255) >> 3, Ts) + (tid & 7) * 16;
     f32x4 pre[2];
+#if DSD_RS_EARLY
+    if (wave < 4) {
+        pre[0] = ld4(r_e, ev0, 0);
+        pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
+    }
+    RS_PIN();
+#endif
     RS_STAMP(1, 1);
 #if DSD_RS_OUT_LATE
     z_write(0);
@@ -467,8 +726,10 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
             }
             RS_PIN();
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bc[j][1], acc[1], 0, 0, 0);
+#if !DSD_RS_EARLY
             if (j == 0 && s == 1) pre[0] = ld4(r_e, ev0, 0);
             if (j == 0 && s == 2) pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
+#endif
             RS_PIN();
         }
 #if DSD_RS_OUT_LATE
@@ -534,10 +795,13 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
 }
 #undef RS_PIN
 
-int wn_rs_conv_lds_bytes(int sw) { return (256 * sw + 2 * 64 * 36) * 4; }       // x tile + the two K halves' transpose tiles
+#ifndef DSD_RS_CONV_Q
+#define DSD_RS_CONV_Q 1
+#endif
+int wn_rs_conv_lds_bytes(int sw) { return (256 * sw + (DSD_RS_CONV_Q ? 4 : 2) * 64 * 36) * 4; }       // x tile + the K parts' transpose tiles
 int wn_rs_out_lds_bytes() { return (256 * 48 + 2 * 64 * 36) * 4; }
 
-bool wn_rowsplit_supported(int C, int dil) { return C == 256 && dil >= 1 && dil <= 16; }
+bool wn_rowsplit_supported(int C, int dil, long Ts) { return C == 256 && dil >= 1 && dil <= 16 && Ts < (1L << 22); }
 
 template <typename K>
 static hipError_t rs_attr(K kern) {
@@ -546,18 +810,23 @@ static hipError_t rs_attr(K kern) {
 
 template <int SW, int RAG>
 static hipError_t rs_launch_conv(const WnLayerP& p, int nwg, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+#if DSD_RS_CONV_Q
+    constexpr auto kern = wn_conv_rq_kernel<SW, RAG>;
+#else
+    constexpr auto kern = wn_conv_rs_kernel<SW, RAG>;
+#endif
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = rs_attr(wn_conv_rs_kernel<SW, RAG>);
+        hipError_t e = rs_attr(kern);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (nwg == 0) return hipSuccess;
     const int ldsb = wn_rs_conv_lds_bytes(SW);
     if (e0 && e1)
-        hipExtLaunchKernelGGL((wn_conv_rs_kernel<SW, RAG>), dim3(nwg), dim3(512), ldsb, st, e0, e1, 0, p);
+        hipExtLaunchKernelGGL(kern, dim3(nwg), dim3(512), ldsb, st, e0, e1, 0, p);
     else
-        hipLaunchKernelGGL((wn_conv_rs_kernel<SW, RAG>), dim3(nwg), dim3(512), ldsb, st, p);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), ldsb, st, p);
     return hipGetLastError();
 }
 

@@ -75,7 +75,7 @@ if "--edge" in sys.argv:
             print(f"    {lb:58s} mean {m:8.0f}  min {mn:8.0f}  max {mx:8.0f}")
     sys.exit(0)
 if ROWSPLIT:
-    buf2 = np.zeros((2, 4096, 10), dtype=np.uint64)
+    buf2 = np.zeros((2, 4096, 40), dtype=np.uint64)
     assert _lib.lib().dsd_dbg_read_rs_stamps(buf2.ctypes.data_as(C.c_void_p)) == 0
     names = [("conv + FiLM + gate", ["tile decode -> loads issued (x, FiLM, 5 weight blocks)",
                                      "x tile landed, FiLM + mask, LDS write, 2 barriers", "K walk (48 x 8 MFMA per wave)",
@@ -93,6 +93,9 @@ if ROWSPLIT:
               f"{np.median(life / np.maximum(real, 1e-12) / 1e9):.3f} GHz -> {np.median(real) * 1e6:.2f} us per workgroup")
         for lb, m, mn, mx in zip(labels, d.mean(axis=0), d.min(axis=0), d.max(axis=0)):
             print(f"    {lb:62s} mean {m:8.0f}  min {mn:8.0f}  max {mx:8.0f}")
+        if k == 0 and (st[:, 10:34] > 0).all():          # the conv walk step by step (wave 0; the stamp itself costs an lgkmcnt(0))
+            w = np.diff(np.concatenate([st[:, 2:3], st[:, 10:34]], axis=1), axis=1).mean(axis=0)
+            print("    conv walk, cycles per local step (256 = the MFMAs of two waves): " + " ".join(f"{v:.0f}" for v in w))
         if k == 0 and (st[:, 7] > 0).all():
             e = st[:, 7] - st[:, 6]
             print(f"    kernel entry -> every argument in SGPRs (one batch of scalar loads): mean {e.mean():6.0f}  min {e.min():6.0f}  max {e.max():6.0f};"
