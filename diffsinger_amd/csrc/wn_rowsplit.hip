@@ -16,6 +16,7 @@
 //     row-major, with the conditioner projection fetched as float4 during the K walk.
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "dsd_internal.h"
@@ -793,12 +794,11 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     RS_STAMP(1, 4);
     RS_STAMP(1, 5);
 }
+// (The out-proj in the same K-quarter layout - 4 steps of 16 MFMAs per wave, four partial tiles - was built and measured: 14.76
+// against 14.75 ms per loop; its walk is too short for the halved LDS reads to pay for the wider reduction.  Not kept.)
 #undef RS_PIN
 
-#ifndef DSD_RS_CONV_Q
-#define DSD_RS_CONV_Q 1
-#endif
-int wn_rs_conv_lds_bytes(int sw) { return (256 * sw + (DSD_RS_CONV_Q ? 4 : 2) * 64 * 36) * 4; }       // x tile + the K parts' transpose tiles
+int wn_rs_conv_lds_bytes(int sw, bool quarters) { return (256 * sw + (quarters ? 4 : 2) * 64 * 36) * 4; }       // x tile + the K parts' transpose tiles
 int wn_rs_out_lds_bytes() { return (256 * 48 + 2 * 64 * 36) * 4; }
 
 bool wn_rowsplit_supported(int C, int dil, long Ts) { return C == 256 && dil >= 1 && dil <= 16 && Ts < (1L << 22); }
@@ -810,19 +810,20 @@ static hipError_t rs_attr(K kern) {
 
 template <int SW, int RAG>
 static hipError_t rs_launch_conv(const WnLayerP& p, int nwg, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-#if DSD_RS_CONV_Q
-    constexpr auto kern = wn_conv_rq_kernel<SW, RAG>;
-#else
-    constexpr auto kern = wn_conv_rs_kernel<SW, RAG>;
-#endif
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = rs_attr(kern);
+        hipError_t e = rs_attr(wn_conv_rq_kernel<SW, RAG>);
+        if (e == hipSuccess) e = rs_attr(wn_conv_rs_kernel<SW, RAG>);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (nwg == 0) return hipSuccess;
-    const int ldsb = wn_rs_conv_lds_bytes(SW);
+    // The K-quarter layout needs 86 KiB of LDS (SW 48), one workgroup per CU; the K-half layout 67 KiB, two.  DSD_RS_CONV_Q=0/1
+    // forces the choice (A/B).
+    static const int q_env = getenv("DSD_RS_CONV_Q") ? atoi(getenv("DSD_RS_CONV_Q")) : -1;
+    const bool quarters = q_env >= 0 ? q_env != 0 : nwg <= 256;
+    const int ldsb = wn_rs_conv_lds_bytes(SW, quarters);
+    const auto kern = quarters ? wn_conv_rq_kernel<SW, RAG> : wn_conv_rs_kernel<SW, RAG>;
     if (e0 && e1)
         hipExtLaunchKernelGGL(kern, dim3(nwg), dim3(512), ldsb, st, e0, e1, 0, p);
     else
