@@ -334,8 +334,8 @@ def main():
         elif kind == "wavenet":
             kflops = 2 * 3 * Cc * 2 * Cc * vf                 # 786,432 FLOP/frame
             kbytes = (4 * Cc + 8 * Cc + 4 * Cc) * vf          # read x, read hoisted cond-proj, write gated z
-            kname = ("dilated conv k=3 + FiLM + sigmoid*tanh gate: wn_conv_rs_kernel (row-split pair, 32-frame tiles on "
-                     "one-utterance grids) or gemm_kernel<ST_FILM,3,EP_GATE> (other tile widths)")
+            kname = ("dilated conv k=3 + FiLM + sigmoid*tanh gate: wn_conv_rq_kernel / wn_conv_rs_kernel (row-split pair, "
+                     "32-frame tiles on one-utterance grids) or gemm_kernel<ST_FILM,3,EP_GATE> (other tile widths)")
         else:
             inner = Cc * bargs["expansion_factor"]
             kflops = 2 * Cc * 2 * inner * vf

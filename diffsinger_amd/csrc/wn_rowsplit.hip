@@ -442,7 +442,18 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
     constexpr int NE = 128 * W4 / 512;              // float4 per thread of 128 rows: 3 (SW 48), 4 (SW 80)
     constexpr int NS = NCH * 12;                    // weight blocks per packed row block: [chunk][tap][k16 in chunk]
     constexpr int NQ = 12;                          // steps per wave (one chunk)
-    constexpr int LW = 3, LB = 4;                   // late rows: written after step LW, barrier after step LB, read from step 6 on
+#ifndef DSD_RQ_LW
+#define DSD_RQ_LW 3
+#endif
+#ifndef DSD_RQ_LB
+#define DSD_RQ_LB 4
+#endif
+#ifndef DSD_RQ_CP
+#define DSD_RQ_CP 7
+#endif
+    constexpr int LW = DSD_RQ_LW, LB = DSD_RQ_LB;   // late rows: written after step LW, barrier after step LB, read from step 6 on
+    constexpr int CPS = DSD_RQ_CP;                  // the conditioner projection's two loads: steps CPS and CPS + 1
+    static_assert(LW >= 2 && LW <= LB && LB <= 4 && CPS >= 2 && CPS <= 10, "step 5 fetches step 6's operands");
     static_assert(NE <= 4, "the late rows are fetched two per step during steps 0 and 1");
     float* xs = lds;                                 // [C][SW]
     float* et = lds + C * SW;                        // [4 quarters][64][ES]: FiLM vector first, the quarters' accumulators last
@@ -561,8 +572,8 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
             RS_PIN();
             acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv0[j], bc[j][1], acc[0][1], 0, 0, 0);
             if (j < 2 && t < 2 && 2 * t + j < NE) svl[2 * t + j] = ld4(r_x, row_ts(x_row(2 * t + j, 1), Ts) + x_c4(2 * t + j) * 16, 0);
-            if (j == 0 && t == 7) cpg = ld4(r_c, row_ts(gch, Ts) + (tid & 7) * 16, 0);
-            if (j == 0 && t == 8) cpf = ld4(r_c, row_ts(gch + C, Ts) + (tid & 7) * 16, 0);
+            if (j == 0 && t == CPS) cpg = ld4(r_c, row_ts(gch, Ts) + (tid & 7) * 16, 0);
+            if (j == 0 && t == CPS + 1) cpf = ld4(r_c, row_ts(gch + C, Ts) + (tid & 7) * 16, 0);
             RS_PIN();
             acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv1[j], bc[j][0], acc[1][0], 0, 0, 0);
             RS_PIN();
