@@ -830,9 +830,9 @@ static hipError_t rs_launch_conv(const WnLayerP& p, int nwg, hipStream_t st, hip
     }
     if (nwg == 0) return hipSuccess;
     // The K-quarter layout needs 86 KiB of LDS (SW 48), one workgroup per CU; the K-half layout 67 KiB, two.  DSD_RS_CONV_Q=0/1
-    // forces the choice (A/B).
-    static const int q_env = getenv("DSD_RS_CONV_Q") ? atoi(getenv("DSD_RS_CONV_Q")) : -1;
-    const bool quarters = q_env >= 0 ? q_env != 0 : nwg <= 256;
+    // forces the choice (A/B, tests).
+    const char* q_ev = getenv("DSD_RS_CONV_Q");                  // read per call: tests/test_gpu_rowsplit.py switches it between handles
+    const bool quarters = q_ev ? atoi(q_ev) != 0 : nwg <= 256;
     const int ldsb = wn_rs_conv_lds_bytes(SW, quarters);
     const auto kern = quarters ? wn_conv_rq_kernel<SW, RAG> : wn_conv_rs_kernel<SW, RAG>;
     if (e0 && e1)

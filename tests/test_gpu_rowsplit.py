@@ -1,0 +1,80 @@
+"""The two wave layouts of the row-split conv (wn_rowsplit.hip: K halves x four row waves, K quarters x two 32-row waves),
+each forced on (DSD_RS_CONV_Q, read per launch) on grids of either side of the 256-workgroup rule that picks between them:
+one evaluation against the numpy oracle, at the acoustic shape (dilation <= 8), the pitch shape (dilation 16: the 80-float
+row stride), a ragged batch and tiles cut by the utterance end; and the two layouts against each other - they add the same
+products in a different order, so they may differ by rounding only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from diffsinger_amd import synth  # noqa: E402
+from gpu_util import check, dev, make_backbone, set_hp  # noqa: E402
+from oracle import backbones as ob  # noqa: E402
+
+TOL_NFE = 2e-5
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    set_hp()
+    yield
+    os.environ.pop("DSD_RS_CONV_Q", None)
+
+
+def _run(layout, in_dims, args, bsz, t_len, lengths=None):
+    os.environ["DSD_RS_CONV_Q"] = layout
+    try:
+        net, params = make_backbone("wavenet", in_dims, 1, args, 42)
+        x = synth.synth_normal((bsz, 1, in_dims, t_len), 21)
+        cond = synth.synth_normal((bsz, 256, t_len), 22)
+        t = (np.arange(bsz) * 211.5 + 3.25).astype(np.float32)
+        xd = dev(x)
+        if lengths is not None:
+            net.set_lengths(lengths, xd.device)
+        with torch.no_grad():
+            out = net(xd, dev(t), dev(cond))
+            again = net(xd, dev(t), dev(cond))
+        torch.cuda.synchronize()
+        assert torch.equal(out, again)
+        stats = net.stats()
+        net.release_native()
+        return out.cpu().numpy(), params, x, t, cond, stats
+    finally:
+        os.environ.pop("DSD_RS_CONV_Q", None)
+
+
+CASES = {
+    "acoustic_T1000": (128, dict(num_layers=8, num_channels=256, dilation_cycle_length=4), 1, 1000, None),     # 256 workgroups
+    "acoustic_T777": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 1, 777, None),       # last tile cut at 9 frames
+    "acoustic_T2048": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 1, 2048, None),     # 512 workgroups
+    "pitch_T900": (64, dict(num_layers=5, num_channels=256, dilation_cycle_length=5), 1, 900, None),           # dilation 16 in layer 4
+    "ragged_B2": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 2, 640, [640, 333]),     # tile list, per-item ends
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_rowsplit_conv_layouts_vs_oracle(name):
+    in_dims, args, bsz, t_len, lengths = CASES[name]
+    outs = {}
+    for layout in ("0", "1"):
+        out, params, x, t, cond, stats = _run(layout, in_dims, args, bsz, t_len, lengths)
+        assert stats["kernels_per_nfe"] == 2 * args["num_layers"] + 3, stats          # two launches per layer: the split path
+        want = ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=args["dilation_cycle_length"])
+        if lengths is not None:                       # frames past an item's end are the caller's to mask (toplevel.py:104)
+            for b, n in enumerate(lengths):
+                want_b = ob.wavenet_forward(params, x[b:b + 1, :, :, :n], t[b:b + 1], cond[b:b + 1, :, :n],
+                                            dilation_cycle_length=args["dilation_cycle_length"])
+                check(out[b:b + 1, :, :, :n], want_b, TOL_NFE, what=("row-split conv layout " + layout, name, b))
+        else:
+            check(out, want, TOL_NFE, what=("row-split conv layout " + layout, name))
+        outs[layout] = out
+    if lengths is None:
+        check(outs["1"], outs["0"], 2e-6, what=("K quarters vs K halves", name))
+    else:
+        for b, n in enumerate(lengths):
+            check(outs["1"][b:b + 1, :, :, :n], outs["0"][b:b + 1, :, :, :n], 2e-6, what=("K quarters vs K halves", name, b))
