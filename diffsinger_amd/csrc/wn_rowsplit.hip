@@ -101,9 +101,10 @@ __device__ __forceinline__ void rs_pin_args(const WnLayerP& p) {
 #ifndef DSD_RS_DEPTH
 #define DSD_RS_DEPTH 3
 #endif
-#ifndef DSD_RS_ONE_BARRIER
-#define DSD_RS_ONE_BARRIER 1
-#endif
+// (Tried: the two MFMA operand registers swapped - they have the same lane pattern, so D^T = X^T W^T needs no other change and a
+// lane's four accumulator values become four consecutive FRAMES of one row: the tails' LDS transposes are then one
+// ds_write_b128 per accumulator instead of four ds_write_b32, bit-identical results.  No effect on the loop time, here
+// (14.76 = 14.75 ms) or in the fused kernel's gate / epilogue (67.3 = 67.3 ms at B = 8): those phases are not LDS-issue bound.)
 #ifndef DSD_RS_DEPTH_OUT
 #define DSD_RS_DEPTH_OUT DSD_RS_DEPTH
 #endif
@@ -193,6 +194,9 @@ extern "C" int dsd_dbg_read_rs_stamps(unsigned long long* host_out) {
 // weight load for step s + 5 and an operand load behind the first two, one LDS read pair of step s + 1 behind each of
 // the first four.
 #define RS_PIN() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ f32x4 rs_mfma(float wfrag, float xfrag, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag, xfrag, acc, 0, 0, 0);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Both kernels: C = 256 (NCH = 4 chunks of 64 channels), 512 threads = 8 waves = two K HALVES of four row waves: wave
@@ -338,14 +342,14 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
         constexpr int nb0 = rs_issued_before(s, NH), nb1 = rs_issued_before(s + 1, NH);     // this step issues blocks [nb0, nb1)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bc[j][0], acc[0], 0, 0, 0);
+            acc[0] = rs_mfma(wv[j], bc[j][0], acc[0]);
             if (!(DSD_RS_DIAG & 1) && j < 2 && nb0 + j < nb1) W[(nb0 + j) % DMAX] = ld4(r_w, wl + ((nb0 + j) & 3) * 1024, ((nb0 + j) >> 2) * 4096);
             if (!(DSD_RS_DIAG & 2) && j == 0 && !(DSD_RS_LATE_B == 11 && s == 11) && s + 1 < NH) {      // the next step's 4 LDS read pairs in one burst
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) read_b1(bn, s + 1, jj);
             }
             RS_PIN();
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bc[j][1], acc[1], 0, 0, 0);
+            acc[1] = rs_mfma(wv[j], bc[j][1], acc[1]);
 #if !DSD_RS_EARLY
             if (!(DSD_RS_DIAG & 4) && j == 0 && s < NE) svl[s] = ld4(r_x, row_ts(x_row(s, 1), Ts) + x_c4(s) * 16, 0);
             if (!(DSD_RS_DIAG & 8) && j == 0 && s == 12) cpg = ld4(r_c, row_ts(gch, Ts) + (tid & 7) * 16, 0);
@@ -372,44 +376,23 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
     RS_STAMP(0, 3);
 
     // ---------------- the two K halves' sums; accumulators -> LDS tile (rows [0, 32): gate, [32, 64): filter) ----------------
-#if DSD_RS_ONE_BARRIER
-    // each half transposes its own accumulators into its own tile; ONE barrier; the gate's threads add the two tiles
+    // each half writes its own accumulators into its own tile; ONE barrier; the gate's threads add the two tiles (first version:
+    // half 1 writes, barrier, half 0 adds and transposes, barrier - 15.29 against 15.02 ms per loop)
     {
         float* tk = kh == 0 ? et : red;
-        const int trow = (w & 1) * 32 + (w >> 1) * 16 + rq;
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tk[(trow + r) * ES + n * 16 + lcol] = acc[n][r];
-    }
-    __syncthreads();
-#else
-    if (kh == 1) {
-        *reinterpret_cast<f32x4*>(&red[((w * 2 + 0) * 64 + lane) * 4]) = acc[0];
-        *reinterpret_cast<f32x4*>(&red[((w * 2 + 1) * 64 + lane) * 4]) = acc[1];
-    }
-    __syncthreads();
-    if (kh == 0) {
-        const int trow = (w & 1) * 32 + (w >> 1) * 16 + rq;
+        const int trow = (w & 1) * 32 + (w >> 1) * 16;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(&red[((w * 2 + n) * 64 + lane) * 4]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) et[(trow + r) * ES + n * 16 + lcol] = acc[n][r] + o[r];
+            for (int r = 0; r < 4; ++r) tk[(trow + rq + r) * ES + n * 16 + lcol] = acc[n][r];
         }
     }
     __syncthreads();
-#endif
     if (tid < 256) {
         const int cw = tid >> 3, c4 = tid & 7;
-#if DSD_RS_ONE_BARRIER
         const f32x4 g = *reinterpret_cast<const f32x4*>(&et[cw * ES + c4 * 4]) + *reinterpret_cast<const f32x4*>(&red[cw * ES + c4 * 4]);
         const f32x4 f = *reinterpret_cast<const f32x4*>(&et[(32 + cw) * ES + c4 * 4]) +
                         *reinterpret_cast<const f32x4*>(&red[(32 + cw) * ES + c4 * 4]);
-#else
-        const f32x4 g = *reinterpret_cast<const f32x4*>(&et[cw * ES + c4 * 4]);
-        const f32x4 f = *reinterpret_cast<const f32x4*>(&et[(32 + cw) * ES + c4 * 4]);
-#endif
         f32x4 z;
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = sigmoid_fast(g[e] + cpg[e]) * tanh_fast(f[e] + cpf[e]);      // wavenet.py:41-42
@@ -562,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
         float (&bn)[4][2] = bq[(t + 1) & 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv0[j], bc[j][0], acc[0][0], 0, 0, 0);
+            acc[0][0] = rs_mfma(wv0[j], bc[j][0], acc[0][0]);
             if (t == 0) w_load(1 + j / 2, j & 1);                // step 0 issues steps 1 and 2 ...
             else if (j < 2 && t + 2 < NQ) w_load(t + 2, j);      // ... step t >= 1 issues step t + 2
             if (j == 0 && t + 1 < NQ) {                          // the next step's 4 LDS read pairs in one burst
@@ -570,14 +553,14 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
                 for (int jj = 0; jj < 4; ++jj) read_b1(bn, t + 1, jj);
             }
             RS_PIN();
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv0[j], bc[j][1], acc[0][1], 0, 0, 0);
+            acc[0][1] = rs_mfma(wv0[j], bc[j][1], acc[0][1]);
             if (j < 2 && t < 2 && 2 * t + j < NE) svl[2 * t + j] = ld4(r_x, row_ts(x_row(2 * t + j, 1), Ts) + x_c4(2 * t + j) * 16, 0);
             if (j == 0 && t == CPS) cpg = ld4(r_c, row_ts(gch, Ts) + (tid & 7) * 16, 0);
             if (j == 0 && t == CPS + 1) cpf = ld4(r_c, row_ts(gch + C, Ts) + (tid & 7) * 16, 0);
             RS_PIN();
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv1[j], bc[j][0], acc[1][0], 0, 0, 0);
+            acc[1][0] = rs_mfma(wv1[j], bc[j][0], acc[1][0]);
             RS_PIN();
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv1[j], bc[j][1], acc[1][1], 0, 0, 0);
+            acc[1][1] = rs_mfma(wv1[j], bc[j][1], acc[1][1]);
             RS_PIN();
         }
         if (t == LW) {
@@ -726,7 +709,7 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
         float (&bn)[4][2] = bq[(s + 1) & 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bc[j][0], acc[0], 0, 0, 0);
+            acc[0] = rs_mfma(wv[j], bc[j][0], acc[0]);
             if (j == 0 && s + DEPTH_OUT - 1 < NH)
                 W[(s + DEPTH_OUT - 1) % DEPTH_OUT] = ld4(r_w, wl + ((s + DEPTH_OUT - 1) & 3) * 1024, ((s + DEPTH_OUT - 1) >> 2) * 4096);
             if (j == 0 && s + 1 < NH) {          // the next step's 4 LDS read pairs in one burst: spread one per MFMA pair
@@ -737,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
                 }
             }
             RS_PIN();
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], bc[j][1], acc[1], 0, 0, 0);
+            acc[1] = rs_mfma(wv[j], bc[j][1], acc[1]);
 #if !DSD_RS_EARLY
             if (j == 0 && s == 1) pre[0] = ld4(r_e, ev0, 0);
             if (j == 0 && s == 2) pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
@@ -759,43 +742,23 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     RS_STAMP(1, 3);
 
     // ---------------- the two K halves' sums; residual / skip (wavenet.py:45-48), row-major ----------------
-#if DSD_RS_ONE_BARRIER
     {
         float* tk = kh == 0 ? et : red;
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 2; ++n) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) tk[(16 * w + rq + r) * ES + n * 16 + lcol] = acc[n][r];
-    }
-    __syncthreads();
-#else
-    if (kh == 1) {
-        *reinterpret_cast<f32x4*>(&red[((w * 2 + 0) * 64 + lane) * 4]) = acc[0];
-        *reinterpret_cast<f32x4*>(&red[((w * 2 + 1) * 64 + lane) * 4]) = acc[1];
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(&red[((w * 2 + n) * 64 + lane) * 4]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) et[(16 * w + rq + r) * ES + n * 16 + lcol] = acc[n][r] + o[r];
         }
     }
     __syncthreads();
-#endif
     if (tid < 256) {
         const __amdgpu_buffer_rsrc_t r_o = rsrc((const float*)(is_res ? xo : sa) + eoff);
         const float scale = is_res ? 0.70710678118654752440f : 1.f;     // (x + o) / sqrt(2): times the fp32 reciprocal
         const bool add_pre = is_res || !p.first_layer;                  // the first layer's skip sum is its own output
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-#if DSD_RS_ONE_BARRIER
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(&et[((tid >> 3) + 32 * k) * ES + (tid & 7) * 4]) +
                              *reinterpret_cast<const f32x4*>(&red[((tid >> 3) + 32 * k) * ES + (tid & 7) * 4]);
-#else
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&et[((tid >> 3) + 32 * k) * ES + (tid & 7) * 4]);
-#endif
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ((add_pre ? pre[k][e] : 0.f) + a4[e]) * scale;
