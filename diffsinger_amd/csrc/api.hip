@@ -1399,8 +1399,13 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             static const int rs_env = getenv("DSD_ROWSPLIT") ? atoi(getenv("DSD_ROWSPLIT")) : -1;
             const bool rs_ok = rs_env != 0 && wn_rowsplit_supported(C, dil, Ts);
             GemmCall g = make_gemm(h, h->g_conv[l], h->xh, xs, Ts, B, T, ST_FILM, EP_GATE, dil, false, rs_ok);
-            if (rs_ok && g.nb == 1 && g.fast) {
-                const bool ragged = h->use_cg && !h->lens_host.empty();
+            const bool ragged = h->use_cg && !h->lens_host.empty();
+            // 48-frame tiles where they make a dense launch ONE round of workgroups and 32-frame tiles do not (T in (1024, 1536]
+            // at B = 1: 35-48 tiles of 32 frames = 280-384 workgroups for 256 CUs): 21.9 -> see DESIGN 4.2.  DSD_RS_BN48=0: off
+            static const int bn48_env = getenv("DSD_RS_BN48") ? atoi(getenv("DSD_RS_BN48")) : -1;
+            const bool bn48 = rs_ok && bn48_env != 0 && !ragged && (long)B * ((T + 31) / 32) * 8 > 256 && (long)B * ((T + 47) / 48) * 8 <= 256;
+            if (rs_ok && ((g.nb == 1 && g.fast) || bn48)) {
+                const int bn = bn48 ? 48 : 32;
                 WnLayerP p;
                 memset(&p, 0, sizeof(p));
                 p.Aconv = h->blob + h->g_conv[l].a_off;
@@ -1411,15 +1416,15 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                 p.cp = h->cp + (long)l * 2 * C * Ts; p.cp_bstride = cps;
                 film_of(h, l, film_col0, film_colb, p.film, p.film_cstride, p.film_col0, p.film_colb);
                 p.dil = dil;
-                p.T = T; p.tiles_per_b = (T + 31) / 32; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
+                p.T = T; p.tiles_per_b = (T + bn - 1) / bn; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
                 p.first_layer = (l == 0);
                 if (ragged) { p.lens = h->lens_dev; p.cgmap = h->cg_dev[1]; p.ncg = h->cg_n[1]; }
                 timed_begin();
                 if (timed_now) wn_rowsplit_set_timing_events(h->ev_pool[h->ev_used].first, h->ev_pool[h->ev_used].second);
-                hipError_t le = launch_wn_rowsplit(p, 0, C, B, st);
+                hipError_t le = launch_wn_rowsplit(p, 0, C, B, bn, st);
                 if (timed_now) wn_rowsplit_set_timing_events(nullptr, nullptr);
                 timed_end();
-                if (le == hipSuccess) le = launch_wn_rowsplit(p, 1, C, B, st);
+                if (le == hipSuccess) le = launch_wn_rowsplit(p, 1, C, B, bn, st);
                 if (le != hipSuccess) return fail(h, DSD_EHIP, "row-split WaveNet layer launch failed: %s", hipGetErrorString(le));
                 continue;
             }

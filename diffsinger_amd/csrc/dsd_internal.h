@@ -163,7 +163,7 @@ void wn_layer_set_timing_events(hipEvent_t start, hipEvent_t stop);
 // wn_rowsplit.hip: the same layer as two launches with the 2C rows split over 2C / 64 workgroups per 32-frame tile, for
 // grids too small for full-row tiles.  which = 0: conv + FiLM + gate (xin -> z); 1: out-proj + residual / skip (in place
 // when xout == xin)
-hipError_t launch_wn_rowsplit(const WnLayerP& p, int which, int C, int batch, hipStream_t st);
+hipError_t launch_wn_rowsplit(const WnLayerP& p, int which, int C, int batch, int bn, hipStream_t st);
 hipError_t wn_rowsplit_init_all();
 bool wn_rowsplit_supported(int C, int dil, long Ts);
 void wn_rowsplit_set_timing_events(hipEvent_t start, hipEvent_t stop);

@@ -33,6 +33,8 @@ __device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((flo
 // byte offset of a row as a 24-bit multiply (rows < 512; the host keeps Ts below 2^22): a 32-bit `row * Ts + c` compiles to
 // v_mad_u64_u32, whose 64-bit addend has an undefined high half - the register allocator parked it on a register with a load
 // in flight (the FiLM value) and the hardware dependency put an s_waitcnt vmcnt(0) in front of the x-tile loads.
+template <int B4>
+__device__ __forceinline__ int div_b4(int x) { return B4 == 8 ? x >> 3 : fdiv_floor(x, 1.0f / B4); }     // x / B4, x < 2^16
 __device__ __forceinline__ int row_ts(int row, int Ts) { return (int)__umul24((unsigned)row, (unsigned)(Ts * 4)); }   // BYTES
 
 constexpr unsigned kRange = 0x7FFFFFF0u;
@@ -414,15 +416,19 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
 // others are fetched behind the first two steps' MFMAs, written after step 3, barrier after step 4.  The ring holds three
 // steps but only step 0's two blocks are in the prologue burst; step 0 issues steps 1 and 2.
 // ---------------------------------------------------------------------------------------------------------------
-template <int SW, int RAG>
+// NCB: 16-frame column blocks of the tile (2: 32 frames; 3: 48 frames - one round of workgroups for T in (1024, 1536] at B = 1);
+// SW: LDS row stride of the x tile (= 16 or 48 mod 64: the four k rows of a B fragment in different banks), HL: halo
+template <int NCB, int SW, int HL, int RAG>
 __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
+    constexpr int BN = 16 * NCB, ES = BN + 4, B4 = BN / 4;      // (shadow the 32-frame constants of the K-half kernels)
+    static_assert(SW >= BN + 2 * HL && (SW % 64 == 16 || SW % 64 == 48), "x tile row stride");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     RS_STAMP(0, 6);
     rs_pin_args(p);
     RS_STAMP(0, 7);
-    constexpr int HL = SW == 48 ? 8 : 16;
     constexpr int W4 = (BN + 2 * HL) / 4;
-    constexpr int NE = 128 * W4 / 512;              // float4 per thread of 128 rows: 3 (SW 48), 4 (SW 80)
+    constexpr int NE = 128 * W4 / 512;              // float4 per thread of 128 rows: 3 - 5
+    static_assert(128 * W4 % 512 == 0, "whole float4 slots per thread");
     constexpr int NS = NCH * 12;                    // weight blocks per packed row block: [chunk][tap][k16 in chunk]
     constexpr int NQ = 12;                          // steps per wave (one chunk)
 #ifndef DSD_RQ_LW
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
     constexpr int LW = DSD_RQ_LW, LB = DSD_RQ_LB;   // late rows: written after step LW, barrier after step LB, read from step 6 on
     constexpr int CPS = DSD_RQ_CP;                  // the conditioner projection's two loads: steps CPS and CPS + 1
     static_assert(LW >= 2 && LW <= LB && LB <= 4 && CPS >= 2 && CPS <= 10, "step 5 fetches step 6's operands");
-    static_assert(NE <= 4, "the late rows are fetched two per step during steps 0 and 1");
+    static_assert(NE <= 6 && DSD_RQ_LW >= 2, "the late rows are fetched two per step during steps 0 .. 2");
     float* xs = lds;                                 // [C][SW]
     float* et = lds + C * SW;                        // [4 quarters][64][ES]: FiLM vector first, the quarters' accumulators last
 
@@ -490,7 +496,9 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
     RS_PIN();
     // the hoisted conditioner projection (+ biases) of this tile's 32 channels, row-major float4 for the gate below:
     // thread (of the first 256) -> channel tid >> 3, frames 4 * (tid & 7)
-    const int gch = 32 * mtile + ((tid & 255) >> 3);
+    // (threads beyond the tile's 32 x B4 float4: a copy of the last channel's, unused)
+    const int gcw = min(div_b4<B4>(tid), 31), gc4 = tid - div_b4<B4>(tid) * B4;
+    const int gch = 32 * mtile + gcw;
     const __amdgpu_buffer_rsrc_t r_c = rsrc(p.cp + (long)bu * p.cp_bstride + t0u);
     f32x4 cpg = f32x4{0.f, 0.f, 0.f, 0.f}, cpf = cpg;
     RS_STAMP(0, 1);
@@ -520,20 +528,20 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
     RS_STAMP(0, 2);
 
     // ---------------- K walk ----------------
-    f32x4 acc[2][2];
+    f32x4 acc[2][NCB];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[rb][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NCB; ++n) acc[rb][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* bt0 = xs + (kq * 64 + lrow) * SW + HL + lcol - p.dil;
     const float* bt1 = bt0 + p.dil;
     const float* bt2 = bt1 + p.dil;
-    float bq[2][4][2];
-    auto read_b1 = [&](float (&bv)[4][2], int t, int j) {        // both column blocks of k4 step j of local step t
+    float bq[2][4][NCB];
+    auto read_b1 = [&](float (&bv)[4][NCB], int t, int j) {      // every column block of k4 step j of local step t
         const int tap = (t % 6) / 2, k16 = (t / 6) * 2 + (t % 2);
         const float* base = (tap == 0 ? bt0 : (tap == 1 ? bt1 : bt2)) + (k16 * 16 + j * 4) * SW;
-        bv[j][0] = base[0];
-        bv[j][1] = base[16];
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) bv[j][n] = base[16 * n];
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) read_b1(bq[0], 0, j);
@@ -541,27 +549,33 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
     rs_static_for<0, NQ>([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value;
         const f32x4 wv0 = W[t % 3][0], wv1 = W[t % 3][1];
-        float (&bc)[4][2] = bq[t & 1];
-        float (&bn)[4][2] = bq[(t + 1) & 1];
+        float (&bc)[4][NCB] = bq[t & 1];
+        float (&bn)[4][NCB] = bq[(t + 1) & 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc[0][0] = rs_mfma(wv0[j], bc[j][0], acc[0][0]);
             if (t == 0) w_load(1 + j / 2, j & 1);                // step 0 issues steps 1 and 2 ...
             else if (j < 2 && t + 2 < NQ) w_load(t + 2, j);      // ... step t >= 1 issues step t + 2
-            if (j == 0 && t + 1 < NQ) {                          // the next step's 4 LDS read pairs in one burst
+            if (j == 0 && t + 1 < NQ) {                          // the next step's LDS reads in one burst
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) read_b1(bn, t + 1, jj);
             }
             RS_PIN();
             acc[0][1] = rs_mfma(wv0[j], bc[j][1], acc[0][1]);
-            if (j < 2 && t < 2 && 2 * t + j < NE) svl[2 * t + j] = ld4(r_x, row_ts(x_row(2 * t + j, 1), Ts) + x_c4(2 * t + j) * 16, 0);
-            if (j == 0 && t == CPS) cpg = ld4(r_c, row_ts(gch, Ts) + (tid & 7) * 16, 0);
-            if (j == 0 && t == CPS + 1) cpf = ld4(r_c, row_ts(gch + C, Ts) + (tid & 7) * 16, 0);
+            if (j < 2 && t < 3 && 2 * t + j < NE) svl[2 * t + j] = ld4(r_x, row_ts(x_row(2 * t + j, 1), Ts) + x_c4(2 * t + j) * 16, 0);
+            if (j == 0 && t == CPS) cpg = ld4(r_c, row_ts(gch, Ts) + gc4 * 16, 0);
+            if (j == 0 && t == CPS + 1) cpf = ld4(r_c, row_ts(gch + C, Ts) + gc4 * 16, 0);
             RS_PIN();
-            acc[1][0] = rs_mfma(wv1[j], bc[j][0], acc[1][0]);
-            RS_PIN();
-            acc[1][1] = rs_mfma(wv1[j], bc[j][1], acc[1][1]);
-            RS_PIN();
+#pragma unroll
+            for (int n = 2; n < NCB; ++n) {
+                acc[0][n] = rs_mfma(wv0[j], bc[j][n], acc[0][n]);
+                RS_PIN();
+            }
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) {
+                acc[1][n] = rs_mfma(wv1[j], bc[j][n], acc[1][n]);
+                RS_PIN();
+            }
         }
         if (t == LW) {
 #pragma unroll
@@ -582,13 +596,13 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < NCB; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tk[(rb * 32 + wr * 16 + rq + r) * ES + n * 16 + lcol] = acc[rb][n][r];
     }
     __syncthreads();
-    if (tid < 256) {
-        const int cw = tid >> 3, c4 = tid & 7;
+    if (tid < 32 * B4) {
+        const int cw = gcw, c4 = gc4;
         f32x4 g = *reinterpret_cast<const f32x4*>(&et[cw * ES + c4 * 4]);
         f32x4 f = *reinterpret_cast<const f32x4*>(&et[(32 + cw) * ES + c4 * 4]);
 #pragma unroll
@@ -606,12 +620,14 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
     RS_STAMP(0, 5);
 }
 
-template <int RAG>
+template <int NCB, int RAG>
 __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
+    constexpr int BN = 16 * NCB, ES = BN + 4, B4 = BN / 4;      // (shadow the 32-frame constants)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     rs_pin_args(p);
     constexpr int SZ = 48;
-    constexpr int NZ = C * (BN / 4) / 512;          // staged float4 per thread: 4
+    constexpr int NZ = C * B4 / 512;                // staged float4 per thread: 4 / 6
+    static_assert(SZ >= BN && NCB <= 3, "z tile row stride");
     constexpr int NS = NCH * 4;
     constexpr int NH = NS / 2;
     float* zs = lds;                                 // [C][SZ]
@@ -634,15 +650,15 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
 
     // ---------------- prologue: z tile (all C channels), the first weight blocks, bias ----------------
     const __amdgpu_buffer_rsrc_t r_z = rsrc(p.z + (long)bu * p.x_bstride + t0u);
-    // staging slot u of a thread = float4 (idx & 7) of row idx >> 3, idx = tid + 512 u: slot u lies in 64-channel chunk u
+    // staging slot u of a thread = float4 idx % B4 of row idx / B4, idx = tid + 512 u
     f32x4 sv[NZ];
     auto z_load = [&](int u) {
-        const int idx = tid + 512 * u;
-        sv[u] = ld4(r_z, row_ts(idx >> 3, Ts) + (idx & 7) * 16, 0);
+        const int idx = tid + 512 * u, row = div_b4<B4>(idx);
+        sv[u] = ld4(r_z, row_ts(row, Ts) + (idx - row * B4) * 16, 0);
     };
     auto z_write = [&](int u) {
-        const int idx = tid + 512 * u;
-        *reinterpret_cast<f32x4*>(&zs[(idx >> 3) * SZ + (idx & 7) * 4]) = sv[u];
+        const int idx = tid + 512 * u, row = div_b4<B4>(idx);
+        *reinterpret_cast<f32x4*>(&zs[row * SZ + (idx - row * B4) * 4]) = sv[u];
     };
 #if DSD_RS_OUT_LATE
     z_load(0);
@@ -670,7 +686,9 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     const long eoff = (long)bu * p.x_bstride + (long)(is_res ? 64 * mtile : 64 * mtile - C) * Ts + t0u;
     const unsigned long long xa = (unsigned long long)p.xin, sa = (unsigned long long)p.skip, xo = (unsigned long long)p.xout;
     const __amdgpu_buffer_rsrc_t r_e = rsrc((const float*)(is_res ? xa : sa) + eoff);
-    const int ev0 = row_ts((tid & 255) >> 3, Ts) + (tid & 7) * 16;
+    // (threads beyond the tile's 32 x B4 float4 per half: a copy of the last row's, unused)
+    const int erow = min(div_b4<B4>(tid), 31), ec4 = tid - div_b4<B4>(tid) * B4;
+    const int ev0 = row_ts(erow, Ts) + ec4 * 16;
     f32x4 pre[2];
 #if DSD_RS_EARLY
     if (wave < 4) {
@@ -691,22 +709,23 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     RS_STAMP(1, 2);
 
     // ---------------- K walk ----------------
-    f32x4 acc[2];
+    f32x4 acc[NCB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[0][r] = acc[1][r] = kh == 0 ? bo[r] : 0.f;     // the bias rides in the first half
+    for (int n = 0; n < NCB; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[n][r] = kh == 0 ? bo[r] : 0.f;             // the bias rides in the first half
     const float* zt = zs + (kh * 128 + lrow) * SZ + lcol;
-    float bq[2][4][2];
+    float bq[2][4][NCB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        bq[0][j][0] = zt[(j * 4) * SZ];
-        bq[0][j][1] = zt[(j * 4) * SZ + 16];
-    }
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) bq[0][j][n] = zt[(j * 4) * SZ + 16 * n];
     RS_PIN();
 #pragma unroll
     for (int s = 0; s < NH; ++s) {
         const f32x4 wv = W[s % DEPTH_OUT];
-        float (&bc)[4][2] = bq[s & 1];
-        float (&bn)[4][2] = bq[(s + 1) & 1];
+        float (&bc)[4][NCB] = bq[s & 1];
+        float (&bn)[4][NCB] = bq[(s + 1) & 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc[0] = rs_mfma(wv[j], bc[j][0], acc[0]);
@@ -714,10 +733,9 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
                 W[(s + DEPTH_OUT - 1) % DEPTH_OUT] = ld4(r_w, wl + ((s + DEPTH_OUT - 1) & 3) * 1024, ((s + DEPTH_OUT - 1) >> 2) * 4096);
             if (j == 0 && s + 1 < NH) {          // the next step's 4 LDS read pairs in one burst: spread one per MFMA pair
 #pragma unroll                                   // they cost the walk 12 % more (measured 5.0 k vs 4.45 k cycles)
-                for (int jj = 0; jj < 4; ++jj) {
-                    bn[jj][0] = zt[((s + 1) * 16 + jj * 4) * SZ];
-                    bn[jj][1] = zt[((s + 1) * 16 + jj * 4) * SZ + 16];
-                }
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int n = 0; n < NCB; ++n) bn[jj][n] = zt[((s + 1) * 16 + jj * 4) * SZ + 16 * n];
             }
             RS_PIN();
             acc[1] = rs_mfma(wv[j], bc[j][1], acc[1]);
@@ -726,6 +744,11 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
             if (j == 0 && s == 2) pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
 #endif
             RS_PIN();
+#pragma unroll
+            for (int n = 2; n < NCB; ++n) {
+                acc[n] = rs_mfma(wv[j], bc[j][n], acc[n]);
+                RS_PIN();
+            }
         }
 #if DSD_RS_OUT_LATE
         if (s == 1) {
@@ -745,20 +768,20 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     {
         float* tk = kh == 0 ? et : red;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NCB; ++n) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) tk[(16 * w + rq + r) * ES + n * 16 + lcol] = acc[n][r];
         }
     }
     __syncthreads();
-    if (tid < 256) {
+    if (tid < 32 * B4) {
         const __amdgpu_buffer_rsrc_t r_o = rsrc((const float*)(is_res ? xo : sa) + eoff);
         const float scale = is_res ? 0.70710678118654752440f : 1.f;     // (x + o) / sqrt(2): times the fp32 reciprocal
         const bool add_pre = is_res || !p.first_layer;                  // the first layer's skip sum is its own output
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&et[((tid >> 3) + 32 * k) * ES + (tid & 7) * 4]) +
-                             *reinterpret_cast<const f32x4*>(&red[((tid >> 3) + 32 * k) * ES + (tid & 7) * 4]);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&et[(erow + 32 * k) * ES + ec4 * 4]) +
+                             *reinterpret_cast<const f32x4*>(&red[(erow + 32 * k) * ES + ec4 * 4]);
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ((add_pre ? pre[k][e] : 0.f) + a4[e]) * scale;
@@ -772,32 +795,21 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
 // against 14.75 ms per loop; its walk is too short for the halved LDS reads to pay for the wider reduction.  Not kept.)
 #undef RS_PIN
 
-int wn_rs_conv_lds_bytes(int sw, bool quarters) { return (256 * sw + (quarters ? 4 : 2) * 64 * 36) * 4; }       // x tile + the K parts' transpose tiles
-int wn_rs_out_lds_bytes() { return (256 * 48 + 2 * 64 * 36) * 4; }
-
-bool wn_rowsplit_supported(int C, int dil, long Ts) { return C == 256 && dil >= 1 && dil <= 16 && Ts < (1L << 22); }
-
 template <typename K>
 static hipError_t rs_attr(K kern) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-template <int SW, int RAG>
-static hipError_t rs_launch_conv(const WnLayerP& p, int nwg, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = rs_attr(wn_conv_rq_kernel<SW, RAG>);
-        if (e == hipSuccess) e = rs_attr(wn_conv_rs_kernel<SW, RAG>);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    if (nwg == 0) return hipSuccess;
-    // The K-quarter layout needs 86 KiB of LDS (SW 48), one workgroup per CU; the K-half layout 67 KiB, two.  DSD_RS_CONV_Q=0/1
-    // forces the choice (A/B, tests).
-    const char* q_ev = getenv("DSD_RS_CONV_Q");                  // read per call: tests/test_gpu_rowsplit.py switches it between handles
-    const bool quarters = q_ev ? atoi(q_ev) != 0 : nwg <= 256;
-    const int ldsb = wn_rs_conv_lds_bytes(SW, quarters);
-    const auto kern = quarters ? wn_conv_rq_kernel<SW, RAG> : wn_conv_rs_kernel<SW, RAG>;
+// x tile + the K parts' transpose tiles
+int wn_rs_conv_lds_bytes(int sw, int bn, bool quarters) { return (256 * sw + (quarters ? 4 : 2) * 64 * (bn + 4)) * 4; }
+int wn_rs_out_lds_bytes(int bn) { return (256 * 48 + 2 * 64 * (bn + 4)) * 4; }
+
+// 48-frame tiles (NCB = 3) exist in the K-quarter layout only, on dense batches: they are chosen where they make the launch ONE
+// round of workgroups (api.hip)
+bool wn_rowsplit_supported(int C, int dil, long Ts) { return C == 256 && dil >= 1 && dil <= 16 && Ts < (1L << 22); }
+
+template <typename K>
+static hipError_t rs_go(K kern, const WnLayerP& p, int nwg, int ldsb, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     if (e0 && e1)
         hipExtLaunchKernelGGL(kern, dim3(nwg), dim3(512), ldsb, st, e0, e1, 0, p);
     else
@@ -805,17 +817,46 @@ static hipError_t rs_launch_conv(const WnLayerP& p, int nwg, hipStream_t st, hip
     return hipGetLastError();
 }
 
-template <int RAG>
-static hipError_t rs_launch_out(const WnLayerP& p, int nwg, hipStream_t st) {
+template <int SW, int RAG>
+static hipError_t rs_launch_conv(const WnLayerP& p, int nwg, int bn, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    constexpr int HL = SW == 48 ? 8 : 16;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = rs_attr(wn_out_rs_kernel<RAG>);
+        hipError_t e = rs_attr(wn_conv_rq_kernel<2, SW, HL, RAG>);
+        if (e == hipSuccess) e = rs_attr(wn_conv_rs_kernel<SW, RAG>);
+        if (e == hipSuccess && !RAG) e = rs_attr(wn_conv_rq_kernel<3, 80, HL, 0>);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (nwg == 0) return hipSuccess;
-    hipLaunchKernelGGL((wn_out_rs_kernel<RAG>), dim3(nwg), dim3(512), wn_rs_out_lds_bytes(), st, p);
-    return hipGetLastError();
+    if (bn == 48) {
+        if (RAG) return hipErrorInvalidValue;
+        return rs_go(wn_conv_rq_kernel<3, 80, HL, 0>, p, nwg, wn_rs_conv_lds_bytes(80, 48, true), st, e0, e1);
+    }
+    // The K-quarter layout needs 86 KiB of LDS (SW 48), one workgroup per CU; the K-half layout 67 KiB, two.  DSD_RS_CONV_Q=0/1
+    // forces the choice (A/B, tests).
+    const char* q_ev = getenv("DSD_RS_CONV_Q");                  // read per call: tests/test_gpu_rowsplit.py switches it between handles
+    const bool quarters = q_ev ? atoi(q_ev) != 0 : nwg <= 256;
+    const int ldsb = wn_rs_conv_lds_bytes(SW, 32, quarters);
+    if (quarters) return rs_go(wn_conv_rq_kernel<2, SW, HL, RAG>, p, nwg, ldsb, st, e0, e1);
+    return rs_go(wn_conv_rs_kernel<SW, RAG>, p, nwg, ldsb, st, e0, e1);
+}
+
+template <int RAG>
+static hipError_t rs_launch_out(const WnLayerP& p, int nwg, int bn, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = rs_attr(wn_out_rs_kernel<2, RAG>);
+        if (e == hipSuccess && !RAG) e = rs_attr(wn_out_rs_kernel<3, 0>);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (nwg == 0) return hipSuccess;
+    if (bn == 48) {
+        if (RAG) return hipErrorInvalidValue;
+        return rs_go(wn_out_rs_kernel<3, 0>, p, nwg, wn_rs_out_lds_bytes(48), st, nullptr, nullptr);
+    }
+    return rs_go(wn_out_rs_kernel<2, RAG>, p, nwg, wn_rs_out_lds_bytes(32), st, nullptr, nullptr);
 }
 
 static thread_local hipEvent_t g_rs_ev0 = nullptr, g_rs_ev1 = nullptr;
@@ -824,14 +865,15 @@ void wn_rowsplit_set_timing_events(hipEvent_t start, hipEvent_t stop) {
     g_rs_ev1 = stop;
 }
 
-// which = 0: conv + FiLM + gate (p.xin -> p.z);  which = 1: out-proj + residual / skip (p.z, p.xin -> p.xout, p.skip)
-hipError_t launch_wn_rowsplit(const WnLayerP& p, int which, int C_, int batch, hipStream_t st) {
-    if (C_ != 256) return hipErrorInvalidValue;
+// which = 0: conv + FiLM + gate (p.xin -> p.z);  which = 1: out-proj + residual / skip (p.z, p.xin -> p.xout, p.skip);
+// bn = frames per tile (32, or 48 on dense batches): p.tiles_per_b counts tiles of that width
+hipError_t launch_wn_rowsplit(const WnLayerP& p, int which, int C_, int batch, int bn, hipStream_t st) {
+    if (C_ != 256 || (bn != 32 && bn != 48)) return hipErrorInvalidValue;
     const int nwg = (p.cgmap ? p.ncg : batch * p.tiles_per_b) * 8;
-    if (which == 1) return p.cgmap ? rs_launch_out<1>(p, nwg, st) : rs_launch_out<0>(p, nwg, st);
+    if (which == 1) return p.cgmap ? rs_launch_out<1>(p, nwg, bn, st) : rs_launch_out<0>(p, nwg, bn, st);
     if (p.dil <= 8)
-        return p.cgmap ? rs_launch_conv<48, 1>(p, nwg, st, g_rs_ev0, g_rs_ev1) : rs_launch_conv<48, 0>(p, nwg, st, g_rs_ev0, g_rs_ev1);
-    return p.cgmap ? rs_launch_conv<80, 1>(p, nwg, st, g_rs_ev0, g_rs_ev1) : rs_launch_conv<80, 0>(p, nwg, st, g_rs_ev0, g_rs_ev1);
+        return p.cgmap ? rs_launch_conv<48, 1>(p, nwg, bn, st, g_rs_ev0, g_rs_ev1) : rs_launch_conv<48, 0>(p, nwg, bn, st, g_rs_ev0, g_rs_ev1);
+    return p.cgmap ? rs_launch_conv<80, 1>(p, nwg, bn, st, g_rs_ev0, g_rs_ev1) : rs_launch_conv<80, 0>(p, nwg, bn, st, g_rs_ev0, g_rs_ev1);
 }
 
 hipError_t wn_rowsplit_init_all() {
@@ -843,8 +885,8 @@ hipError_t wn_rowsplit_init_all() {
             p.cgmap = rag ? reinterpret_cast<const int*>(&p) : nullptr;      // (no launch: the grid is empty)
             p.ncg = 0;
             p.tiles_per_b = 0;
-            if ((e = launch_wn_rowsplit(p, 0, 256, 0, nullptr)) != hipSuccess) return e;
-            if ((e = launch_wn_rowsplit(p, 1, 256, 0, nullptr)) != hipSuccess) return e;
+            if ((e = launch_wn_rowsplit(p, 0, 256, 0, 32, nullptr)) != hipSuccess) return e;
+            if ((e = launch_wn_rowsplit(p, 1, 256, 0, 32, nullptr)) != hipSuccess) return e;
         }
     return hipSuccess;
 }

@@ -1,5 +1,6 @@
 """The two wave layouts of the row-split conv (wn_rowsplit.hip: K halves x four row waves, K quarters x two 32-row waves),
-each forced on (DSD_RS_CONV_Q, read per launch) on grids of either side of the 256-workgroup rule that picks between them:
+each forced on (DSD_RS_CONV_Q, read per launch) on grids of either side of the 256-workgroup rule that picks between them
+(and the 48-frame tiles of the K-quarter layout on the dense launches that select them):
 one evaluation against the numpy oracle, at the acoustic shape (dilation <= 8), the pitch shape (dilation 16: the 80-float
 row stride), a ragged batch and tiles cut by the utterance end; and the two layouts against each other - they add the same
 products in a different order, so they may differ by rounding only."""
@@ -54,6 +55,12 @@ CASES = {
     "acoustic_T2048": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 1, 2048, None),     # 512 workgroups
     "pitch_T900": (64, dict(num_layers=5, num_channels=256, dilation_cycle_length=5), 1, 900, None),           # dilation 16 in layer 4
     "ragged_B2": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 2, 640, [640, 333]),     # tile list, per-item ends
+    # 48-frame tiles (K-quarter layout only): dense launches that they turn into one round of workgroups
+    "acoustic_T1100_bn48": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 1, 1100, None),  # 23 tiles, last cut at 44
+    "acoustic_T1088_bn48": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 1, 1088, None),  # tiles reach 16 past 64 m
+    "acoustic_T1536_bn48": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 1, 1536, None),  # 32 full tiles
+    "pitch_T1300_bn48": (64, dict(num_layers=5, num_channels=256, dilation_cycle_length=5), 1, 1300, None),      # dilation 16
+    "acoustic_B2_T700_bn48": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 2, 700, None), # 2 x 15 tiles
 }
 
 
