@@ -37,6 +37,12 @@ __device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn
 __device__ __forceinline__ float tanh_fast(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * v)); }
 __device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
+// 1: the FiLM values of a thread's staging rows read from LDS in one batch, the late chunks written after step 9 and the barrier
+// taken after step 10 (as in wn_rowsplit.hip, finding (7) of DESIGN 4.2).  0: first version (A/B build).
+#ifndef DSD_WN_LATE
+#define DSD_WN_LATE 1
+#endif
+
 #ifdef DSD_STAMPS
 // [workgroup][0..7]: s_memtime at the phase boundaries; [8], [9]: s_memrealtime (100 MHz) at the first and last stamp
 __device__ unsigned long long g_wn_stamps[4096][10];
@@ -122,6 +128,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     // the other chunks travel one float4 per step behind its MFMAs and go to LDS after step 11.
     constexpr int NU0 = W4 / 4;                     // float4 per thread of a 64-channel chunk (idx = tid + 256 u)
     static_assert(64 * W4 == NU0 * 256 && NU - NU0 <= 12, "chunk 0 = the first NU0 staging slots; the rest fit 12 steps");
+    constexpr bool EARLY_LATE = DSD_WN_LATE && NU - NU0 <= 9;    // the late chunks' loads are all issued by step 8
     f32x4 sv[NU];
     auto x_voff = [&](int u) {
         const int idx = tid + 256 * u;
@@ -157,10 +164,19 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     es[tid] = fmine;                                             // (threads beyond C: a copy of the last channel's, unused)
     __syncthreads();
     // FiLM add, then the zero padding (wavenet.py:36-38: the pad is applied to x + d), then LDS
+#if DSD_WN_LATE
+    float fav[NU];                                               // one batch of LDS reads, not one round trip per float4 staged
+#pragma unroll
+    for (int u = 0; u < NU; ++u) fav[u] = es[(tid + 256 * u) / W4];
+#endif
     auto stage_write = [&](int u) {
         const int idx = tid + 256 * u;
         const int row = idx / W4, c4 = idx - row * W4;
+#if DSD_WN_LATE
+        const float fa = fav[u];
+#else
         const float fa = es[row];
+#endif
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -245,20 +261,35 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
             cpv[s - 12] = ld4(r_c, ev0, (((s - 12) % (NE / 2)) * 8 + (s - 12 >= NE / 2 ? C : 0)) * Ts * 4);
         else if (s >= 12 + NE && s < 12 + NE + MBW)
             bo[s - 12 - NE] = ld4(r_b, rq * 4, (s - 12 - NE) * 64);
-        if (s != 11) read_b1(bq[(s + 1) & 1], s + 1 < NS1 ? s + 1 : 0);      // (after the last step: unused)
+        if (EARLY_LATE || s != 11) read_b1(bq[(s + 1) & 1], s + 1 < NS1 ? s + 1 : 0);      // (after the last step: unused)
         mfma_step(W[s % 3], bq[s & 1]);
         WN_SPREAD()
     };
+    if constexpr (EARLY_LATE) {
+        // chunks 1.. of the x tile are read from step 12 on and their loads ride behind steps 0 .. 8: written after step 9, the
+        // workgroup meets after step 10, step 11 fetches step 12's operands in its normal slot
 #pragma unroll
-    for (int s = 0; s < 12; ++s) conv_step(s);
-    // chunks 1.. of the x tile are read from step 12 on
+        for (int s = 0; s < 10; ++s) conv_step(s);
 #pragma unroll
-    for (int u = NU0; u < NU; ++u) stage_write(u);
-    __syncthreads();
-    read_b1(bq[0], 12);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int u = NU0; u < NU; ++u) stage_write(u);
+        __builtin_amdgcn_sched_barrier(0);
+        conv_step(10);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 12; s < NS1; ++s) conv_step(s);
+        for (int s = 11; s < NS1; ++s) conv_step(s);
+    } else {
+        // (the 80-float tile's late loads ride behind steps 0 .. 11: written right before they are read)
+#pragma unroll
+        for (int s = 0; s < 12; ++s) conv_step(s);
+#pragma unroll
+        for (int u = NU0; u < NU; ++u) stage_write(u);
+        __syncthreads();
+        read_b1(bq[0], 12);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 12; s < NS1; ++s) conv_step(s);
+    }
     static_assert(12 + NE + MBW <= NS1, "one extra operand load per step");
     WN_STAMP(3);
 
