@@ -62,10 +62,10 @@ def test_edge_kernel_vs_three_gemms_ddpm_family(hp):
     noise = dev(synth.synth_normal((bsz, 1, 128, 150), 41))
     with _edge("0"):
         want = off(cond, infer=True, noise=noise)
-        assert off.denoise_fn.stats()["kernels_per_nfe"] == 2 * 4 + 3
+        assert off.denoise_fn.stats()["kernels_per_nfe"] in (2 * 4 + 3, 4 + 3)           # (4 + 3: DSD_FUSED_LAYER=1 forced runs)
     with _edge("1"):
         got = [on(cond, infer=True, noise=noise) for _ in range(3)]          # eager, then graph replays
-        assert on.denoise_fn.stats()["kernels_per_nfe"] == 2 * 4 + 1, on.denoise_fn.stats()
+        assert on.denoise_fn.stats()["kernels_per_nfe"] in (2 * 4 + 1, 4 + 1), on.denoise_fn.stats()
     check(got[0], want.cpu().numpy(), 2e-6, what=("edge kernel vs three GEMMs", hp["diff_accelerator"]))
     assert torch.equal(got[0], got[1]) and torch.equal(got[1], got[2])
     on.denoise_fn.release_native()
