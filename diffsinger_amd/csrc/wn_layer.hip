@@ -42,6 +42,11 @@ __device__ __forceinline__ int fdiv_floor(int x, float inv) { return (int)(((flo
 #ifndef DSD_WN_LATE
 #define DSD_WN_LATE 1
 #endif
+// 1: only step 0's weight blocks are part of the prologue's burst of loads (a CU issues one vector-memory wave-instruction per
+// ~50 cycles and the burst is the prologue's critical path); step 0 issues steps 1 and 2.  0: steps 0 and 1 in the prologue.
+#ifndef DSD_WN_RAMP
+#define DSD_WN_RAMP 1
+#endif
 
 #ifdef DSD_STAMPS
 // [workgroup][0..7]: s_memtime at the phase boundaries; [8], [9]: s_memrealtime (100 MHz) at the first and last stamp
@@ -158,7 +163,9 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
         for (int k = 0; k < MBW; ++k) dst[k] = ld4(r_w2, wk2[k] + (s & 3) * 1024, (s >> 2) * 4096);
     };
     load_w1(W[0], 0);
+#if !DSD_WN_RAMP
     load_w1(W[1], 1);
+#endif
     WN_STAMP(1);
     // FiLM vector -> LDS (the staging region is free until the gate), so each thread can pick the scalars of its rows
     es[tid] = fmine;                                             // (threads beyond C: a copy of the last channel's, unused)
@@ -236,6 +243,19 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           \
     }                                                                                \
     __builtin_amdgcn_sched_barrier(0);
+    // step 0 of a ramped ring issues TWO steps' weights (DSD_WN_RAMP): two loads behind every 8 MFMAs
+#define WN_SPREAD2()                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
+    _Pragma("unroll") for (int g_ = 1; g_ < MBW; ++g_) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           \
+    }                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
 
     // operands fetched during GEMM 1: the hoisted conditioner projection (+ conv bias + its own bias) of this wave's rows
     // as row-major float4 (local row rl = idx >> 3: [0, 8 MBW) gate rows, [8 MBW, 16 MBW) filter rows), and the
@@ -251,6 +271,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     __builtin_amdgcn_sched_barrier(0);
     auto conv_step = [&](int s) {
         // step s + 2: a conv step, or one of the out-proj's first two blocks behind the last conv steps
+        if (DSD_WN_RAMP && s == 0) load_w1(W[1], 1);           // (only step 0's weights are in the prologue burst)
         if (s + 2 < NS1) load_w1(W[(s + 2) % 3], s + 2);
         else load_w2(W[(s + 2) % 3], s + 2 - NS1);
         // the step's one extra operand load: the rest of the x tile first, then the conditioner projection (filter rows sit
@@ -263,7 +284,11 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
             bo[s - 12 - NE] = ld4(r_b, rq * 4, (s - 12 - NE) * 64);
         if (EARLY_LATE || s != 11) read_b1(bq[(s + 1) & 1], s + 1 < NS1 ? s + 1 : 0);      // (after the last step: unused)
         mfma_step(W[s % 3], bq[s & 1]);
-        WN_SPREAD()
+        if (DSD_WN_RAMP && s == 0) {
+            WN_SPREAD2()
+        } else {
+            WN_SPREAD()
+        }
     };
     if constexpr (EARLY_LATE) {
         // chunks 1.. of the x tile are read from step 12 on and their loads ride behind steps 0 .. 8: written after step 9, the
@@ -364,6 +389,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
         WN_SPREAD()
     }
 #undef WN_SPREAD
+#undef WN_SPREAD2
     WN_STAMP(5);
 
     // ---------------- epilogue: residual / skip (wavenet.py:45-48) ----------------
