@@ -139,6 +139,10 @@ __device__ __forceinline__ void rs_pin_args(const WnLayerP& p) {
 #endif
 // The conv's ring RAMPS: DEPTH - 1 blocks per wave in the prologue burst, then two blocks per step until DSD_RS_DEPTH_MAX - 1
 // are in flight (= DEPTH: no ramp).
+// Out-proj: 1 = one weight block less in the prologue's burst (DEPTH_OUT - 2), step 0 issues two (as the K-quarter conv does)
+#ifndef DSD_RS_OUT_RAMP
+#define DSD_RS_OUT_RAMP 1
+#endif
 #ifndef DSD_RS_DEPTH_MAX
 #define DSD_RS_DEPTH_MAX DSD_RS_DEPTH
 #endif
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     f32x4 W[DEPTH_OUT];
     const f32x4 bo = ld4(rsrc(p.bias_out + orow), rq * 4, 0);
 #pragma unroll
-    for (int s = 0; s < DEPTH_OUT - 1; ++s) W[s] = ld4(r_w, wl + (s & 3) * 1024, (s >> 2) * 4096);
+    for (int s = 0; s < DEPTH_OUT - 1 - DSD_RS_OUT_RAMP; ++s) W[s] = ld4(r_w, wl + (s & 3) * 1024, (s >> 2) * 4096);
     RS_PIN();
 #if DSD_RS_OUT_LATE
     z_load(1);
@@ -729,7 +733,9 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc[0] = rs_mfma(wv[j], bc[j][0], acc[0]);
-            if (j == 0 && s + DEPTH_OUT - 1 < NH)
+            if (DSD_RS_OUT_RAMP && s == 0 && j == 0)             // (the prologue's burst holds one block less: step 0 issues two)
+                W[DEPTH_OUT - 2] = ld4(r_w, wl + ((DEPTH_OUT - 2) & 3) * 1024, ((DEPTH_OUT - 2) >> 2) * 4096);
+            if (j == (DSD_RS_OUT_RAMP && s == 0 ? 1 : 0) && s + DEPTH_OUT - 1 < NH)
                 W[(s + DEPTH_OUT - 1) % DEPTH_OUT] = ld4(r_w, wl + ((s + DEPTH_OUT - 1) & 3) * 1024, ((s + DEPTH_OUT - 1) >> 2) * 4096);
             if (j == 0 && s + 1 < NH) {          // the next step's 4 LDS read pairs in one burst: spread one per MFMA pair
 #pragma unroll                                   // they cost the walk 12 % more (measured 5.0 k vs 4.45 k cycles)
