@@ -676,7 +676,11 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     const __amdgpu_buffer_rsrc_t r_w = rsrc(p.Aout + ((long)(4 * mtile + w) * NS + NH * kh) * 256);
     const int wl = lane * 16;
     f32x4 W[DEPTH_OUT];
-    const f32x4 bo = ld4(rsrc(p.bias_out + orow), rq * 4, 0);
+#ifndef DSD_RS_BIAS_KH0
+#define DSD_RS_BIAS_KH0 1
+#endif
+    f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};                        // the bias rides in the first K half: only its waves fetch it
+    if (!DSD_RS_BIAS_KH0 || kh == 0) bo = ld4(rsrc(p.bias_out + orow), rq * 4, 0);
 #pragma unroll
     for (int s = 0; s < DEPTH_OUT - 1 - DSD_RS_OUT_RAMP; ++s) W[s] = ld4(r_w, wl + (s & 3) * 1024, (s >> 2) * 4096);
     RS_PIN();
@@ -691,13 +695,18 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     const unsigned long long xa = (unsigned long long)p.xin, sa = (unsigned long long)p.skip, xo = (unsigned long long)p.xout;
     const __amdgpu_buffer_rsrc_t r_e = rsrc((const float*)(is_res ? xa : sa) + eoff);
     // (threads beyond the tile's 32 x B4 float4 per half: a copy of the last row's, unused)
-    const int erow = min(div_b4<B4>(tid), 31), ec4 = tid - div_b4<B4>(tid) * B4;
+    // 32-frame tiles: 64 rows x 8 float4 = one item per thread, all eight waves; 48-frame tiles: rows r and r + 32 per thread
+#ifndef DSD_RS_OUT_ITEMS1
+#define DSD_RS_OUT_ITEMS1 1
+#endif
+    constexpr int ITEMS = (DSD_RS_OUT_ITEMS1 && NCB == 2) ? 1 : 2, RP = 64 / ITEMS;
+    const int erow = min(div_b4<B4>(tid), RP - 1), ec4 = tid - div_b4<B4>(tid) * B4;
     const int ev0 = row_ts(erow, Ts) + ec4 * 16;
     f32x4 pre[2];
 #if DSD_RS_EARLY
     if (wave < 4) {
         pre[0] = ld4(r_e, ev0, 0);
-        pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
+        if (ITEMS == 2) pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
     }
     RS_PIN();
 #endif
@@ -717,7 +726,7 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
 #pragma unroll
     for (int n = 0; n < NCB; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[n][r] = kh == 0 ? bo[r] : 0.f;             // the bias rides in the first half
+        for (int r = 0; r < 4; ++r) acc[n][r] = DSD_RS_BIAS_KH0 ? bo[r] : (kh == 0 ? bo[r] : 0.f);
     const float* zt = zs + (kh * 128 + lrow) * SZ + lcol;
     float bq[2][4][NCB];
 #pragma unroll
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
             acc[1] = rs_mfma(wv[j], bc[j][1], acc[1]);
 #if !DSD_RS_EARLY
             if (j == 0 && s == 1) pre[0] = ld4(r_e, ev0, 0);
-            if (j == 0 && s == 2) pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
+            if (ITEMS == 2 && j == 0 && s == 2) pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
 #endif
             RS_PIN();
 #pragma unroll
@@ -780,12 +789,12 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
         }
     }
     __syncthreads();
-    if (tid < 32 * B4) {
+    if (tid < RP * B4) {
         const __amdgpu_buffer_rsrc_t r_o = rsrc((const float*)(is_res ? xo : sa) + eoff);
         const float scale = is_res ? 0.70710678118654752440f : 1.f;     // (x + o) / sqrt(2): times the fp32 reciprocal
         const bool add_pre = is_res || !p.first_layer;                  // the first layer's skip sum is its own output
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < ITEMS; ++k) {
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(&et[(erow + 32 * k) * ES + ec4 * 4]) +
                              *reinterpret_cast<const f32x4*>(&red[(erow + 32 * k) * ES + ec4 * 4]);
             f32x4 o;
