@@ -125,20 +125,13 @@ __device__ __forceinline__ void rs_pin_args(const WnLayerP& p) {
 #ifndef DSD_RS_FA_BATCH
 #define DSD_RS_FA_BATCH 1
 #endif
-// Out-proj (1 = A/B build): only the two 64-channel chunks that the first four steps of either K half read staged before the
-// walk, the other two written after step 1 behind a barrier after step 2.  Not kept: the walk is 8 steps and the extra
-// barrier costs what the earlier start gains (14.99 against 14.97 ms).
-#ifndef DSD_RS_OUT_LATE
-#define DSD_RS_OUT_LATE 0
-#endif
-// 1 (A/B build): the loads that the first version spreads over the walk's first steps (the late x chunks, the conditioner
-// projection, the out-proj's residual / skip operand) issued in the prologue, right behind the first weight blocks.  Not kept:
-// 15.44 against 14.98 ms per loop - ten more wave-level loads per wave in the burst before the walk.
-#ifndef DSD_RS_EARLY
-#define DSD_RS_EARLY 0
-#endif
-// The conv's ring RAMPS: DEPTH - 1 blocks per wave in the prologue burst, then two blocks per step until DSD_RS_DEPTH_MAX - 1
-// are in flight (= DEPTH: no ramp).
+// (Measured and removed.  Out-proj: only the two 64-channel chunks that the first four steps of either K half read staged before
+// the walk, the other two written after step 1 behind a barrier after step 2 - the walk is 8 steps and the extra barrier costs
+// what the earlier start gains, 14.99 against 14.97 ms.  Both kernels: the loads spread over the walk's first steps - late x
+// chunks, conditioner projection, residual / skip operand - issued in the prologue right behind the first weight blocks:
+// 15.44 against 14.98 ms per loop, ten more wave-level loads per wave in the burst before the walk.)
+// The K-half conv's ring can RAMP: DEPTH - 1 blocks per wave in the prologue burst, then two blocks per step until
+// DSD_RS_DEPTH_MAX - 1 are in flight (= DEPTH: no ramp; measured equal for 4 .. 8).
 // Out-proj: 1 = one weight block less in the prologue's burst (DEPTH_OUT - 2), step 0 issues two (as the K-quarter conv does)
 #ifndef DSD_RS_OUT_RAMP
 #define DSD_RS_OUT_RAMP 1
@@ -281,15 +274,6 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
     const int gch = 32 * mtile + ((tid & 255) >> 3);
     const __amdgpu_buffer_rsrc_t r_c = rsrc(p.cp + (long)bu * p.cp_bstride + t0u);
     f32x4 cpg = f32x4{0.f, 0.f, 0.f, 0.f}, cpf = cpg;
-#if DSD_RS_EARLY
-#pragma unroll
-    for (int u = 0; u < NE; ++u) svl[u] = ld4(r_x, row_ts(x_row(u, 1), Ts) + x_c4(u) * 16, 0);
-    if (wave < 4) {
-        cpg = ld4(r_c, row_ts(gch, Ts) + (tid & 7) * 16, 0);
-        cpf = ld4(r_c, row_ts(gch + C, Ts) + (tid & 7) * 16, 0);
-    }
-    RS_PIN();
-#endif
     RS_STAMP(0, 1);
 #if DSD_RS_FILM4
     if (wave < 4) et[tid] = fmine;
@@ -356,11 +340,9 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
             }
             RS_PIN();
             acc[1] = rs_mfma(wv[j], bc[j][1], acc[1]);
-#if !DSD_RS_EARLY
             if (!(DSD_RS_DIAG & 4) && j == 0 && s < NE) svl[s] = ld4(r_x, row_ts(x_row(s, 1), Ts) + x_c4(s) * 16, 0);
             if (!(DSD_RS_DIAG & 8) && j == 0 && s == 12) cpg = ld4(r_c, row_ts(gch, Ts) + (tid & 7) * 16, 0);
             if (!(DSD_RS_DIAG & 8) && j == 0 && s == 13) cpf = ld4(r_c, row_ts(gch + C, Ts) + (tid & 7) * 16, 0);
-#endif
             RS_PIN();
         }
         if (!(DSD_RS_DIAG & 4) && s == DSD_RS_LATE_W) {
@@ -664,13 +646,8 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
         const int idx = tid + 512 * u, row = div_b4<B4>(idx);
         *reinterpret_cast<f32x4*>(&zs[row * SZ + (idx - row * B4) * 4]) = sv[u];
     };
-#if DSD_RS_OUT_LATE
-    z_load(0);
-    z_load(2);
-#else
 #pragma unroll
     for (int u = 0; u < NZ; ++u) z_load(u);
-#endif
     RS_PIN();                                                    // (issue order = return order: what the walk needs first, first)
     const int orow = 64 * mtile + 16 * w;                        // this wave's 16 output rows (of 2C)
     const __amdgpu_buffer_rsrc_t r_w = rsrc(p.Aout + ((long)(4 * mtile + w) * NS + NH * kh) * 256);
@@ -684,10 +661,6 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
 #pragma unroll
     for (int s = 0; s < DEPTH_OUT - 1 - DSD_RS_OUT_RAMP; ++s) W[s] = ld4(r_w, wl + (s & 3) * 1024, (s >> 2) * 4096);
     RS_PIN();
-#if DSD_RS_OUT_LATE
-    z_load(1);
-    z_load(3);
-#endif
     // residual stream (row tiles of the first C rows) or running skip sum (the other half), row-major float4:
     // thread (of the first 256) -> rows (tid >> 3) and 32 + (tid >> 3) of the tile, frames 4 * (tid & 7)
     const bool is_res = mtile < NCH;                             // workgroup-uniform
@@ -703,21 +676,9 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     const int erow = min(div_b4<B4>(tid), RP - 1), ec4 = tid - div_b4<B4>(tid) * B4;
     const int ev0 = row_ts(erow, Ts) + ec4 * 16;
     f32x4 pre[2];
-#if DSD_RS_EARLY
-    if (wave < 4) {
-        pre[0] = ld4(r_e, ev0, 0);
-        if (ITEMS == 2) pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
-    }
-    RS_PIN();
-#endif
     RS_STAMP(1, 1);
-#if DSD_RS_OUT_LATE
-    z_write(0);
-    z_write(2);
-#else
 #pragma unroll
     for (int u = 0; u < NZ; ++u) z_write(u);
-#endif
     __syncthreads();
     RS_STAMP(1, 2);
 
@@ -754,10 +715,8 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
             }
             RS_PIN();
             acc[1] = rs_mfma(wv[j], bc[j][1], acc[1]);
-#if !DSD_RS_EARLY
             if (j == 0 && s == 1) pre[0] = ld4(r_e, ev0, 0);
             if (ITEMS == 2 && j == 0 && s == 2) pre[1] = ld4(r_e, ev0, 32 * Ts * 4);
-#endif
             RS_PIN();
 #pragma unroll
             for (int n = 2; n < NCB; ++n) {
@@ -765,17 +724,6 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
                 RS_PIN();
             }
         }
-#if DSD_RS_OUT_LATE
-        if (s == 1) {
-            z_write(1);
-            z_write(3);
-            RS_PIN();
-        }
-        if (s == 2) {
-            __syncthreads();
-            RS_PIN();
-        }
-#endif
     }
     RS_STAMP(1, 3);
 
