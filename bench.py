@@ -271,10 +271,29 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0          # this rank's K steps, from the common start to its own last kernel
     sync()
+    dist_info = None
     if use_dist:                                # the job's time = the slowest rank's
+        mine_ms = elapsed / max(args.steps, 1) * 1e3
         el = torch.tensor([elapsed], device=sharding._staging(device), dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
+        # what only a working N-rank collective can produce: every rank contributes a one (SUM), its own time and its device
+        ones = torch.ones(1, device=sharding._staging(device), dtype=torch.float64)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        per = torch.zeros(world, device=sharding._staging(device), dtype=torch.float64)
+        per[rank] = mine_ms
+        dist.all_reduce(per, op=dist.ReduceOp.SUM)
+        devs = torch.zeros(world, device=sharding._staging(device), dtype=torch.float64)
+        devs[rank] = float(torch.cuda.current_device())
+        dist.all_reduce(devs, op=dist.ReduceOp.SUM)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        dist_info = {"backend": dist.get_backend(), "ranks_seen": int(round(float(ones.item()))),
+                     "rccl_version": ver, "ms_per_step_by_rank": [round(float(v), 4) for v in per.tolist()],
+                     "device_by_rank": [int(v) for v in devs.tolist()], "exchange_scatters": exchange.scatters,
+                     "utterances_by_rank": [len(sh) for sh in shards]}
     if rank == 0:
         assert out is not None and torch.isfinite(out).all()
     sec_per_step = elapsed / max(args.steps, 1)
@@ -306,68 +325,99 @@ def main():
         "path_mfma_frac": round(stats["flops_per_frame_nfe"] * frames / sec_per_step / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),
         "path_hbm_frac": round(stats["bytes_per_frame_nfe"] * frames / sec_per_step / 1e9 / world / PEAK_HBM_GBPS, 5),
     }
+    if dist_info is not None:
+        result["distributed"] = dist_info
 
     if rank == 0 and not args.no_roofline:
-        # dominant kernel (WaveNet: dilated conv + FiLM + gate GEMM; LYNXNet: LN -> C->4C -> SwiGLU GEMM),
-        # bracketed by hipEvents on its own stream, one eager pass of the same workload
+        # The layer kernels of this workload (WaveNet: the fused layer kernel / the row-split or GEMM pair, per tile halo and per
+        # segment of a mixed plan; LYNXNet: the two pointwise GEMMs), each timed by hipEvents attached to the dispatch itself on
+        # the stream it is launched on, in one eager pass of the same workload (every 7th launch of a class carries events);
+        # the library reports per class the instantiation that ran and its algorithmic FLOPs / bytes per launch.
         import ctypes as C
         from diffsinger_amd import _lib
-        h = d.denoise_fn._handle
-        _lib.check(h, _lib.lib().dsd_kernel_timing(h, 1), "dsd_kernel_timing")
+        handles = [d.denoise_fn._handle] + ([variance.velocity_fn._handle] if variance is not None else [])
+        for h in handles:
+            _lib.check(h, _lib.lib().dsd_kernel_timing(h, 1), "dsd_kernel_timing")
         t_pass = time.perf_counter()
         run(cond_all[mine] if use_dist else cond_all)
         torch.cuda.synchronize(device)
         t_pass = (time.perf_counter() - t_pass) * 1e3
-        raw_ms, empty_ms, n = C.c_double(), C.c_double(), C.c_int64()
-        _lib.check(h, _lib.lib().dsd_kernel_timing_read(h, C.byref(raw_ms), C.byref(empty_ms), C.byref(n)),
-                   "dsd_kernel_timing_read")
-        # events are attached to the dispatch itself (hipExtLaunchKernelGGL): kernel begin -> end, no bracket cost
-        mean_ms = raw_ms
-        _lib.check(h, _lib.lib().dsd_kernel_timing(h, 0), "dsd_kernel_timing")
-        Cc = bargs["num_channels"]
-        fused = kind == "wavenet" and stats["kernels_per_nfe"] in (bargs["num_layers"] + 1, bargs["num_layers"] + 3)   # one launch per layer
-        vf = (sum(my_lens) if my_lens else B * T)             # frames one launch covers on this rank
-        if fused:
-            kflops = 2 * (3 * Cc * 2 * Cc + Cc * 2 * Cc) * vf     # conv 786,432 + out-proj 262,144 FLOP/frame
-            kbytes = 24 * Cc * vf                                  # x r/w, hoisted cond-proj read, skip sum r/w
-            kname = "wn_layer_kernel (dilated conv k=3 + FiLM + gate + 1x1 out-proj + residual / skip, one launch per layer)"
-        elif kind == "wavenet":
-            kflops = 2 * 3 * Cc * 2 * Cc * vf                 # 786,432 FLOP/frame
-            kbytes = (4 * Cc + 8 * Cc + 4 * Cc) * vf          # read x, read hoisted cond-proj, write gated z
-            kname = ("dilated conv k=3 + FiLM + sigmoid*tanh gate: wn_conv_rq_kernel / wn_conv_rs_kernel (row-split pair, "
-                     "32-frame tiles on one-utterance grids) or gemm_kernel<ST_FILM,3,EP_GATE> (other tile widths)")
-        else:
-            inner = Cc * bargs["expansion_factor"]
-            kflops = 2 * Cc * 2 * inner * vf
-            kbytes = (4 * Cc + 4 * inner) * vf
-            kname = ("LayerNorm -> 1x1 C->4C -> SwiGLU GEMM (lx_pw1_kernel, K resident in LDS, on batched grids; "
-                     "gemm_kernel<ST_LN,1,EP_SWIGLU> on small ones)")
-        traffic, traffic_src, prof_ns, prof_split = None, None, None, None
-        try:   # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of this same command
+        classes, empty_us = [], 0.0
+        for h in handles:
+            arr = (_lib.DsdKernelTime * 8)()
+            n, empty_ms = C.c_int32(), C.c_double()
+            _lib.check(h, _lib.lib().dsd_kernel_timing_classes(h, arr, 8, C.byref(n), C.byref(empty_ms)), "dsd_kernel_timing_classes")
+            empty_us = max(empty_us, empty_ms.value * 1e3)
+            for k in arr[:n.value]:
+                classes.append({"kernel": k.name.decode(), "launches_per_step": round(k.launches / max(k.evaluations, 1) * nfe),
+                                "launches_timed": int(k.launches_timed), "avg_launch_us": k.mean_ms * 1e3,
+                                "flops_per_launch": k.flops_per_launch, "bytes_per_launch": k.bytes_per_launch})
+            _lib.check(h, _lib.lib().dsd_kernel_timing(h, 0), "dsd_kernel_timing")
+        # committed rocprofv3 evidence of this same command (tools/collect_profiles.sh -> tools/summarize_profile.py):
+        # per-kernel average duration of the --kernel-trace --stats run and the fabric-side bytes of the --pmc passes
+        prof, prof_src = {}, None
+        try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             ent = tj.get(f"{args.workload}{'_ragged' if lengths else ''}/B{B}/T{T}")
             if ent:
-                traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
-                prof_ns, prof_split = ent.get("rocprof_avg_ns"), ent.get("rocprof_split_ns")
-                if ent.get("kernel"):        # the name rocprofv3 recorded for this very configuration
-                    kname += " | name in the committed rocprofv3 trace of this configuration: " + ent["kernel"]
+                prof_src = ent.get("source")
+                prof = ent["kernels"] if "kernels" in ent else {ent["kernel"]: ent}
         except Exception:
             pass
-        sec = mean_ms.value / 1e3
-        ach = kflops / sec / 1e12 if sec > 0 else 0.0
-        result["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                              "traffic_source": traffic_src,
-                              "kernel": kname, "launches_timed": int(n.value),
-                              "avg_launch_us": round(mean_ms.value * 1e3, 3), "timing_pass_ms": round(t_pass, 2),
-                              # committed rocprofv3 evidence for the same command: average over ALL launches, and
-                              # split into hipGraph-replay launches vs this eager, event-carrying pass
-                              "rocprof_avg_launch_us": None if prof_ns is None else round(prof_ns / 1e3, 3),
-                              "rocprof_split_ns": prof_split,
-                              "empty_event_pair_us": round(empty_ms.value * 1e3, 3),
-                              "algorithmic_flops_per_launch": kflops, "algorithmic_bytes_per_launch": kbytes,
-                              "hbm_achieved_GBps": round(kbytes / sec / 1e9, 1) if sec > 0 else 0.0,
-                              "hbm_frac": round(kbytes / sec / 1e9 / PEAK_HBM_GBPS, 5) if sec > 0 else 0.0}
+
+        def rocprof_of(name):
+            hits = [v for k, v in prof.items() if ("dsd::" + name + "(") in k]
+            return hits[0] if len(hits) == 1 else None
+
+        tot_fl = tot_by = tot_ev = tot_rp = tot_tr = 0.0
+        n_launch, all_rp, all_tr = 0, bool(classes), bool(classes)
+        for c in classes:
+            r = rocprof_of(c["kernel"])
+            w = c["launches_per_step"]
+            c["rocprof_avg_launch_us"] = round(r["rocprof_avg_ns"] / 1e3, 3) if r else None
+            c["traffic"] = r.get("traffic_bytes_per_launch") if r else None
+            c["mfma_busy_frac_profiled"] = r.get("mfma_busy_frac_profiled") if r else None
+            c["frac_events"] = round(c["flops_per_launch"] / (c["avg_launch_us"] * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+            c["frac"] = (round(c["flops_per_launch"] / (r["rocprof_avg_ns"] * 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if r else None)
+            c["avg_launch_us"] = round(c["avg_launch_us"], 3)
+            tot_fl += w * c["flops_per_launch"]
+            tot_by += w * c["bytes_per_launch"]
+            tot_ev += w * c["avg_launch_us"] * 1e-6
+            n_launch += w
+            if r:
+                tot_rp += w * r["rocprof_avg_ns"] * 1e-9
+            else:
+                all_rp = False
+            if r and r.get("traffic_bytes_per_launch") is not None:
+                tot_tr += w * r["traffic_bytes_per_launch"]
+            else:
+                all_tr = False
+        # `frac` is the figure a reader can recompute from profiles/ (rocprofv3 averages of the committed trace of this
+        # command) when that trace exists for every kernel of the set; the dispatch-event figure of THIS run rides along as
+        # frac_events (events on the dispatch add ~1-2 us of command-processor time to a 5-70 us kernel).
+        sec = tot_rp if all_rp else tot_ev
+        ach = tot_fl / sec / 1e12 if sec > 0 else 0.0
+        ach_ev = tot_fl / tot_ev / 1e12 if tot_ev > 0 else 0.0
+        result["roofline"] = {
+            "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "frac_source": ("rocprofv3 --kernel-trace --stats averages of the committed profile: " + str(prof_src)) if all_rp
+                           else "hip events on the dispatches of this run (no committed rocprofv3 trace of this configuration)",
+            "frac_events": round(ach_ev / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": int(round(tot_tr / max(n_launch, 1))) if all_tr else None,
+            "traffic_source": prof_src if all_tr else None,
+            "scope": "time-weighted over the layer kernels of one step (all launches of `kernels`); per-launch means",
+            "kernel": classes[0]["kernel"] if classes else None,
+            "share_of_step": round(tot_ev / sec_per_step, 4),
+            "launches_per_step": int(n_launch),
+            "avg_launch_us": round(sec / max(n_launch, 1) * 1e6, 3),
+            "avg_launch_us_events": round(tot_ev / max(n_launch, 1) * 1e6, 3),
+            "algorithmic_flops_per_launch": tot_fl / max(n_launch, 1), "algorithmic_bytes_per_launch": tot_by / max(n_launch, 1),
+            "hbm_achieved_GBps": round(tot_by / sec / 1e9, 1) if sec > 0 else 0.0,
+            "hbm_frac": round(tot_by / sec / 1e9 / PEAK_HBM_GBPS, 5) if sec > 0 else 0.0,
+            "timing_pass_ms": round(t_pass, 2), "empty_event_pair_us": round(empty_us, 3),
+            "plan": {k: stats[k] for k in ("kernels_per_nfe", "layer_launches", "fused_tiles", "split_tiles")},
+            "kernels": classes}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(kind, params, bargs, B, T, bins=64 if variance is not None else 128)
     if rank == 0:

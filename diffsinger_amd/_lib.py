@@ -25,7 +25,7 @@ ACT_IDS = {"PReLU": 0, "SiLU": 1, "ReLU": 2}
 EXPORTS = [
     "dsd_api_version", "dsd_create", "dsd_destroy", "dsd_last_error", "dsd_load_weight",
     "dsd_finalize_weights", "dsd_prepare_cond", "dsd_denoise", "dsd_sample", "dsd_get_stats",
-    "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode", "dsd_vocoder_create", "dsd_vocode",
+    "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_kernel_timing_classes", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode", "dsd_vocoder_create", "dsd_vocode",
     "dsd_token_encoder_create", "dsd_token_encode", "dsd_predict_dur", "dsd_cond_assemble", "dsd_set_lengths",
 ]
 POS_ROPE, POS_REL, POS_NONE, POS_SIN = 0, 1, 2, 3       # DSD_POS_*
@@ -103,7 +103,15 @@ class DsdProgram(C.Structure):
 class DsdStats(C.Structure):
     _fields_ = [("weight_bytes", C.c_int64), ("workspace_bytes", C.c_int64),
                 ("flops_per_frame_nfe", C.c_int64), ("bytes_per_frame_nfe", C.c_int64),
-                ("kernels_per_nfe", C.c_int32), ("graphs_cached", C.c_int32)]
+                ("kernels_per_nfe", C.c_int32), ("graphs_cached", C.c_int32),
+                ("layer_launches", C.c_int32), ("fused_tiles", C.c_int32), ("split_tiles", C.c_int32),
+                ("reserved_", C.c_int32)]
+
+
+class DsdKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("mean_ms", C.c_double), ("launches_timed", C.c_int64),
+                ("launches", C.c_int64), ("evaluations", C.c_int64), ("flops_per_launch", C.c_double),
+                ("bytes_per_launch", C.c_double)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -147,9 +155,10 @@ def _load():
     lib.dsd_get_stats.argtypes = [vp, C.POINTER(DsdStats)]
     lib.dsd_kernel_timing.argtypes = [vp, i32]
     lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
+    lib.dsd_kernel_timing_classes.argtypes = [vp, C.POINTER(DsdKernelTime), i32, C.POINTER(i32), C.POINTER(C.c_double)]
     for name in EXPORTS:
         getattr(lib, name)
-    if lib.dsd_api_version() != 9:
+    if lib.dsd_api_version() != 10:
         raise NativeLibraryError("libdsdenoise.so API version mismatch")
     return lib
 

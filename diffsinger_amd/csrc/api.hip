@@ -31,6 +31,45 @@
 
 using namespace dsd;
 
+// ------------------------------------------------------------------------------------------
+// path switches: read from the environment once per C-ABI entry point (dsd_internal.h, PathOpts)
+// ------------------------------------------------------------------------------------------
+namespace dsd {
+static PathOpts g_path_opts = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 512};
+const PathOpts& path_opts() { return g_path_opts; }
+void refresh_path_opts() {
+    auto geti = [](const char* name, int dflt) {
+        const char* v = getenv(name);
+        return v && *v ? atoi(v) : dflt;
+    };
+    PathOpts& o = g_path_opts;
+    o.fused_layer = geti("DSD_FUSED_LAYER", -1);
+    o.wn_plan = geti("DSD_WN_PLAN", -1);
+    o.rowsplit = geti("DSD_ROWSPLIT", -1);
+    o.rs_bn48 = geti("DSD_RS_BN48", -1);
+    o.rs_conv_q = geti("DSD_RS_CONV_Q", -1);
+    o.rs_rows = geti("DSD_RS_ROWS", -1);
+    o.edge = geti("DSD_EDGE", -1);
+    o.lynx_resident = geti("DSD_LYNX_RESIDENT", -1);
+    o.lynx_pw1p = geti("DSD_LYNX_PW1P", -1);
+    o.lynx_pw2d = geti("DSD_LYNX_PW2D", -1);
+    o.narrow = geti("DSD_NARROW", -1);
+    o.gm_shift = geti("DSD_GM_SHIFT", -1);
+    o.film_t = geti("DSD_FILM_T", -1);
+    o.dwconv_rows = geti("DSD_DWCONV_ROWS", -1);
+    o.precision = geti("DSD_PRECISION", -1);
+    const char* nb = getenv("DSD_NB2_MIN_WG");
+    o.nb2_min = nb && *nb ? atol(nb) : 512;
+}
+}  // namespace dsd
+
+namespace dsd {
+TimingSlot& timing_slot() {
+    static thread_local TimingSlot slot;
+    return slot;
+}
+}  // namespace dsd
+
 namespace {
 
 std::string g_create_error = "";
@@ -154,13 +193,22 @@ struct dsd_handle {
     std::map<std::string, GraphEntry> graphs;
     std::set<std::string> graph_seen;      // programs run once eagerly: a graph is captured when one comes back
 
-    // timing of the dominant kernel
+    // timing of the layer kernels (dsd_kernel_timing): per kernel CLASS - a launch site of run_backbone and the variant of
+    // it that ran (tile width, halo, segment of a mixed plan) - every timing_stride-th launch carries an event pair
+    struct TimedClass {
+        int key = 0;
+        std::string name;           // the instantiation, as rocprofv3 prints it (filled in by the launcher that took the slot)
+        double flops = 0, bytes = 0;    // algorithmic work of one launch (valid frames)
+        long launches = 0;          // all launches of the class since timing was switched on
+        std::vector<size_t> evs;    // indices into ev_pool
+    };
     bool timing = false;
+    std::vector<TimedClass> tclasses;
+    long timing_evals = 0;         // backbone evaluations since timing was switched on
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> cal_pool;   // back-to-back pairs: the cost of the bracket itself
     size_t cal_used = 0;
-    long timing_seq = 0;
     int timing_stride = 7;         // coprime with the layer count: every layer is sampled over a pass
 };
 
@@ -1152,7 +1200,7 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     // tile width: 64 frames when that still fills the chip twice over, else 32
     const int mtiles = g.pairC > 0 ? (g.pairC + 31) / 32 : (g.M + 63) / 64;
     const long wg64 = (long)batch * ((T + 63) / 64) * mtiles;
-    static const long nb2_min = getenv("DSD_NB2_MIN_WG") ? atol(getenv("DSD_NB2_MIN_WG")) : 512;     // diagnostic override
+    const long nb2_min = path_opts().nb2_min;          // (DSD_NB2_MIN_WG: diagnostic override)
     c.nb = wg64 >= nb2_min ? 2 : 1;
     // a conv on the generic path keeps all input channels resident: 64-frame tiles only while that fits in LDS
     if ((g.taps > 3 || (generic_only && g.taps > 1)) &&
@@ -1160,7 +1208,7 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     // narrow tiles (64 rows x 16 frames, c.nb == 0): when 32-frame tiles would put at most ~1.5 workgroups on a CU,
     // twice as many half-size workgroups share each SIMD between two waves and halve the latency of a lone one
     if (c.nb == 1) {
-        static const int force = getenv("DSD_NARROW") ? atoi(getenv("DSD_NARROW")) : -1;      // diagnostic override
+        const int force = path_opts().narrow;          // (DSD_NARROW: diagnostic override)
         const long wg32 = (long)batch * ((T + 31) / 32) * mtiles;
         int s16 = 16 + 2 * p.HL;
         while (s16 % 32 != 16) s16 += 4;
@@ -1194,7 +1242,7 @@ GemmCall make_gemm(dsd_handle* h, const PackedGemm& g, const float* Bsrc, long b
     p.lpr_shift = 3;
     while ((1 << p.lpr_shift) < w4) ++p.lpr_shift;
     {   // L2 blocking of the work order for GEMMs with many row tiles (GemmP::gm_shift): groups of 8 row tiles
-        static const int gm_env = getenv("DSD_GM_SHIFT") ? atoi(getenv("DSD_GM_SHIFT")) : -1;       // diagnostic override
+        const int gm_env = path_opts().gm_shift;       // (DSD_GM_SHIFT: diagnostic override)
         const int shift = gm_env >= 0 ? gm_env : 3;
         const long nft = ragged ? (long)p.ncg : (long)batch * p.tiles_per_b;
         if (shift > 0 && mtiles >= (2 << shift) && mtiles % (1 << shift) == 0 && nft * mtiles >= 2048 && (nft << shift) < (1L << 22)) {
@@ -1228,42 +1276,84 @@ int run_gemm(dsd_handle* h, const GemmCall& c, hipStream_t st) {
     return DSD_OK;
 }
 
-// WaveNet: one fused launch per residual layer (wn_layer.hip) when the grid gives (nearly) every CU a full-row tile of 32
-// frames; else the two-GEMM path of gemm.hip, whose 8x finer row tiles fill the chip from a single utterance.  A fused
-// launch is ceil(tiles / 256) rounds of one tile per CU, ~67 us each at C = 256 (63 us of it the tile's own 152 k cycles);
-// the two launches cost a fixed part plus a slope per tile (measured: 13 us + 0.275 us per tile from B = 5 up).  Batch
-// sweep at T = 1000 (profiles/r02_sweep_fused.txt): fused wins at B = 7-8, 14-16, 22-24, the split path in between.
-// DSD_FUSED_LAYER=0/1 forces the choice.
-bool wn_use_fused(const dsd_handle* h) {
+// WaveNet: how one residual layer runs on this (B, T) / these lengths.  Three launch shapes exist:
+//   * wn_layer.hip, ONE launch per layer, a workgroup per 32-frame tile with all 2C rows: a launch is ceil(tiles / 256) rounds
+//     of one tile per CU and a round takes the same time whether 1 or 256 of its tiles exist (at C = 256 ~67 us, 63 us of it
+//     the tile's own 152 k cycles) - the most efficient form at whole rounds (0.81 of the fp32-MFMA peak), the worst just
+//     above one (B = 9 x 1000 frames = 288 tiles: two rounds for 1.125 rounds of work);
+//   * wn_rowsplit.hip, TWO launches per layer with the rows split over 8 workgroups per tile: fills the chip from 32 tiles,
+//     balanced at any tile count, but two boundaries / cold prologues per layer and every x tile staged eight times
+//     (one utterance: ~14 us; slope ~0.30 us per tile);
+//   * the two GEMMs of gemm.hip (any shape; 64-frame tiles from 512 workgroups up: 13 us + 0.275 us per tile).
+// A PLAN is a list of segments, each a launch shape over a contiguous range of the batch's (item, frame tile) order; every
+// segment reads the layer's input buffer and writes the other one (x ping-pongs between xh and z, so tiles are independent
+// within a layer and a neighbour's halo is always the layer's INPUT), the row-split segments put their gated tile into hbuf.
+// Mixed plans: the whole rounds on the fused kernel, the remainder on the row-split pair (B = 9: 67 + 14 us instead of
+// 2 x 67 fused or ~92 split).  Costs below are in units of one fused round; they are RATIOS measured on one box
+// (profiles/r03_plan_sweep.txt), not absolute times.  DSD_FUSED_LAYER=0/1 forces no / only fused segments, DSD_WN_PLAN=0
+// keeps one launch shape per layer (round 2's rule).  An empty plan = the per-layer choice between the row-split pair
+// and the GEMM pair in run_backbone.
+enum { WN_FUSED = 0, WN_ROWSPLIT = 1 };
+struct WnSeg {
+    int kind, bn;       // launch shape, frames per tile
+    int t0, nt;         // tiles [t0, t0 + nt) of the (item, frame tile) order at this width (ragged: of the valid-tile list)
+};
+
+inline long wn_tiles32(const dsd_handle* h) {
+    if (h->lens_host.empty()) return (long)h->B * ((h->T + 31) / 32);
+    long tiles = 0;
+    for (int v : h->lens_host) tiles += (v + 31) / 32;
+    return tiles;
+}
+
+bool wn_plan_for(const dsd_handle* h, std::vector<WnSeg>& segs) {
+    segs.clear();
     if (!is_wavenet(h)) return false;
     const int C = C_of(h);
     const int max_dil = 1 << (std::min(h->cfg.dilation_cycle_length, L_of(h)) - 1);
-    if (!wn_layer_supported(C, max_dil) || h->cfg.dilation_cycle_length < 1) return false;
-    static const int force = getenv("DSD_FUSED_LAYER") ? atoi(getenv("DSD_FUSED_LAYER")) : -1;
-    if (force == 0) return false;
-    if (force == 1) return true;
-    const bool ragged = !h->lens_host.empty();
-    long tiles = 0;
-    if (ragged) for (int v : h->lens_host) tiles += (v + 31) / 32;
-    else tiles = (long)h->B * ((h->T + 31) / 32);
-    static const double t_tile = getenv("DSD_FUSED_TILE_US") ? atof(getenv("DSD_FUSED_TILE_US")) : 67.0;
-    const double scale = (double)C / 256.0 * C / 256.0;                 // FLOPs per frame ~ C^2
-    const double fused = (double)((tiles + 255) / 256) * t_tile * scale;
-    const double split = 13.0 + 0.275 * (double)tiles * scale;
-    return tiles >= 128 && fused < split;
+    if (h->cfg.dilation_cycle_length < 1 || !wn_layer_supported(C, max_dil)) return false;
+    const PathOpts& o = path_opts();
+    if (o.fused_layer == 0) return false;
+    const long tiles = wn_tiles32(h);
+    if (tiles == 0 || tiles >= (1L << 22)) return false;
+    if (o.fused_layer == 1) {                      // forced: every tile through the fused kernel, whatever the grid
+        segs.push_back({WN_FUSED, 32, 0, (int)tiles});
+        return true;
+    }
+    if (o.wn_plan == 2 && o.rowsplit != 0 && wn_rowsplit_supported(C, max_dil, h->Ts)) {
+        // test hook: a mixed plan at any size - the first half of the tiles fused, the rest on the row-split pair
+        const int nfh = (int)(tiles / 2);
+        if (nfh > 0) segs.push_back({WN_FUSED, 32, 0, nfh});
+        segs.push_back({WN_ROWSPLIT, 32, nfh, (int)tiles - nfh});
+        return true;
+    }
+    const long rounds = (tiles + 255) / 256, nf = tiles / 256 * 256, rem = tiles - nf;
+    const double fused_all = (double)rounds;
+    const double split_all = 0.194 + (double)tiles / 244.0;          // the GEMM pair / row-split pair over everything
+    const bool rs_ok = o.rowsplit != 0 && o.wn_plan != 0 && wn_rowsplit_supported(C, max_dil, h->Ts);
+    double mixed = 1e30;
+    if (rs_ok && nf > 0 && rem > 0) mixed = (double)(nf / 256) + 0.067 + (double)rem / 223.0;
+    if (tiles < 128) return false;
+    if (mixed < fused_all && mixed < split_all) {
+        segs.push_back({WN_FUSED, 32, 0, (int)nf});
+        segs.push_back({WN_ROWSPLIT, 32, (int)nf, (int)rem});
+        return true;
+    }
+    if (fused_all < split_all) {
+        segs.push_back({WN_FUSED, 32, 0, (int)tiles});
+        return true;
+    }
+    return false;
 }
 
 // DSD_EDGE: 0 = never the edge kernel (wn_edge.hip), 1 = on every grid, unset = by grid size.  Read per call: tests/
 // test_gpu_edge.py switches it between two handles of one process.
-inline int edge_choice() {
-    const char* ev = getenv("DSD_EDGE");
-    return ev ? atoi(ev) : -1;
-}
+inline int edge_choice() { return path_opts().edge; }
 
 // Layer `layer`'s FiLM vector d[c] for step column col0 (+ colb per batch item): kernels read film[c * cstride + c0 + b * cb].
 // From the transposed table Dt [step][L * C] that is C contiguous floats (DSD_FILM_T=0: from D [L * C][Ns], one line per row - A/B)
 inline void film_of(const dsd_handle* h, int layer, int col0, int colb, const float*& film, int& cstride, int& c0, int& cb) {
-    static const int transposed = getenv("DSD_FILM_T") ? atoi(getenv("DSD_FILM_T")) : 1;
+    const int transposed = path_opts().film_t != 0;
     const int C = C_of(h), LC = L_of(h) * C;
     if (transposed) {
         film = h->Dt + (long)layer * C; cstride = 1; c0 = col0 * LC; cb = colb * LC;
@@ -1305,25 +1395,45 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
     const long xs = (long)C * Ts;
     int rc;
     RaggedScope ragged_scope(h);
-    // only every timing_stride-th launch of the dominant kernel carries events (a dispatch with profiling events
-    // costs the command processor more than a plain one; sampling keeps the pass close to the untimed pace)
-    bool timed_now = false;
-    auto timed_begin = [&]() {
-        timed_now = h->timing && (h->timing_seq++ % h->timing_stride == 0);
-        if (!timed_now) return;
+    // timing pass: per kernel class (launch site + variant) every timing_stride-th launch carries events (a dispatch with
+    // profiling events costs the command processor more than a plain one; sampling keeps the pass close to the untimed pace)
+    dsd_handle::TimedClass* tcls = nullptr;
+    auto timed_begin = [&](int key, double flops, double bytes) {
+        tcls = nullptr;
+        if (!h->timing) return;
+        for (auto& c : h->tclasses)
+            if (c.key == key) tcls = &c;
+        if (!tcls) {
+            h->tclasses.emplace_back();
+            tcls = &h->tclasses.back();
+            tcls->key = key;
+        }
+        tcls->flops = flops;
+        tcls->bytes = bytes;
+        if (tcls->launches++ % h->timing_stride != 0) { tcls = nullptr; return; }
         if (h->ev_used == h->ev_pool.size()) {
             hipEvent_t a, b;
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
             h->ev_pool.emplace_back(a, b);
         }
-        gemm_set_timing_events(h->ev_pool[h->ev_used].first, h->ev_pool[h->ev_used].second);
+        TimingSlot& ts = timing_slot();
+        ts.e0 = h->ev_pool[h->ev_used].first;
+        ts.e1 = h->ev_pool[h->ev_used].second;
+        ts.taken = false;
     };
     auto timed_end = [&]() {
-        if (!timed_now) return;
-        gemm_set_timing_events(nullptr, nullptr);
-        ++h->ev_used;
+        if (!tcls) return;
+        TimingSlot& ts = timing_slot();
+        if (ts.taken) {
+            if (tcls->name.empty()) tcls->name = ts.name;
+            tcls->evs.push_back(h->ev_used++);
+        }
+        ts.e0 = ts.e1 = nullptr;
+        ts.taken = false;
+        tcls = nullptr;
     };
+    if (h->timing) ++h->timing_evals;
     if (h->timing) {      // one empty bracket per evaluation calibrates what a hipEvent pair itself costs
         if (h->cal_used == h->cal_pool.size()) {
             hipEvent_t a, b;
@@ -1362,32 +1472,73 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
     }
     if (is_wavenet(h)) {
         const long cps = (long)L * 2 * C * Ts;
-        if (wn_use_fused(h)) {
-            // one launch per residual layer; the residual stream ping-pongs between xh and z (a tile's halo columns must
-            // come from the layer's INPUT, which a neighbouring tile may already have replaced in place)
-            const bool ragged = h->use_cg && !h->lens_host.empty();
+        const bool ragged = h->use_cg && !h->lens_host.empty();
+        // algorithmic work of the layer kernels per VALID frame: conv 3*C*2C MACs, out-proj C*2C;
+        // bytes: the conv launch reads x and the hoisted conditioner projection and writes z (16 C), the out-proj launch
+        // reads z, updates x and the skip sum (20 C); fused: x r/w, conditioner projection, skip r/w (24 C)
+        const double fl_conv = 2.0 * 3 * C * 2 * C, fl_out = 2.0 * C * 2 * C;
+        auto seg_frames = [&](int bn, int t0, int nt) -> double {       // valid frames in tiles [t0, t0 + nt) at width bn
+            const int tpb = (T + bn - 1) / bn;
+            double fr = 0;
+            if (!ragged) {
+                for (int i = t0; i < t0 + nt; ++i) fr += std::min(bn, T - (i % tpb) * bn);
+            } else {
+                const int k = bn == 16 ? 0 : bn / 32;
+                for (int i = t0; i < t0 + nt; ++i) {
+                    const int e = h->cg_host[k][i], b = e / tpb, ft = e - b * tpb;
+                    fr += std::min(bn, h->lens_host[b] - ft * bn);
+                }
+            }
+            return fr;
+        };
+        auto layer_params = [&](WnLayerP& p, int l, int bn) {
+            memset(&p, 0, sizeof(p));
+            p.Aconv = h->blob + h->g_conv[l].a_off;
+            p.Aout = h->blob + h->g_outp[l].a_off;
+            p.bias_out = h->blob + h->g_outp[l].bias_off;
+            p.skip = h->skip;
+            p.x_bstride = xs; p.Ts = Ts;
+            p.cp = h->cp + (long)l * 2 * C * Ts; p.cp_bstride = cps;
+            film_of(h, l, film_col0, film_colb, p.film, p.film_cstride, p.film_col0, p.film_colb);
+            p.dil = 1 << (l % h->cfg.dilation_cycle_length);
+            p.T = T; p.tiles_per_b = (T + bn - 1) / bn; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
+            p.first_layer = (l == 0);
+        };
+        std::vector<WnSeg> plan;
+        if (wn_plan_for(h, plan)) {
+            // the residual stream ping-pongs between xh and z (a tile's halo columns must come from the layer's INPUT, which
+            // a neighbouring tile - of this or another segment - may already have replaced); row-split segments gate into hbuf
             const float* xi = h->xh;
             float* xo = h->z;
+            std::vector<double> seg_fr(plan.size());
+            for (size_t k = 0; k < plan.size(); ++k) seg_fr[k] = seg_frames(plan[k].bn, plan[k].t0, plan[k].nt);
             for (int l = 0; l < L; ++l) {
-                WnLayerP p;
-                memset(&p, 0, sizeof(p));
-                p.Aconv = h->blob + h->g_conv[l].a_off;
-                p.Aout = h->blob + h->g_outp[l].a_off;
-                p.bias_out = h->blob + h->g_outp[l].bias_off;
-                p.xin = xi; p.xout = xo; p.skip = h->skip;
-                p.x_bstride = xs; p.Ts = Ts;
-                p.cp = h->cp + (long)l * 2 * C * Ts; p.cp_bstride = cps;
-                film_of(h, l, film_col0, film_colb, p.film, p.film_cstride, p.film_col0, p.film_colb);
-                p.dil = 1 << (l % h->cfg.dilation_cycle_length);
-                p.T = T; p.tiles_per_b = (T + 31) / 32; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
-                p.first_layer = (l == 0);
-                if (ragged) { p.lens = h->lens_dev; p.cgmap = h->cg_dev[1]; p.ncg = h->cg_n[1]; }
-                timed_begin();
-                if (timed_now) wn_layer_set_timing_events(h->ev_pool[h->ev_used].first, h->ev_pool[h->ev_used].second);
-                hipError_t le = launch_wn_layer(p, C, B, st);
-                if (timed_now) wn_layer_set_timing_events(nullptr, nullptr);
-                timed_end();
-                if (le != hipSuccess) return fail(h, DSD_EHIP, "fused WaveNet layer launch failed: %s", hipGetErrorString(le));
+                for (size_t k = 0; k < plan.size(); ++k) {
+                    const WnSeg& sg = plan[k];
+                    WnLayerP p;
+                    layer_params(p, l, sg.bn);
+                    p.xin = xi; p.xout = xo; p.z = h->hbuf;
+                    p.tile0 = sg.t0; p.ntiles = sg.nt;
+                    if (ragged) { p.lens = h->lens_dev; p.cgmap = h->cg_dev[1] + sg.t0; p.ncg = sg.nt; }
+                    const int vkey = (int)k * 4 + (p.dil > 8 ? 2 : 0);
+                    hipError_t le;
+                    if (sg.kind == WN_FUSED) {
+                        timed_begin(100 + vkey, (fl_conv + fl_out) * seg_fr[k], 24.0 * C * seg_fr[k]);
+                        le = launch_wn_layer(p, C, B, st);
+                        timed_end();
+                        if (le != hipSuccess) return fail(h, DSD_EHIP, "fused WaveNet layer launch failed: %s", hipGetErrorString(le));
+                    } else {
+                        timed_begin(200 + vkey, fl_conv * seg_fr[k], 16.0 * C * seg_fr[k]);
+                        le = launch_wn_rowsplit(p, 0, C, B, sg.bn, st);
+                        timed_end();
+                        if (le == hipSuccess) {
+                            timed_begin(300 + vkey, fl_out * seg_fr[k], 20.0 * C * seg_fr[k]);
+                            le = launch_wn_rowsplit(p, 1, C, B, sg.bn, st);
+                            timed_end();
+                        }
+                        if (le != hipSuccess) return fail(h, DSD_EHIP, "row-split WaveNet layer launch failed: %s", hipGetErrorString(le));
+                    }
+                }
                 xi = xo;
                 xo = (xo == h->z) ? h->xh : h->z;
             }
@@ -1396,49 +1547,44 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             const int dil = 1 << (l % h->cfg.dilation_cycle_length);
             // 32-frame tiles on a grid of about one workgroup per CU (one utterance of ~1000 frames): the row-split pair
             // of wn_rowsplit.hip - every weight block loaded once, compiler-counted waits - instead of the two GEMMs
-            static const int rs_env = getenv("DSD_ROWSPLIT") ? atoi(getenv("DSD_ROWSPLIT")) : -1;
-            const bool rs_ok = rs_env != 0 && wn_rowsplit_supported(C, dil, Ts);
+            const bool rs_ok = path_opts().rowsplit != 0 && wn_rowsplit_supported(C, dil, Ts);
             GemmCall g = make_gemm(h, h->g_conv[l], h->xh, xs, Ts, B, T, ST_FILM, EP_GATE, dil, false, rs_ok);
-            const bool ragged = h->use_cg && !h->lens_host.empty();
             // 48-frame tiles where they make a dense launch ONE round of workgroups and 32-frame tiles do not (T in (1024, 1536]
             // at B = 1: 35-48 tiles of 32 frames = 280-384 workgroups for 256 CUs): 21.9 -> see DESIGN 4.2.  DSD_RS_BN48=0: off
-            static const int bn48_env = getenv("DSD_RS_BN48") ? atoi(getenv("DSD_RS_BN48")) : -1;
-            const bool bn48 = rs_ok && bn48_env != 0 && !ragged && (long)B * ((T + 31) / 32) * 8 > 256 && (long)B * ((T + 47) / 48) * 8 <= 256;
+            const bool bn48 = rs_ok && path_opts().rs_bn48 != 0 && !ragged && (long)B * ((T + 31) / 32) * 8 > 256 &&
+                              (long)B * ((T + 47) / 48) * 8 <= 256;
+            const double fr_all = ragged ? seg_frames(32, 0, h->cg_n[1]) : (double)B * T;
             if (rs_ok && ((g.nb == 1 && g.fast) || bn48)) {
                 const int bn = bn48 ? 48 : 32;
                 WnLayerP p;
-                memset(&p, 0, sizeof(p));
-                p.Aconv = h->blob + h->g_conv[l].a_off;
-                p.Aout = h->blob + h->g_outp[l].a_off;
-                p.bias_out = h->blob + h->g_outp[l].bias_off;
-                p.xin = h->xh; p.xout = h->xh; p.skip = h->skip; p.z = h->z;
-                p.x_bstride = xs; p.Ts = Ts;
-                p.cp = h->cp + (long)l * 2 * C * Ts; p.cp_bstride = cps;
-                film_of(h, l, film_col0, film_colb, p.film, p.film_cstride, p.film_col0, p.film_colb);
-                p.dil = dil;
-                p.T = T; p.tiles_per_b = (T + bn - 1) / bn; p.inv_tiles_per_b = 1.0f / (float)p.tiles_per_b;
-                p.first_layer = (l == 0);
+                layer_params(p, l, bn);
+                p.xin = h->xh; p.xout = h->xh; p.z = h->z;
                 if (ragged) { p.lens = h->lens_dev; p.cgmap = h->cg_dev[1]; p.ncg = h->cg_n[1]; }
-                timed_begin();
-                if (timed_now) wn_rowsplit_set_timing_events(h->ev_pool[h->ev_used].first, h->ev_pool[h->ev_used].second);
+                timed_begin(200 + (bn48 ? 1 : 0) + (dil > 8 ? 2 : 0), fl_conv * fr_all, 16.0 * C * fr_all);
                 hipError_t le = launch_wn_rowsplit(p, 0, C, B, bn, st);
-                if (timed_now) wn_rowsplit_set_timing_events(nullptr, nullptr);
                 timed_end();
-                if (le == hipSuccess) le = launch_wn_rowsplit(p, 1, C, B, bn, st);
+                if (le == hipSuccess) {
+                    timed_begin(300 + (bn48 ? 1 : 0) + (dil > 8 ? 2 : 0), fl_out * fr_all, 20.0 * C * fr_all);
+                    le = launch_wn_rowsplit(p, 1, C, B, bn, st);
+                    timed_end();
+                }
                 if (le != hipSuccess) return fail(h, DSD_EHIP, "row-split WaveNet layer launch failed: %s", hipGetErrorString(le));
                 continue;
             }
             film_of(h, l, film_col0, film_colb, g.p.film, g.p.film_cstride, g.p.film_col0, g.p.film_colb);
             g.p.aux = h->cp + (long)l * 2 * C * Ts; g.p.aux_bstride = cps; g.p.aux_rstride = Ts;
             g.p.out = h->z; g.p.o_bstride = xs; g.p.o_rstride = Ts;
-            timed_begin();
+            timed_begin(400 + (dil > 8 ? 2 : 0), fl_conv * fr_all, 16.0 * C * fr_all);
             rc = run_gemm(h, g, st);
             timed_end();
             if (rc) return rc;
             GemmCall o = make_gemm(h, h->g_outp[l], h->z, xs, Ts, B, T, ST_PLAIN, EP_RESSKIP, 0);
             o.p.C = C; o.p.x = h->xh; o.p.skip = h->skip; o.p.first_layer = (l == 0);
             o.p.o_bstride = xs; o.p.o_rstride = Ts;
-            if ((rc = run_gemm(h, o, st))) return rc;
+            timed_begin(500, fl_out * fr_all, 20.0 * C * fr_all);
+            rc = run_gemm(h, o, st);
+            timed_end();
+            if (rc) return rc;
         }
         // skip projection -> output projection + solver update (-> the next evaluation's input projection) in one launch with
         // one workgroup per frame tile (wn_edge.hip); DSD_EDGE=0: the three GEMMs of gemm.hip
@@ -1477,7 +1623,11 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             int nwg = B * p.tiles_per_b;
             if (ragged) { p.cgmap = h->cg_dev[ncb == 2 ? 1 : 0]; p.ncg = h->cg_n[ncb == 2 ? 1 : 0]; nwg = p.ncg; }
             if (fits) {      // (more state terms than the kernel holds at once: the three GEMMs below)
+                double fr_all = (double)B * T;
+                if (ragged) { fr_all = 0; for (int v : h->lens_host) fr_all += v; }
+                timed_begin(700, 2.0 * (C * C + 2.0 * C * FM) * fr_all, 4.0 * (2 * C + 3 * FM) * fr_all);
                 hipError_t ee = launch_wn_edge(p, C, ncb, nwg, st);
+                timed_end();
                 if (ee != hipSuccess) return fail(h, DSD_EHIP, "WaveNet edge-kernel launch failed: %s", hipGetErrorString(ee));
                 if (p.next_src >= 0) h->edge_xh_src = next_xin;
                 return DSD_OK;
@@ -1509,13 +1659,19 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
     // pw2 launches only C / 512 workgroups per frame tile, so a single utterance stays on the GEMM family
     const bool lx_ragged = h->use_cg && !h->lens_host.empty();
     const long lx_tiles = lx_ragged ? (long)h->cg_n[1] : (long)B * ((T + 31) / 32);
-    static const int lx_env = getenv("DSD_LYNX_RESIDENT") ? atoi(getenv("DSD_LYNX_RESIDENT")) : -1;
+    const int lx_env = path_opts().lynx_resident;
     const bool lx_ok = lx_env != 0 && lx_layer_supported(C, inner);
     // pw1 launches 2 inner / 512 workgroups per frame tile (8 at C = 1024: one utterance of ~1000 frames already fills the
     // chip), pw2 only C / 512 (measured at C = 1024: slower at B = 2, +4 % at 3, +12 % at 4, +10 % at 8)
     const bool lx_res1 = lx_ok && (lx_env == 1 || lx_tiles * (2 * inner / 512) >= 192);
     const bool lx_res2 = lx_ok && (lx_env == 1 || lx_tiles * (C / 512) >= 192);
     const bool lx_res = lx_res1;
+    // algorithmic work per valid frame of the two pointwise GEMMs: pw1 C -> 2 inner (reads x_in, writes the
+    // SwiGLU product), pw2 inner -> C (reads the depthwise conv's output, the residual stream and the next layer's hoisted
+    // conditioner projection, writes x and x_in)
+    double lx_fr = (double)B * T;
+    if (lx_ragged) { lx_fr = 0; for (int v : h->lens_host) lx_fr += v; }
+    const double lx_fl1 = 2.0 * C * 2 * inner, lx_by1 = 4.0 * (C + inner), lx_fl2 = 2.0 * inner * C, lx_by2 = 4.0 * (inner + 4 * C);
     for (int l = 0; l < L; ++l) {
         if (lx_res) {
             LxLayerP p;
@@ -1541,10 +1697,8 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                 p.cpn = h->cp + (long)next * C * Ts; p.cpn_bstride = (long)L * C * Ts;
                 film_of(h, next, film_col0, film_colb, p.film, p.film_cstride, p.film_col0, p.film_colb);
             }
-            timed_begin();
-            if (timed_now) lx_layer_set_timing_events(h->ev_pool[h->ev_used].first, h->ev_pool[h->ev_used].second);
+            timed_begin(600, lx_fl1 * lx_fr, lx_by1 * lx_fr);
             hipError_t le = launch_lx_layer(p, 0, C, st);
-            if (timed_now) lx_layer_set_timing_events(nullptr, nullptr);
             timed_end();
             if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw1 launch failed: %s", hipGetErrorString(le));
             e = launch_dwconv(h->ubuf, h->vbuf, us, Ts, inner, B, T, h->lens_host.empty() ? nullptr : h->lens_dev,
@@ -1552,21 +1706,26 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                               h->dw_prelu[l] == SIZE_MAX ? nullptr : h->blob + h->dw_prelu[l], st);
             if (e != hipSuccess) return fail(h, DSD_EHIP, "dwconv launch failed: %s", hipGetErrorString(e));
             if (lx_res2) {
-                if ((le = launch_lx_layer(p, 1, C, st)) != hipSuccess)
-                    return fail(h, DSD_EHIP, "LYNXNet pw2 launch failed: %s", hipGetErrorString(le));
+                timed_begin(610, lx_fl2 * lx_fr, lx_by2 * lx_fr);
+                le = launch_lx_layer(p, 1, C, st);
+                timed_end();
+                if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw2 launch failed: %s", hipGetErrorString(le));
             } else {
                 GemmCall o = make_gemm(h, h->g_pw2[l], h->vbuf, us, Ts, B, T, ST_PLAIN, EP_LYNX_NEXT, 0);
                 o.p.act = ACT_NONE;
                 o.p.aux = h->xh; o.p.aux_bstride = xs; o.p.aux_rstride = Ts;
                 lynx_next(o, l + 1);
-                if ((rc = run_gemm(h, o, st))) return rc;
+                timed_begin(620, lx_fl2 * lx_fr, lx_by2 * lx_fr);
+                rc = run_gemm(h, o, st);
+                timed_end();
+                if (rc) return rc;
             }
             continue;
         }
         GemmCall g = make_gemm(h, h->g_pw1[l], h->xin, xs, Ts, B, T, ST_LN, EP_SWIGLU, 0);
         if ((rc = ln_input(g))) return rc;
         g.p.out = h->ubuf; g.p.o_bstride = us; g.p.o_rstride = Ts;
-        timed_begin();
+        timed_begin(630, lx_fl1 * lx_fr, lx_by1 * lx_fr);
         rc = run_gemm(h, g, st);
         timed_end();
         if (rc) return rc;
@@ -1579,7 +1738,10 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
         o.p.act = ACT_NONE;
         o.p.aux = h->xh; o.p.aux_bstride = xs; o.p.aux_rstride = Ts;
         lynx_next(o, l + 1);
-        if ((rc = run_gemm(h, o, st))) return rc;
+        timed_begin(620, lx_fl2 * lx_fr, lx_by2 * lx_fr);
+        rc = run_gemm(h, o, st);
+        timed_end();
+        if (rc) return rc;
     }
     GemmCall f = make_gemm(h, h->g_out, h->xh, xs, Ts, B, T, ST_LN, EP_LINCOMB, 0);
     if ((rc = ln_input(f))) return rc;
@@ -1755,6 +1917,7 @@ int dsd_finalize_weights(dsd_handle* h) {
 
 int dsd_prepare_cond(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64_t stride_b, int64_t stride_h,
                      int64_t stride_t, void* stream) {
+    refresh_path_opts();
     if (!h || !cond) return fail(h, DSD_EINVAL, "dsd_prepare_cond: null argument");
     if (is_aux(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is an aux decoder (use dsd_aux_decode)");
     if (is_enc(h) || is_tok(h)) return fail(h, DSD_ESTATE, "dsd_prepare_cond: this handle is an encoder (use dsd_encode / dsd_token_encode)");
@@ -1902,6 +2065,7 @@ static int run_fs2_layers(dsd_handle* h, int H, int NL, int heads, int ffn_ks, i
 
 int dsd_encode(dsd_handle* h, const int64_t* txt_tokens, const int64_t* mel2ph, const float* f0, int32_t B, int32_t L,
                int32_t T, const dsd_encode_extras* ex, float* cond_out, void* stream) {
+    refresh_path_opts();
     if (!h || !txt_tokens || !mel2ph || !f0 || !cond_out) return fail(h, DSD_EINVAL, "dsd_encode: null argument");
     if (!is_enc(h)) return fail(h, DSD_ESTATE, "dsd_encode: this handle is not an encoder");
     if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_encode: weights are not finalized");
@@ -2016,6 +2180,7 @@ static int tok_common(dsd_handle* h, const char* who, const void* a, const void*
 
 int dsd_token_encode(dsd_handle* h, const float* embed, const uint8_t* padding_mask, int32_t B, int32_t L, float* enc_out,
                      void* stream) {
+    refresh_path_opts();
     int rc = tok_common(h, "dsd_token_encode", embed, padding_mask, enc_out, B, L);
     if (rc) return rc;
     const dsd_token_encoder_config& t = h->tcfg;
@@ -2050,6 +2215,7 @@ int dsd_token_encode(dsd_handle* h, const float* embed, const uint8_t* padding_m
 
 int dsd_predict_dur(dsd_handle* h, const float* dur_cond, const uint8_t* padding_mask, int32_t B, int32_t L, float* dur_out,
                     void* stream) {
+    refresh_path_opts();
     int rc = tok_common(h, "dsd_predict_dur", dur_cond, padding_mask, dur_out, B, L);
     if (rc) return rc;
     const dsd_token_encoder_config& t = h->tcfg;
@@ -2187,6 +2353,7 @@ int dsd_vocoder_create(const dsd_vocoder_config* cfg, dsd_handle** out) {
 int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_m, int64_t stride_t,
                const float* f0, const float* rand_ini, const float* noise, const float* pre_noise, float* wav_out,
                void* stream) {
+    refresh_path_opts();
     if (!h || !mel || !f0 || !wav_out) return fail(h, DSD_EINVAL, "dsd_vocode: null argument");
     if (!is_voc(h)) return fail(h, DSD_ESTATE, "dsd_vocode: this handle is not a vocoder");
     if (!h->vcfg.mini_nsf && (!rand_ini || !noise))
@@ -2355,6 +2522,7 @@ int dsd_vocode(dsd_handle* h, const float* mel, int32_t B, int32_t T, int64_t st
 
 int dsd_aux_decode(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64_t stride_b, int64_t stride_h,
                    int64_t stride_t, float* out, const float* out_scale, const float* out_shift, void* stream) {
+    refresh_path_opts();
     if (!h || !cond || !out) return fail(h, DSD_EINVAL, "dsd_aux_decode: null argument");
     if (!is_aux(h)) return fail(h, DSD_ESTATE, "dsd_aux_decode: this handle is a denoiser backbone");
     if (!h->finalized) return fail(h, DSD_ESTATE, "dsd_aux_decode: weights are not finalized");
@@ -2403,6 +2571,7 @@ int dsd_aux_decode(dsd_handle* h, const float* cond, int32_t B, int32_t T, int64
 }
 
 int dsd_denoise(dsd_handle* h, const float* x, const float* t, int32_t t_len, float* out, void* stream) {
+    refresh_path_opts();
     if (!h || !x || !t || !out) return fail(h, DSD_EINVAL, "dsd_denoise: null argument");
     if (!h->cond_ready) return fail(h, DSD_ESTATE, "dsd_denoise: call dsd_prepare_cond first");
     if (x == out) return fail(h, DSD_EINVAL, "dsd_denoise: out must not alias x");
@@ -2432,6 +2601,7 @@ int dsd_denoise(dsd_handle* h, const float* x, const float* t, int32_t t_len, fl
 
 int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, const float* noise, float* out,
                const float* out_scale, const float* out_shift, uint32_t flags, void* stream) {
+    refresh_path_opts();
     if (!h || !prog || !x_init || !out) return fail(h, DSD_EINVAL, "dsd_sample: null argument");
     if (!h->cond_ready) return fail(h, DSD_ESTATE, "dsd_sample: call dsd_prepare_cond first");
     if (prog->n_bufs < 1 || prog->n_bufs > 64 || prog->n_evals < 0 || (prog->n_evals > 0 && !prog->evals))
@@ -2519,6 +2689,7 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
         key.append((const char*)&noise, sizeof(noise));
         key.append((const char*)&B, sizeof(B));             // batch shape: grids and strides are baked into the launches
         key.append((const char*)&T, sizeof(T));
+        key.append((const char*)&path_opts(), sizeof(PathOpts));   // the path switches: a graph is ONE set of launch choices
         key.push_back(h->lens_host.empty() ? 'd' : 'r');       // dense / ragged: other kernels, and grids that follow
         for (int v : h->lens_host) key.append((const char*)&v, sizeof(v));      // the lengths (baked into the launches)
         auto it = h->graphs.find(key);
@@ -2595,6 +2766,7 @@ int dsd_set_lengths(dsd_handle* h, const int32_t* lengths, int32_t B, void* stre
 int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
     if (!h || !out) return DSD_EINVAL;
     memset(out, 0, sizeof(*out));
+    refresh_path_opts();
     const int64_t C = h->c_user ? h->c_user : C_of(h), M = FM_of(h), L = L_of(h);
     out->weight_bytes = (int64_t)h->blob_floats * 4;
     out->workspace_bytes = (int64_t)h->arena_floats * 4;
@@ -2618,7 +2790,20 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
         long t32 = (long)h->B * ((h->T + 31) / 32);
         if (!h->lens_host.empty()) { t32 = 0; for (int v : h->lens_host) t32 += (v + 31) / 32; }
         const bool edge = edge_env != 0 && wn_edge_supported(C_of(h), FM_of(h)) && h->arena && (edge_env == 1 || t32 >= 128);
-        out->kernels_per_nfe = (h->arena && wn_use_fused(h) ? 1 : 2) * (int)L + (edge ? 1 : 3);    // fused: one launch per layer
+        std::vector<WnSeg> plan;
+        int per_layer = 2;                          // the row-split pair or the two GEMMs
+        const long tiles = wn_tiles32(h);
+        out->split_tiles = (int32_t)tiles;
+        if (h->arena && wn_plan_for(h, plan)) {
+            per_layer = 0;
+            out->split_tiles = 0;
+            for (const WnSeg& sg : plan) {
+                per_layer += sg.kind == WN_FUSED ? 1 : 2;
+                (sg.kind == WN_FUSED ? out->fused_tiles : out->split_tiles) += sg.nt;
+            }
+        }
+        out->layer_launches = per_layer;
+        out->kernels_per_nfe = per_layer * (int)L + (edge ? 1 : 3);
     } else {
         const int64_t inner = inner_of(h), ks = h->cfg.kernel_size;
         out->flops_per_frame_nfe = 2 * (M * C + L * (C * 2 * inner + ks * inner + inner * C) + C * M);
@@ -2632,32 +2817,73 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
 int dsd_kernel_timing(dsd_handle* h, int32_t enable) {
     if (!h) return DSD_EINVAL;
     h->timing = enable != 0;
-    h->timing_seq = 0;
+    h->tclasses.clear();
+    h->timing_evals = 0;
     if (const char* e = getenv("DSD_TIMING_STRIDE")) h->timing_stride = std::max(1, atoi(e));
     h->ev_used = 0;
     h->cal_used = 0;
     return DSD_OK;
 }
 
+int dsd_kernel_timing_classes(dsd_handle* h, dsd_kernel_time* out, int32_t max_classes, int32_t* n_classes,
+                              double* empty_pair_ms) {
+    if (!h || !out || !n_classes || max_classes < 1) return DSD_EINVAL;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    int n = 0;
+    // largest share of the evaluation first
+    std::vector<std::pair<double, const dsd_handle::TimedClass*>> order;
+    std::vector<double> means(h->tclasses.size(), 0.0);
+    for (size_t i = 0; i < h->tclasses.size(); ++i) {
+        const auto& c = h->tclasses[i];
+        double sum = 0;
+        for (size_t idx : c.evs) {
+            HIP_OK(h, hipEventSynchronize(h->ev_pool[idx].second));
+            float ms = 0.f;
+            HIP_OK(h, hipEventElapsedTime(&ms, h->ev_pool[idx].first, h->ev_pool[idx].second));
+            sum += ms;
+        }
+        means[i] = c.evs.empty() ? 0.0 : sum / (double)c.evs.size();
+        order.emplace_back(-means[i] * (double)c.launches, &c);
+    }
+    std::sort(order.begin(), order.end());
+    for (auto& kv : order) {
+        if (n == max_classes) break;
+        const auto& c = *kv.second;
+        if (c.evs.empty()) continue;
+        dsd_kernel_time& o = out[n++];
+        memset(&o, 0, sizeof(o));
+        snprintf(o.name, sizeof(o.name), "%s", c.name.c_str());
+        o.mean_ms = means[&c - h->tclasses.data()];
+        o.launches_timed = (int64_t)c.evs.size();
+        o.launches = (int64_t)c.launches;
+        o.evaluations = (int64_t)h->timing_evals;
+        o.flops_per_launch = c.flops;
+        o.bytes_per_launch = c.bytes;
+    }
+    *n_classes = n;
+    if (empty_pair_ms) {
+        double cal = 0;
+        for (size_t i = 0; i < h->cal_used; ++i) {
+            HIP_OK(h, hipEventSynchronize(h->cal_pool[i].second));
+            float ms = 0.f;
+            HIP_OK(h, hipEventElapsedTime(&ms, h->cal_pool[i].first, h->cal_pool[i].second));
+            cal += ms;
+        }
+        *empty_pair_ms = h->cal_used ? cal / (double)h->cal_used : 0.0;
+    }
+    return DSD_OK;
+}
+
 int dsd_kernel_timing_read(dsd_handle* h, double* mean_ms, double* empty_pair_ms, int64_t* launches) {
     if (!h || !mean_ms || !empty_pair_ms || !launches) return DSD_EINVAL;
-    HIP_OK(h, hipSetDevice(h->cfg.device));
-    double sum = 0, cal = 0;
-    for (size_t i = 0; i < h->ev_used; ++i) {
-        HIP_OK(h, hipEventSynchronize(h->ev_pool[i].second));
-        float ms = 0.f;
-        HIP_OK(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
-        sum += ms;
-    }
-    for (size_t i = 0; i < h->cal_used; ++i) {
-        HIP_OK(h, hipEventSynchronize(h->cal_pool[i].second));
-        float ms = 0.f;
-        HIP_OK(h, hipEventElapsedTime(&ms, h->cal_pool[i].first, h->cal_pool[i].second));
-        cal += ms;
-    }
-    *launches = (int64_t)h->ev_used;
-    *mean_ms = h->ev_used ? sum / (double)h->ev_used : 0.0;
-    *empty_pair_ms = h->cal_used ? cal / (double)h->cal_used : 0.0;
+    dsd_kernel_time top;
+    int32_t n = 0;
+    int rc = dsd_kernel_timing_classes(h, &top, 1, &n, empty_pair_ms);      // the class with the largest share of the pass
+    if (rc) return rc;
+    *launches = n ? top.launches_timed : 0;
+    *mean_ms = n ? top.mean_ms : 0.0;
+    h->tclasses.clear();
+    h->timing_evals = 0;
     h->ev_used = 0;
     h->cal_used = 0;
     return DSD_OK;

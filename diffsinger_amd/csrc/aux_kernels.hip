@@ -436,7 +436,7 @@ hipError_t launch_dwconv(const float* src, float* dst, long bstride, int rstride
                          const float* w, const float* bias, int ksz, int act, const float* prelu,
                          hipStream_t stream) {
     if (ksz > DW_MAXK || ksz < 1 || ksz % 2 == 0) return hipErrorInvalidValue;
-    static const int rows_env = getenv("DSD_DWCONV_ROWS") ? atoi(getenv("DSD_DWCONV_ROWS")) : -1;      // 0: the first form (A/B)
+    const int rows_env = path_opts().dwconv_rows;      // 0: the first form (A/B)
     if (rows_env != 0 && (ksz == 31 || ksz == 7)) {
         const int nrows = B * C;
         if (ksz == 31)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 namespace dsd {
 
@@ -34,6 +35,60 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3, ACT_LRELU = 4
 #ifndef DSD_ST_AUX
 #define DSD_ST_AUX 16
 #endif
+
+// Path switches (diagnostics, A/B runs, tests).  Every entry point of the C ABI that launches kernels re-reads them from the
+// environment ONCE (refresh_path_opts), so one process can drive either side of a switch through consecutive calls - this is
+// how tests/test_gpu_fused.py puts every instantiation of the layer kernels under oracle parity - and the values are part of
+// the hipGraph cache key (a captured graph is the launch sequence of ONE set of choices).  -1 = unset: the library's own rule.
+struct PathOpts {
+    int fused_layer;        // DSD_FUSED_LAYER     0: never wn_layer.hip, 1: on every supported grid
+    int wn_plan;            // DSD_WN_PLAN         0: one launch shape per layer (round 2), 1/unset: mixed plans (wn_plan_for)
+    int rowsplit;           // DSD_ROWSPLIT        0: never wn_rowsplit.hip
+    int rs_bn48;            // DSD_RS_BN48         0: no 48-frame tiles of the row-split pair
+    int rs_conv_q;          // DSD_RS_CONV_Q       0 / 1: K-half / K-quarter layout of the row-split conv
+    int rs_rows;            // DSD_RS_ROWS         64 / 128 / 256: rows per workgroup of the row-split pair
+    int edge;               // DSD_EDGE            0: never wn_edge.hip, 1: on every grid
+    int lynx_resident;      // DSD_LYNX_RESIDENT   0: never lynx_layer.hip, 1: on every supported grid
+    int lynx_pw1p;          // DSD_LYNX_PW1P
+    int lynx_pw2d;          // DSD_LYNX_PW2D
+    int narrow;             // DSD_NARROW          gemm.hip: 16-frame tiles off / on
+    int gm_shift;           // DSD_GM_SHIFT        gemm.hip: L2 blocking of the work order
+    int film_t;             // DSD_FILM_T          0: FiLM vectors from D [L*C][Ns] instead of the transposed table
+    int dwconv_rows;        // DSD_DWCONV_ROWS     0: the first depthwise-convolution kernel
+    int precision;          // DSD_PRECISION       1: split-bf16 (bf16x3) layer kernels where they exist (opt-in, own tolerance)
+    long nb2_min;           // DSD_NB2_MIN_WG      gemm.hip: workgroups from which 64-frame tiles are used (default 512)
+};
+const PathOpts& path_opts();
+void refresh_path_opts();
+
+// Timing hook of bench.py (dsd_kernel_timing): api.hip arms the slot with a start / stop event pair before a launch it wants
+// timed; the launcher that finds it armed goes through hipExtLaunchKernelGGL, which ties the two events to the dispatch
+// packet itself (their elapsed time is the kernel's own begin -> end time, what a rocprofv3 kernel trace reports, not a
+// bracket around the launch), records WHICH instantiation ran - kernel name + template arguments as rocprofv3 prints them,
+// e.g. "wn_layer_kernel<4, 48, 0>" - and disarms it (one launch per arming).
+struct TimingSlot {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool taken = false;
+    char name[96] = {0};
+};
+TimingSlot& timing_slot();      // thread-local (api.hip)
+
+template <typename K, typename P, typename... NameArgs>
+inline hipError_t launch_timed(K kern, dim3 grid, dim3 block, int lds, hipStream_t st, const P& p, const char* name_fmt,
+                               NameArgs... name_args) {
+    TimingSlot& ts = timing_slot();
+    if (ts.e0 && ts.e1 && !ts.taken) {
+        hipExtLaunchKernelGGL(kern, grid, block, lds, st, ts.e0, ts.e1, 0, p);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wformat-security"
+        snprintf(ts.name, sizeof(ts.name), name_fmt, name_args...);      // (every caller passes a literal)
+#pragma clang diagnostic pop
+        ts.taken = true;
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, lds, st, p);
+    }
+    return hipGetLastError();
+}
 
 constexpr int kMaxTerms = 8;
 constexpr int kMaxOut = 3;
@@ -128,7 +183,6 @@ struct GemmP {
 // gemm.hip
 hipError_t launch_gemm(const GemmP& p, int stage, int taps, int epi, int nb, int fast, int batch, hipStream_t st);
 bool gemm_has_fast(int taps, int nb, int S);
-void gemm_set_timing_events(hipEvent_t start, hipEvent_t stop);   // next launches on this thread; (nullptr, nullptr) = off
 int gemm_lds_bytes(int KC, int S);
 int gemm_lds_bytes_fast(int S, int stage, int taps, int K, int nb, int resident);
 int gemm_fast_chunk_rows(int taps, int nb);
@@ -155,18 +209,19 @@ struct WnLayerP {
     const int* lens;        // ragged batches: per-item valid length (nullptr: T)
     const int* cgmap;       // ragged batches: the (item, 32-frame tile) column groups that hold valid frames
     int ncg;
+    int tile0;              // dense batches: the launch covers tiles [tile0, tile0 + ntiles) of the batch's (item, frame tile)
+                            // order - a layer may run as several launches over disjoint tile ranges (api.hip, wn_plan_for)
+    int ntiles;             // ... their number (0: all of batch * tiles_per_b; ragged: ncg)
 };
 hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st);
 bool wn_layer_supported(int C, int dil);
 hipError_t wn_layer_init_all();
-void wn_layer_set_timing_events(hipEvent_t start, hipEvent_t stop);
 // wn_rowsplit.hip: the same layer as two launches with the 2C rows split over 2C / 64 workgroups per 32-frame tile, for
 // grids too small for full-row tiles.  which = 0: conv + FiLM + gate (xin -> z); 1: out-proj + residual / skip (in place
 // when xout == xin)
 hipError_t launch_wn_rowsplit(const WnLayerP& p, int which, int C, int batch, int bn, hipStream_t st);
 hipError_t wn_rowsplit_init_all();
 bool wn_rowsplit_supported(int C, int dil, long Ts);
-void wn_rowsplit_set_timing_events(hipEvent_t start, hipEvent_t stop);
 
 // wn_edge.hip: the WaveNet's small GEMMs around the residual layers (skip projection -> output projection + solver update ->
 // the next evaluation's input projection) as one launch with one workgroup per frame tile
@@ -235,7 +290,6 @@ hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st);
 bool lx_layer_supported(int C, int inner);
 hipError_t lx_layer_init_all();
 bool lx_pw1_merges_stats(const LxLayerP& p, int C);
-void lx_layer_set_timing_events(hipEvent_t start, hipEvent_t stop);
 
 // aux_kernels.hip
 hipError_t launch_pack(const float* src, long sb, long sr, long st, float* dst, int B, int R, int T, int Ts,

@@ -906,26 +906,13 @@ static hipError_t set_attr() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-// bench.py's timing hook: when a start/stop event pair is given, the launch goes through
-// hipExtLaunchKernelGGL, which ties the two events to the dispatch packet itself - their elapsed time is the
-// kernel's own begin->end time (what a rocprofv3 kernel trace reports), not a bracket around the launch.
-static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-void gemm_set_timing_events(hipEvent_t start, hipEvent_t stop) {
-    g_ev_start = start;
-    g_ev_stop = stop;
-}
-
 template <int STAGE, int TAPS, int EPI, int NB, int SW, int RES = 0, int WN = 2, int RAG = 0>
 static hipError_t launch_one(const GemmP& p, int batch, hipStream_t st) {
     const int lds = p.lds_bytes;
     dim3 grid((RAG ? p.ncg : batch * p.tiles_per_b) * p.mtiles, 1, 1);
     if (grid.x == 0) return hipSuccess;          // a ragged batch of empty items
-    if (g_ev_start && g_ev_stop)
-        hipExtLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN, RAG>), grid, dim3(256), lds, st, g_ev_start,
-                              g_ev_stop, 0, p);
-    else
-        hipLaunchKernelGGL((gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN, RAG>), grid, dim3(256), lds, st, p);
-    return hipGetLastError();
+    return launch_timed(gemm_kernel<STAGE, TAPS, EPI, NB, SW, RES, WN, RAG>, grid, dim3(256), lds, st, p,
+                        "gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", STAGE, TAPS, EPI, NB, SW, RES, WN, RAG);
 }
 
 // fast instantiations exist for S = 48 / 80 (32-frame tiles) and 80 / 112 (64-frame tiles); 1x1 GEMMs have

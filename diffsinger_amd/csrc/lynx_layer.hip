@@ -811,12 +811,6 @@ static hipError_t lx_attr(K kern) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-static thread_local hipEvent_t g_lx_ev0 = nullptr, g_lx_ev1 = nullptr;
-void lx_layer_set_timing_events(hipEvent_t start, hipEvent_t stop) {
-    g_lx_ev0 = start;
-    g_lx_ev1 = stop;
-}
-
 template <int KT, int RAG>
 static hipError_t lx_launch_pw1p(const LxLayerP& p, int nwg, hipStream_t st) {
     static bool attr = false;
@@ -827,17 +821,13 @@ static hipError_t lx_launch_pw1p(const LxLayerP& p, int nwg, hipStream_t st) {
     }
     if (nwg == 0) return hipSuccess;
     const int ldsb = lx_pw1p_lds_bytes(KT);
-    if (g_lx_ev0 && g_lx_ev1)
-        hipExtLaunchKernelGGL((lx_pw1p_kernel<KT, RAG>), dim3(nwg), dim3(256), ldsb, st, g_lx_ev0, g_lx_ev1, 0, p);
-    else
-        hipLaunchKernelGGL((lx_pw1p_kernel<KT, RAG>), dim3(nwg), dim3(256), ldsb, st, p);
-    return hipGetLastError();
+    return launch_timed(lx_pw1p_kernel<KT, RAG>, dim3(nwg), dim3(256), ldsb, st, p, "lx_pw1p_kernel<%d, %d>", KT, RAG);
 }
 
 // pw1 as one workgroup per frame tile when that costs no more rounds of the chip than one per (frame tile, row tile):
 // ceil(nft / CUs) * mtiles row-tile times against ceil(nft * mtiles / CUs).  DSD_LYNX_PW1P=0/1 forces the choice.
 static bool lx_use_pw1p(int nft, int mtiles) {
-    static const int force = getenv("DSD_LYNX_PW1P") ? atoi(getenv("DSD_LYNX_PW1P")) : -1;
+    const int force = path_opts().lynx_pw1p;
     if (force >= 0) return force != 0;
     static int cus = 0;
     if (!cus) {
@@ -864,15 +854,8 @@ static hipError_t lx_launch(const LxLayerP& p, int which, int nwg, hipStream_t s
     }
     if (nwg == 0) return hipSuccess;
     const int ldsb = lx_lds_bytes(KT);
-    if (which == 0) {
-        if (g_lx_ev0 && g_lx_ev1)
-            hipExtLaunchKernelGGL((lx_pw1_kernel<KT, RAG>), dim3(nwg), dim3(256), ldsb, st, g_lx_ev0, g_lx_ev1, 0, p);
-        else
-            hipLaunchKernelGGL((lx_pw1_kernel<KT, RAG>), dim3(nwg), dim3(256), ldsb, st, p);
-    } else {
-        hipLaunchKernelGGL((lx_pw2_kernel<KT, RAG>), dim3(nwg), dim3(256), ldsb, st, p);
-    }
-    return hipGetLastError();
+    if (which == 0) return launch_timed(lx_pw1_kernel<KT, RAG>, dim3(nwg), dim3(256), ldsb, st, p, "lx_pw1_kernel<%d, %d>", KT, RAG);
+    return launch_timed(lx_pw2_kernel<KT, RAG>, dim3(nwg), dim3(256), ldsb, st, p, "lx_pw2_kernel<%d, %d>", KT, RAG);
 }
 
 template <int NP, int RAG>
@@ -884,8 +867,7 @@ static hipError_t lx_launch_pw2d(const LxLayerP& p, int nwg, hipStream_t st) {
         attr = true;
     }
     if (nwg == 0) return hipSuccess;
-    hipLaunchKernelGGL((lx_pw2d_kernel<NP, RAG>), dim3(nwg), dim3(256), (2 * 512 * 32 + 1024) * 4, st, p);
-    return hipGetLastError();
+    return launch_timed(lx_pw2d_kernel<NP, RAG>, dim3(nwg), dim3(256), (2 * 512 * 32 + 1024) * 4, st, p, "lx_pw2d_kernel<%d, %d>", NP, RAG);
 }
 
 // which = 0: pw1 (LayerNorm -> C -> 2 inner -> SwiGLU);  1: pw2 (inner -> C + residual + next-layer transition)
@@ -900,7 +882,7 @@ hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st) 
         if (nft != 0 || e != hipSuccess) return e;
     }
     // pw2 with double-buffered 512-channel half-phases (inner = 1024 or 2048); DSD_LYNX_PW2D=0: the two-phase form
-    static const int pw2d = getenv("DSD_LYNX_PW2D") ? atoi(getenv("DSD_LYNX_PW2D")) : -1;
+    const int pw2d = path_opts().lynx_pw2d;
     if (which == 1 && pw2d != 0 && (p.inner == 2048 || p.inner == 1024) && (C == 1024 || C == 512)) {
         hipError_t e = p.inner == 2048 ? (p.cgmap ? lx_launch_pw2d<4, 1>(p, nwg, st) : lx_launch_pw2d<4, 0>(p, nwg, st))
                                        : (p.cgmap ? lx_launch_pw2d<2, 1>(p, nwg, st) : lx_launch_pw2d<2, 0>(p, nwg, st));

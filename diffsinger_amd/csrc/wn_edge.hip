@@ -412,8 +412,8 @@ static hipError_t edge_launch(const WnEdgeP& p, int nwg, hipStream_t st) {
         attr = true;
     }
     if (nwg == 0) return hipSuccess;
-    hipLaunchKernelGGL((wn_edge_kernel<NCH, FMB, NCB, RAG>), dim3(nwg), dim3(256), wn_edge_lds_bytes(64 * NCH, FMB, NCB), st, p);
-    return hipGetLastError();
+    return launch_timed(wn_edge_kernel<NCH, FMB, NCB, RAG>, dim3(nwg), dim3(256), wn_edge_lds_bytes(64 * NCH, FMB, NCB), st, p,
+                        "wn_edge_kernel<%d, %d, %d, %d>", NCH, FMB, NCB, RAG);
 }
 
 // (the kernel also instantiates with 16-frame tiles, NCB = 1; measured at B = 1, T = 1000 - 63 workgroups - it takes 18.6 us

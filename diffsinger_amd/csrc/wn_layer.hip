@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int rest = RAG ? p.cgmap[work] : work;
+    const int rest = RAG ? p.cgmap[work] : work + p.tile0;
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int Tb = (RAG && p.lens) ? p.lens[b] : p.T;
@@ -429,7 +429,7 @@ int wn_layer_lds_bytes(int nch, int sw) { return (64 * nch * sw + 4 * 16 * 2 * n
 bool wn_layer_supported(int C, int dil) { return (C == 256 || C == 192) && dil >= 1 && dil <= 16; }
 
 template <int NCH, int SW, int RAG>
-static hipError_t wn_launch(const WnLayerP& p, int ntiles, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+static hipError_t wn_launch(const WnLayerP& p, int ntiles, hipStream_t st) {
     const int ldsb = wn_layer_lds_bytes(NCH, SW);
     static bool attr_done = false;       // per instantiation; set outside any capture by wn_layer_init_all
     if (!attr_done) {
@@ -439,26 +439,15 @@ static hipError_t wn_launch(const WnLayerP& p, int ntiles, hipStream_t st, hipEv
         attr_done = true;
     }
     if (ntiles == 0) return hipSuccess;
-    if (e0 && e1)
-        hipExtLaunchKernelGGL((wn_layer_kernel<NCH, SW, RAG>), dim3(ntiles), dim3(256), ldsb, st, e0, e1, 0, p);
-    else
-        hipLaunchKernelGGL((wn_layer_kernel<NCH, SW, RAG>), dim3(ntiles), dim3(256), ldsb, st, p);
-    return hipGetLastError();
-}
-
-static thread_local hipEvent_t g_wn_ev0 = nullptr, g_wn_ev1 = nullptr;
-void wn_layer_set_timing_events(hipEvent_t start, hipEvent_t stop) {
-    g_wn_ev0 = start;
-    g_wn_ev1 = stop;
+    return launch_timed(wn_layer_kernel<NCH, SW, RAG>, dim3(ntiles), dim3(256), ldsb, st, p, "wn_layer_kernel<%d, %d, %d>", NCH, SW, RAG);
 }
 
 hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st) {
     const int sw = p.dil <= 8 ? 48 : 80;
-    const int ntiles = p.cgmap ? p.ncg : batch * p.tiles_per_b;
-    hipEvent_t e0 = g_wn_ev0, e1 = g_wn_ev1;
+    const int ntiles = p.cgmap ? p.ncg : (p.ntiles > 0 ? p.ntiles : batch * p.tiles_per_b);
 #define WN_CASE(NCH_, SW_)                                                                                  \
     if (C == 64 * NCH_ && sw == SW_)                                                                        \
-        return p.cgmap ? wn_launch<NCH_, SW_, 1>(p, ntiles, st, e0, e1) : wn_launch<NCH_, SW_, 0>(p, ntiles, st, e0, e1);
+        return p.cgmap ? wn_launch<NCH_, SW_, 1>(p, ntiles, st) : wn_launch<NCH_, SW_, 0>(p, ntiles, st);
     WN_CASE(4, 48)
     WN_CASE(4, 80)
     WN_CASE(3, 48)
@@ -472,8 +461,8 @@ hipError_t wn_layer_init_all() {
     WnLayerP p{};
     hipError_t e;
 #define WN_INIT(NCH_, SW_)                                                                       \
-    if ((e = wn_launch<NCH_, SW_, 0>(p, 0, nullptr, nullptr, nullptr)) != hipSuccess) return e;  \
-    if ((e = wn_launch<NCH_, SW_, 1>(p, 0, nullptr, nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = wn_launch<NCH_, SW_, 0>(p, 0, nullptr)) != hipSuccess) return e;  \
+    if ((e = wn_launch<NCH_, SW_, 1>(p, 0, nullptr)) != hipSuccess) return e;
     WN_INIT(4, 48)
     WN_INIT(4, 80)
     WN_INIT(3, 48)

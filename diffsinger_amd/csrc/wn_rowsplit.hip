@@ -90,7 +90,7 @@ __device__ __forceinline__ void rs_pin_args(const WnLayerP& p) {
 #if DSD_RS_PIN_ARGS
     asm volatile("" ::"s"(p.Aconv), "s"(p.Aout), "s"(p.bias_out), "s"(p.xin), "s"(p.xout), "s"(p.skip), "s"(p.z), "s"(p.x_bstride),
                  "s"(p.Ts), "s"(p.cp), "s"(p.cp_bstride), "s"(p.film), "s"(p.film_cstride), "s"(p.film_col0), "s"(p.film_colb),
-                 "s"(p.dil), "s"(p.T), "s"(p.tiles_per_b), "s"(p.first_layer), "s"(p.inv_tiles_per_b),
+                 "s"(p.dil), "s"(p.T), "s"(p.tiles_per_b), "s"(p.first_layer), "s"(p.inv_tiles_per_b), "s"(p.tile0),
                  "s"((int)gridDim.x));                           // (the grid size is an implicit argument: same segment)
 #endif
 }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
     const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
     const int work = xcd_work();
     const int rest0 = work / MT, mtile = work - rest0 * MT;
-    const int rest = RAG ? p.cgmap[rest0] : rest0;
+    const int rest = RAG ? p.cgmap[rest0] : rest0 + p.tile0;
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int Tb = (RAG && p.lens) ? p.lens[b] : p.T;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
     const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
     const int work = xcd_work();
     const int rest0 = work / MT, mtile = work - rest0 * MT;
-    const int rest = RAG ? p.cgmap[rest0] : rest0;
+    const int rest = RAG ? p.cgmap[rest0] : rest0 + p.tile0;
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int Tb = (RAG && p.lens) ? p.lens[b] : p.T;
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
     const int work = xcd_work();
     const int rest0 = work / MT, mtile = work - rest0 * MT;
-    const int rest = RAG ? p.cgmap[rest0] : rest0;
+    const int rest = RAG ? p.cgmap[rest0] : rest0 + p.tile0;
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int Ts = p.Ts;
@@ -771,17 +771,8 @@ int wn_rs_out_lds_bytes(int bn) { return (256 * 48 + 2 * 64 * (bn + 4)) * 4; }
 // round of workgroups (api.hip)
 bool wn_rowsplit_supported(int C, int dil, long Ts) { return C == 256 && dil >= 1 && dil <= 16 && Ts < (1L << 22); }
 
-template <typename K>
-static hipError_t rs_go(K kern, const WnLayerP& p, int nwg, int ldsb, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    if (e0 && e1)
-        hipExtLaunchKernelGGL(kern, dim3(nwg), dim3(512), ldsb, st, e0, e1, 0, p);
-    else
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), ldsb, st, p);
-    return hipGetLastError();
-}
-
 template <int SW, int RAG>
-static hipError_t rs_launch_conv(const WnLayerP& p, int nwg, int bn, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+static hipError_t rs_launch_conv(const WnLayerP& p, int nwg, int bn, hipStream_t st) {
     constexpr int HL = SW == 48 ? 8 : 16;
     static bool attr_done = false;
     if (!attr_done) {
@@ -794,15 +785,18 @@ static hipError_t rs_launch_conv(const WnLayerP& p, int nwg, int bn, hipStream_t
     if (nwg == 0) return hipSuccess;
     if (bn == 48) {
         if (RAG) return hipErrorInvalidValue;
-        return rs_go(wn_conv_rq_kernel<3, 80, HL, 0>, p, nwg, wn_rs_conv_lds_bytes(80, 48, true), st, e0, e1);
+        return launch_timed(wn_conv_rq_kernel<3, 80, HL, 0>, dim3(nwg), dim3(512), wn_rs_conv_lds_bytes(80, 48, true), st, p,
+                            "wn_conv_rq_kernel<3, 80, %d, 0>", HL);
     }
     // The K-quarter layout needs 86 KiB of LDS (SW 48), one workgroup per CU; the K-half layout 67 KiB, two.  DSD_RS_CONV_Q=0/1
     // forces the choice (A/B, tests).
-    const char* q_ev = getenv("DSD_RS_CONV_Q");                  // read per call: tests/test_gpu_rowsplit.py switches it between handles
-    const bool quarters = q_ev ? atoi(q_ev) != 0 : nwg <= 256;
+    const int q_ev = path_opts().rs_conv_q;                      // (tests/test_gpu_rowsplit.py switches it between handles)
+    const bool quarters = q_ev >= 0 ? q_ev != 0 : nwg <= 256;
     const int ldsb = wn_rs_conv_lds_bytes(SW, 32, quarters);
-    if (quarters) return rs_go(wn_conv_rq_kernel<2, SW, HL, RAG>, p, nwg, ldsb, st, e0, e1);
-    return rs_go(wn_conv_rs_kernel<SW, RAG>, p, nwg, ldsb, st, e0, e1);
+    if (quarters)
+        return launch_timed(wn_conv_rq_kernel<2, SW, HL, RAG>, dim3(nwg), dim3(512), ldsb, st, p, "wn_conv_rq_kernel<2, %d, %d, %d>",
+                            SW, HL, RAG);
+    return launch_timed(wn_conv_rs_kernel<SW, RAG>, dim3(nwg), dim3(512), ldsb, st, p, "wn_conv_rs_kernel<%d, %d>", SW, RAG);
 }
 
 template <int RAG>
@@ -817,26 +811,24 @@ static hipError_t rs_launch_out(const WnLayerP& p, int nwg, int bn, hipStream_t 
     if (nwg == 0) return hipSuccess;
     if (bn == 48) {
         if (RAG) return hipErrorInvalidValue;
-        return rs_go(wn_out_rs_kernel<3, 0>, p, nwg, wn_rs_out_lds_bytes(48), st, nullptr, nullptr);
+        return launch_timed(wn_out_rs_kernel<3, 0>, dim3(nwg), dim3(512), wn_rs_out_lds_bytes(48), st, p, "wn_out_rs_kernel<3, 0>");
     }
-    return rs_go(wn_out_rs_kernel<2, RAG>, p, nwg, wn_rs_out_lds_bytes(32), st, nullptr, nullptr);
-}
-
-static thread_local hipEvent_t g_rs_ev0 = nullptr, g_rs_ev1 = nullptr;
-void wn_rowsplit_set_timing_events(hipEvent_t start, hipEvent_t stop) {
-    g_rs_ev0 = start;
-    g_rs_ev1 = stop;
+    return launch_timed(wn_out_rs_kernel<2, RAG>, dim3(nwg), dim3(512), wn_rs_out_lds_bytes(32), st, p, "wn_out_rs_kernel<2, %d>", RAG);
 }
 
 // which = 0: conv + FiLM + gate (p.xin -> p.z);  which = 1: out-proj + residual / skip (p.z, p.xin -> p.xout, p.skip);
 // bn = frames per tile (32, or 48 on dense batches): p.tiles_per_b counts tiles of that width
 hipError_t launch_wn_rowsplit(const WnLayerP& p, int which, int C_, int batch, int bn, hipStream_t st) {
     if (C_ != 256 || (bn != 32 && bn != 48)) return hipErrorInvalidValue;
-    const int nwg = (p.cgmap ? p.ncg : batch * p.tiles_per_b) * 8;
+    // every store of a tile stays inside its row: the last tile of an item reaches column tiles_per_b * bn (48-frame tiles: up to
+    // 47 past T), and rows are Ts = padded_ts(T) floats apart - holds for every T with the present padded_ts, checked here so that
+    // a change of the padding rule cannot make x / skip / z spill into the next row
+    if ((long)p.tiles_per_b * bn > p.Ts) return hipErrorInvalidValue;
+    const int nt = p.cgmap ? p.ncg : (p.ntiles > 0 ? p.ntiles : batch * p.tiles_per_b);
+    const int nwg = nt * 8;
     if (which == 1) return p.cgmap ? rs_launch_out<1>(p, nwg, bn, st) : rs_launch_out<0>(p, nwg, bn, st);
-    if (p.dil <= 8)
-        return p.cgmap ? rs_launch_conv<48, 1>(p, nwg, bn, st, g_rs_ev0, g_rs_ev1) : rs_launch_conv<48, 0>(p, nwg, bn, st, g_rs_ev0, g_rs_ev1);
-    return p.cgmap ? rs_launch_conv<80, 1>(p, nwg, bn, st, g_rs_ev0, g_rs_ev1) : rs_launch_conv<80, 0>(p, nwg, bn, st, g_rs_ev0, g_rs_ev1);
+    if (p.dil <= 8) return p.cgmap ? rs_launch_conv<48, 1>(p, nwg, bn, st) : rs_launch_conv<48, 0>(p, nwg, bn, st);
+    return p.cgmap ? rs_launch_conv<80, 1>(p, nwg, bn, st) : rs_launch_conv<80, 0>(p, nwg, bn, st);
 }
 
 hipError_t wn_rowsplit_init_all() {

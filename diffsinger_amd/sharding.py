@@ -94,6 +94,7 @@ class Exchange:
         self.recv = torch.empty((self.n_max, t_len, hidden), device=self.stage, dtype=torch.float32)
         self.send = torch.zeros((self.n_max, t_len, out_dims), device=self.stage, dtype=torch.float32)
         self.pieces = self.bufs = self.out_all = None
+        self.scatters = 0
         if self.rank == src:
             self.out_all = torch.zeros((self.world * self.n_max, t_len, out_dims), device=self.stage, dtype=torch.float32)
             self.bufs = list(self.out_all.view(self.world, self.n_max, t_len, out_dims).unbind(0))
@@ -108,13 +109,26 @@ class Exchange:
                 self._inv[torch.as_tensor(flat, dtype=torch.long, device=self.stage)] = self._flat
 
     def scatter(self, cond_all: Optional[torch.Tensor]) -> torch.Tensor:
-        """Rank `src` holds cond_all [n_utt, T, H]; every rank returns its shard [n_local, T, H] (a view of the
-        preallocated receive buffer: consumed before the next scatter)."""
+        """Rank `src` holds cond_all [n_utt, T, H]; every rank returns its shard [n_local, T, H] - a VIEW of the
+        preallocated receive buffer: consume it before the next scatter.  The collective writes the buffer behind
+        autograd's back (`dist.scatter` leaves `Tensor._version` alone), so the version counter is bumped here: consumers
+        that cache on (data_ptr, _version) - `_NativeBackbone.prepare_cond` keys its conditioner hoist that way - see every
+        scatter as the new tensor it is."""
         if self.rank == self.src:
-            if self.direct:
+            direct = (self.direct and cond_all.device == self.stage and cond_all.dtype == torch.float32
+                      and cond_all.is_contiguous())
+            if direct:
                 pieces = list(cond_all.view(self.world, self.n_max, self.t_len, self.hidden).unbind(0))
+            elif self.direct:       # equal contiguous shards, but the caller's tensor is elsewhere / strided / not fp32
+                if self.pieces is None:
+                    pool = torch.zeros((self.world, self.n_max, self.t_len, self.hidden), device=self.stage,
+                                       dtype=torch.float32)
+                    self.pieces = list(pool.unbind(0))
+                for r, p in enumerate(self.pieces):
+                    p.copy_(cond_all[r * self.n_max:(r + 1) * self.n_max])
+                pieces = self.pieces
             else:
-                src_t = cond_all.to(self.stage) if cond_all.device != self.stage else cond_all
+                src_t = cond_all.to(device=self.stage, dtype=torch.float32)
                 for p, idx in zip(self.pieces, self._idx):
                     if idx.numel():
                         torch.index_select(src_t, 0, idx, out=p[:idx.numel()])
@@ -122,14 +136,22 @@ class Exchange:
             dist.scatter(self.recv, pieces, src=self.src)
         else:
             dist.scatter(self.recv, None, src=self.src)
+        torch.autograd.graph.increment_version(self.recv)
+        self.scatters += 1
         out = self.recv[:len(self.mine)]
         return out if self.stage == self.device else out.to(self.device)
 
     def gather(self, mel_local: torch.Tensor) -> Optional[torch.Tensor]:
-        """Inverse of `scatter` for the result [n_local, T, M]; rank `src` gets [n_utt, T, M] in utterance order."""
+        """Inverse of `scatter` for the result [n_local, T, M]; rank `src` gets [n_utt, T, M] in utterance order - with
+        equal contiguous shards a VIEW of the preallocated result buffer, which the next gather overwrites: copy what
+        must outlive it (the one-off `gather_mels` does)."""
+        if tuple(mel_local.shape[1:]) != tuple(self.send.shape[1:]) or mel_local.dtype != self.send.dtype:
+            raise ValueError(f"Exchange.gather: got {tuple(mel_local.shape)} {mel_local.dtype}, the exchange was built for "
+                             f"[n, {self.t_len}, {self.out_dims}] float32 (results of another shape: gather_mels)")
         self.send[:mel_local.shape[0]].copy_(mel_local)
         if self.rank == self.src:
             dist.gather(self.send, self.bufs, dst=self.src)
+            torch.autograd.graph.increment_version(self.out_all)
             if self.direct:
                 return self.out_all[:self.n_utt]
             res = self.out_all.view(-1, self.t_len, self.out_dims).index_select(0, self._inv)
@@ -146,10 +168,21 @@ def scatter_condition(cond_all: Optional[torch.Tensor], n_utt: int, t_len: int, 
 
 
 def gather_mels(mel_local: torch.Tensor, n_utt: int, dst: int = 0) -> Optional[torch.Tensor]:
-    """One-off form of Exchange.gather over contiguous shards."""
-    ex = Exchange(shard_ranges(n_utt, dist.get_world_size()), mel_local.shape[1], 1, mel_local.shape[2],
-                  mel_local.device, dst)
-    return ex.gather(mel_local)
+    """One-off gather over contiguous shards of results of ANY trailing shape and dtype ([n, T, M], multi-feature
+    [n, F, T, M], ...): rank `dst` gets a fresh [n_utt, ...] tensor in utterance order."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    shards = shard_ranges(n_utt, world)
+    n_max = max(len(s) for s in shards)
+    stage = _staging(mel_local.device)
+    send = torch.zeros((n_max,) + tuple(mel_local.shape[1:]), device=stage, dtype=mel_local.dtype)
+    send[:mel_local.shape[0]].copy_(mel_local)
+    if rank != dst:
+        dist.gather(send, None, dst=dst)
+        return None
+    bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.gather(send, bufs, dst=dst)
+    res = torch.cat([b[:len(s)] for b, s in zip(bufs, shards)], 0)
+    return res if stage == mel_local.device else res.to(mel_local.device)
 
 
 def sharded_sample(sample_fn: Callable[..., torch.Tensor], cond_all, n_utt: int, t_len: int,

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSD_API_VERSION 9
+#define DSD_API_VERSION 10
 
 /* error codes */
 #define DSD_OK 0
@@ -413,6 +413,13 @@ typedef struct dsd_stats {
     int64_t bytes_per_frame_nfe; /* algorithmic HBM bytes per mel frame per NFE         */
     int32_t kernels_per_nfe;     /* kernel launches per backbone evaluation             */
     int32_t graphs_cached;
+    /* WaveNet, how a residual layer runs on the current batch shape (API v10): launches per layer (1 = the fused layer
+       kernel over every tile, 2 = the row-split pair or the two GEMMs, 3 = a mixed plan: the whole rounds of tiles on the
+       fused kernel, the remainder on the row-split pair) and how many 32-frame tiles each form covers */
+    int32_t layer_launches;
+    int32_t fused_tiles;
+    int32_t split_tiles;
+    int32_t reserved_;
 } dsd_stats;
 int dsd_get_stats(const dsd_handle* h, dsd_stats* out);
 
@@ -426,6 +433,27 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out);
  */
 int dsd_kernel_timing(dsd_handle* h, int32_t enable);
 int dsd_kernel_timing_read(dsd_handle* h, double* mean_ms, double* empty_pair_ms, int64_t* launches);
+
+/*
+ * The same pass per kernel CLASS (API v10): the layer kernels of an evaluation are several instantiations (tile halo by
+ * dilation, the segments of a mixed plan, the two networks of the variance model each on its own handle), and the roofline
+ * report weights them by time.  Classes are returned largest share first; reading does not reset (dsd_kernel_timing does).
+ *   name              kernel + template arguments as rocprofv3 prints them, e.g. "wn_layer_kernel<4, 48, 0>"
+ *   mean_ms           mean begin -> end time of the launches that carried events (every 7th of the class)
+ *   launches          all launches of the class over the pass, evaluations the backbone evaluations of the pass
+ *   flops_per_launch  algorithmic FLOPs of one launch over its VALID frames, bytes_per_launch likewise (8(d))
+ */
+typedef struct dsd_kernel_time {
+    char name[96];
+    double mean_ms;
+    int64_t launches_timed;
+    int64_t launches;
+    int64_t evaluations;
+    double flops_per_launch;
+    double bytes_per_launch;
+} dsd_kernel_time;
+int dsd_kernel_timing_classes(dsd_handle* h, dsd_kernel_time* out, int32_t max_classes, int32_t* n_classes,
+                              double* empty_pair_ms);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert _lib.lib().dsd_api_version() == 9
+    assert _lib.lib().dsd_api_version() == 10
 
 
 def test_struct_sizes_match_header():

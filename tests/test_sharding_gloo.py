@@ -176,14 +176,32 @@ def _worker_exchange(rank, world, port, q):
         ok = True
         for shards in ([list(r) for r in sharding.shard_ranges(6, world)], sharding.shard_longest_first([9, 3, 12, 5, 7, 2], world)):
             ex = sharding.Exchange(shards, T, H, M, torch.device("cpu"))
+            keys = []
             for step in range(3):           # the same buffers serve every step
                 g = torch.Generator().manual_seed(100 + step)
                 cond_all = torch.randn(6, T, H, generator=g)
                 c = ex.scatter(cond_all if rank == 0 else None)
                 ok = ok and torch.equal(c, cond_all[shards[rank]])
+                # the hoist cache of _NativeBackbone.prepare_cond (backbones.py) keys on exactly this tuple: the reused
+                # receive buffer must read as a NEW tensor after every scatter (dist.scatter leaves _version alone)
+                keys.append((c.data_ptr(), c._version, tuple(c.shape), tuple(c.stride())))
                 out = ex.gather(c[..., :M] * 2.0)
                 if rank == 0:
                     ok = ok and torch.equal(out, cond_all[..., :M] * 2.0)
+            ok = ok and len(set(keys)) == len(keys) and ex.scatters == 3
+            # a caller tensor that is not what the direct (zero-copy) path needs: strided, or not fp32
+            g = torch.Generator().manual_seed(7)
+            wide = torch.randn(6, T, 2 * H, generator=g)
+            c = ex.scatter(wide[..., ::2] if rank == 0 else None)                    # non-contiguous view
+            ok = ok and torch.equal(c, wide[..., ::2][shards[rank]])
+            c = ex.scatter(wide[..., :H].double() if rank == 0 else None)            # float64
+            ok = ok and torch.equal(c, wide[..., :H][shards[rank]])
+        # the one-off gather takes results of any trailing shape / dtype (multi-feature [n, F, T, M], integer ids)
+        rs = sharding.shard_ranges(5, world)
+        full = torch.arange(5 * 2 * T * M, dtype=torch.float64).reshape(5, 2, T, M)
+        got = sharding.gather_mels(full[rs[rank].start:rs[rank].stop], 5)
+        if rank == 0:
+            ok = ok and got.dtype == torch.float64 and torch.equal(got, full)
         q.put(("ok", bool(ok), rank)) if rank == 0 else None
     finally:
         dist.destroy_process_group()

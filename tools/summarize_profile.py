@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output directories (gpurun_out/, scratch) into the small committed summaries under
 profiles/.  Usage: python tools/summarize_profile.py <tag> <trace_dir> [<fetch_dir> <write_dir> [<mfma_dir>]]
-                   [--traffic <workload/B../T..> <dominant kernel name prefix>] [--bench <dir with bench*.json>]
+                   [--traffic <workload/B../T..> <kernel name filter, or - for every dsd:: kernel with >= 1 % of the time>] [--bench <dir with bench*.json>]
 (`tools/collect_profiles.sh <tag> ...` produces gpurun_out/prof_<tag>/{trace,FETCH_SIZE,WRITE_SIZE,MFMA}.)
 
 FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  On gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e.
@@ -84,25 +84,24 @@ if bench_dir:
             line = [l for l in open(src) if l.startswith("{")][-1]
             open(os.path.join(ROOT, "profiles", f"{tag}_{name}"), "w").write(line)
 if traffic_key:
-    hits = [k for k in summary["kernels"] if traffic_kernel in k]
-    assert len(hits) == 1, hits
-    e = summary["kernels"][hits[0]]
+    # every dsd:: kernel with at least 1 % of the traced time (traffic_kernel: an optional name filter, "-" = none): bench.py
+    # weights them by launches; counters only where the PMC passes saw the kernel
+    hits = [k for k, e in summary["kernels"].items() if "dsd::" in k and e["pct"] >= 1.0 and (traffic_kernel in ("-", "") or traffic_kernel in k)]
+    assert hits, "no kernel matches"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    tj[traffic_key] = {
-        "kernel": hits[0], "traffic_bytes_per_launch": int(round(e["fabric_bytes_per_launch_corrected"])),
-        "fetch_size_kib_raw": e["FETCH_SIZE_mean"], "write_size_kib": e["WRITE_SIZE_mean"],
-        "rocprof_avg_ns": e["avg_ns"], "mfma_busy_frac_profiled": round(e.get("mfma_busy_frac_profiled", 0.0), 4),
-        "source": f"profiles/{tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x2 "
-                  "gfx950 correction; fabric-side counters, Infinity-Cache hits included)"}
+    ent = {"source": f"profiles/{tag}_summary.json (rocprofv3 --kernel-trace --stats averages; --pmc FETCH_SIZE / WRITE_SIZE / MFMA in "
+                     "separate eager passes; FETCH x2 gfx950 correction; fabric-side counters, Infinity-Cache hits included)",
+           "kernels": {}}
+    for k in hits:
+        e = summary["kernels"][k]
+        ent["kernels"][k] = {
+            "rocprof_avg_ns": e["avg_ns"], "calls": e["calls"], "pct": e["pct"],
+            "traffic_bytes_per_launch": int(round(e["fabric_bytes_per_launch_corrected"])) if "fabric_bytes_per_launch_corrected" in e else None,
+            "fetch_size_kib_raw": e.get("FETCH_SIZE_mean"), "write_size_kib": e.get("WRITE_SIZE_mean"),
+            "mfma_busy_frac_profiled": round(e["mfma_busy_frac_profiled"], 4) if "mfma_busy_frac_profiled" in e else None}
     if bench_dir and os.path.exists(os.path.join(bench_dir, "trace_split.txt")):
-        txt = open(os.path.join(bench_dir, "trace_split.txt")).read()
         shutil.copy(os.path.join(bench_dir, "trace_split.txt"), os.path.join(ROOT, "profiles", f"{tag}_trace_split.txt"))
-        import re
-        g = re.search(r"graph replay: mean ([0-9.]+) ns", txt)
-        t = re.search(r"timing pass : mean ([0-9.]+) ns", txt)
-        if g and t:
-            tj[traffic_key]["rocprof_split_ns"] = None
-            tj[traffic_key]["rocprof_split_ns"] = {"graph_replay": float(g.group(1)), "timing_pass": float(t.group(1))}
+    tj[traffic_key] = ent
     json.dump(tj, open(tpath, "w"), indent=1)
-    print(tpath, traffic_key)
+    print(tpath, traffic_key, len(hits), "kernels")
