@@ -35,7 +35,7 @@ using namespace dsd;
 // path switches: read from the environment once per C-ABI entry point (dsd_internal.h, PathOpts)
 // ------------------------------------------------------------------------------------------
 namespace dsd {
-static PathOpts g_path_opts = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 512};
+static PathOpts g_path_opts = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 512};
 const PathOpts& path_opts() { return g_path_opts; }
 void refresh_path_opts() {
     auto geti = [](const char* name, int dflt) {
@@ -49,6 +49,7 @@ void refresh_path_opts() {
     o.rs_bn48 = geti("DSD_RS_BN48", -1);
     o.rs_conv_q = geti("DSD_RS_CONV_Q", -1);
     o.rs_rows = geti("DSD_RS_ROWS", -1);
+    o.rs_rows_out = geti("DSD_RS_ROWS_OUT", -1);
     o.edge = geti("DSD_EDGE", -1);
     o.lynx_resident = geti("DSD_LYNX_RESIDENT", -1);
     o.lynx_pw1p = geti("DSD_LYNX_PW1P", -1);
@@ -1297,6 +1298,7 @@ enum { WN_FUSED = 0, WN_ROWSPLIT = 1 };
 struct WnSeg {
     int kind, bn;       // launch shape, frames per tile
     int t0, nt;         // tiles [t0, t0 + nt) of the (item, frame tile) order at this width (ragged: of the valid-tile list)
+    int rows;           // WN_ROWSPLIT: rows per workgroup - 64 (wn_rowsplit.hip), 128 or 256 (wn_rows.hip)
 };
 
 inline long wn_tiles32(const dsd_handle* h) {
@@ -1306,6 +1308,31 @@ inline long wn_tiles32(const dsd_handle* h) {
     return tiles;
 }
 
+// Cost of the two-launch path over `tiles` 32-frame tiles by rows per workgroup, in fused rounds (one round = 256 tiles on
+// wn_layer.hip, ~67 us at C = 256); RATIOS measured on one box at T = 1000 (profiles/r03_rows_sweep.txt):
+//   64 rows  (wn_rowsplit.hip up to ~110 tiles, the 64-frame-tile GEMM pair of gemm.hip above): 23.6 us at 64 tiles, 32.9 at 96,
+//             46.8 at 125, 63.4 at 157, 64.7 at 188
+//   128 rows (wn_rows.hip, 4 workgroups per tile, two resident per CU): 22.9 us per started round of 64 tiles + ~18.3 per further
+//   256 rows (2 workgroups per tile, one per CU): 39.6 us per started round of 128 tiles (5.7 + 33.9 r)
+//             as the remainder segment of a mixed plan (always wn_rowsplit.hip): 15.2 us at 32 tiles, 23.9 at 64, 33.7 at 96,
+//             42.4 at 128, 51.8 at 160 (profiles/r03_plan_sweep.txt)
+inline double wn_split_cost(long tiles, int rows, bool segment) {
+    if (rows == 128) return 0.069 + 0.273 * (double)((tiles + 63) / 64);
+    if (rows == 256) return 0.085 + 0.506 * (double)((tiles + 127) / 128);
+    if (segment) return 0.085 + (double)tiles / 232.0;
+    // (above ~110 tiles: the GEMM pair's 64-frame tiles fill the chip two utterances of ~1000 frames at a time)
+    return tiles <= 110 ? 0.067 + (double)tiles / 223.0 : 0.04 + 0.30 * (double)((tiles + 63) / 64);
+}
+// ... and the rows per workgroup that minimise it.  DSD_RS_ROWS forces.
+inline int wn_rows_for(long tiles, bool segment) {
+    const int force = path_opts().rs_rows;
+    if (force == 64 || force == 128 || force == 256) return force;
+    int best = 64;
+    for (int rows : {128, 256})
+        if (wn_split_cost(tiles, rows, segment) < wn_split_cost(tiles, best, segment)) best = rows;
+    return best;
+}
+
 bool wn_plan_for(const dsd_handle* h, std::vector<WnSeg>& segs) {
     segs.clear();
     if (!is_wavenet(h)) return false;
@@ -1313,37 +1340,47 @@ bool wn_plan_for(const dsd_handle* h, std::vector<WnSeg>& segs) {
     const int max_dil = 1 << (std::min(h->cfg.dilation_cycle_length, L_of(h)) - 1);
     if (h->cfg.dilation_cycle_length < 1 || !wn_layer_supported(C, max_dil)) return false;
     const PathOpts& o = path_opts();
-    if (o.fused_layer == 0) return false;
     const long tiles = wn_tiles32(h);
     if (tiles == 0 || tiles >= (1L << 22)) return false;
+    const bool rs_ok = o.rowsplit != 0 && wn_rowsplit_supported(C, max_dil, h->Ts) && wn_rows_supported(C, max_dil, h->Ts);
     if (o.fused_layer == 1) {                      // forced: every tile through the fused kernel, whatever the grid
-        segs.push_back({WN_FUSED, 32, 0, (int)tiles});
+        segs.push_back({WN_FUSED, 32, 0, (int)tiles, 0});
         return true;
     }
-    if (o.wn_plan == 2 && o.rowsplit != 0 && wn_rowsplit_supported(C, max_dil, h->Ts)) {
-        // test hook: a mixed plan at any size - the first half of the tiles fused, the rest on the row-split pair
+    if (o.wn_plan == 2 && rs_ok && o.fused_layer != 0) {
+        // test hook: a mixed plan at any size - the first half of the tiles fused, the rest on the two-launch path
         const int nfh = (int)(tiles / 2);
-        if (nfh > 0) segs.push_back({WN_FUSED, 32, 0, nfh});
-        segs.push_back({WN_ROWSPLIT, 32, nfh, (int)tiles - nfh});
+        if (nfh > 0) segs.push_back({WN_FUSED, 32, 0, nfh, 0});
+        segs.push_back({WN_ROWSPLIT, 32, nfh, (int)tiles - nfh, wn_rows_for(tiles - nfh, true)});
         return true;
     }
+    const bool rows_forced = rs_ok && (o.rs_rows == 128 || o.rs_rows == 256);
+    if (rows_forced && o.fused_layer == 0) {       // forced: the whole layer on wide row tiles
+        segs.push_back({WN_ROWSPLIT, 32, 0, (int)tiles, o.rs_rows});
+        return true;
+    }
+    if (o.fused_layer == 0) return false;
+    const bool plans = rs_ok && o.wn_plan != 0;     // DSD_WN_PLAN=0: one launch shape per layer, no wide row tiles (round 2's rule)
     const long rounds = (tiles + 255) / 256, nf = tiles / 256 * 256, rem = tiles - nf;
-    const double fused_all = (double)rounds;
-    const double split_all = 0.194 + (double)tiles / 244.0;          // the GEMM pair / row-split pair over everything
-    const bool rs_ok = o.rowsplit != 0 && o.wn_plan != 0 && wn_rowsplit_supported(C, max_dil, h->Ts);
+    const double fused_all = tiles >= 128 ? (double)rounds : 1e30;
+    const int rows_all = plans ? wn_rows_for(tiles, false) : 64;
+    const double split_all = wn_split_cost(tiles, rows_all, false);
     double mixed = 1e30;
-    if (rs_ok && nf > 0 && rem > 0) mixed = (double)(nf / 256) + 0.067 + (double)rem / 223.0;
-    if (tiles < 128) return false;
+    if (plans && nf > 0 && rem > 0) mixed = (double)(nf / 256) + wn_split_cost(rem, wn_rows_for(rem, true), true);
     if (mixed < fused_all && mixed < split_all) {
-        segs.push_back({WN_FUSED, 32, 0, (int)nf});
-        segs.push_back({WN_ROWSPLIT, 32, (int)nf, (int)rem});
+        segs.push_back({WN_FUSED, 32, 0, (int)nf, 0});
+        segs.push_back({WN_ROWSPLIT, 32, (int)nf, (int)rem, wn_rows_for(rem, true)});
         return true;
     }
     if (fused_all < split_all) {
-        segs.push_back({WN_FUSED, 32, 0, (int)tiles});
+        segs.push_back({WN_FUSED, 32, 0, (int)tiles, 0});
         return true;
     }
-    return false;
+    if (rows_all > 64) {
+        segs.push_back({WN_ROWSPLIT, 32, 0, (int)tiles, rows_all});
+        return true;
+    }
+    return false;                                   // 64 rows per workgroup: the per-layer choice in run_backbone
 }
 
 // DSD_EDGE: 0 = never the edge kernel (wn_edge.hip), 1 = on every grid, unset = by grid size.  Read per call: tests/
@@ -1528,12 +1565,14 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                         timed_end();
                         if (le != hipSuccess) return fail(h, DSD_EHIP, "fused WaveNet layer launch failed: %s", hipGetErrorString(le));
                     } else {
+                        const bool wide = sg.rows > 64;
                         timed_begin(200 + vkey, fl_conv * seg_fr[k], 16.0 * C * seg_fr[k]);
-                        le = launch_wn_rowsplit(p, 0, C, B, sg.bn, st);
+                        le = wide ? launch_wn_rows(p, 0, C, B, sg.rows, st) : launch_wn_rowsplit(p, 0, C, B, sg.bn, st);
                         timed_end();
                         if (le == hipSuccess) {
                             timed_begin(300 + vkey, fl_out * seg_fr[k], 20.0 * C * seg_fr[k]);
-                            le = launch_wn_rowsplit(p, 1, C, B, sg.bn, st);
+                            le = wide ? launch_wn_rows(p, 1, C, B, path_opts().rs_rows_out > 64 ? path_opts().rs_rows_out : sg.rows, st)
+                                      : launch_wn_rowsplit(p, 1, C, B, sg.bn, st);
                             timed_end();
                         }
                         if (le != hipSuccess) return fail(h, DSD_EHIP, "row-split WaveNet layer launch failed: %s", hipGetErrorString(le));
@@ -1812,6 +1851,7 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
     hipError_t ie = gemm_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_layer_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_rowsplit_init_all();
+    if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_rows_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_edge_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_LYNXNET) ie = lx_layer_init_all();
     if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: kernel attribute setup failed: %s", hipGetErrorString(ie));

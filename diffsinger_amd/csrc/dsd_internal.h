@@ -47,6 +47,7 @@ struct PathOpts {
     int rs_bn48;            // DSD_RS_BN48         0: no 48-frame tiles of the row-split pair
     int rs_conv_q;          // DSD_RS_CONV_Q       0 / 1: K-half / K-quarter layout of the row-split conv
     int rs_rows;            // DSD_RS_ROWS         64 / 128 / 256: rows per workgroup of the row-split pair
+    int rs_rows_out;        // DSD_RS_ROWS_OUT     128 / 256: ... of its out-proj launch alone (diagnostic: the two launches are independent)
     int edge;               // DSD_EDGE            0: never wn_edge.hip, 1: on every grid
     int lynx_resident;      // DSD_LYNX_RESIDENT   0: never lynx_layer.hip, 1: on every supported grid
     int lynx_pw1p;          // DSD_LYNX_PW1P
@@ -88,6 +89,30 @@ inline hipError_t launch_timed(K kern, dim3 grid, dim3 block, int lds, hipStream
         hipLaunchKernelGGL(kern, grid, block, lds, st, p);
     }
     return hipGetLastError();
+}
+
+// 16-byte raw buffer store followed by two wait states, as ONE inline-asm statement.  A store of more than 8 bytes reads its
+// data registers over several cycles after issue, and a VALU write to one of them in the next issue slot can land first.
+// hipcc (ROCm 7.2) inserts the required wait state for the immediate-soffset form but not when soffset is a register - LLVM's
+// hazard model calls that form safe - and on gfx950 it is not: wn_out_rw_kernel<4, *> stored, nondeterministically and in
+// ~0.4 % of the elements, the NEXT item's operand as the first element of a vector (found with tools/harness/
+// rows_harness.hip; tools/check_store_hazard.py scans the ISA of every kernel file for the pattern, tests/
+// test_kernel_resources.py runs it).  A separate `s_nop` (builtin or asm) behind the builtin store does not stay there -
+// neither scheduling barriers nor a memory clobber kept the post-RA scheduler from moving VALU instructions in between -
+// so the store itself is asm.  `rsrc` = the four descriptor words (dsd_rsrc_words), wave-uniform.
+typedef unsigned dsd_u32x4 __attribute__((ext_vector_type(4)));
+typedef int dsd_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dsd_i32x4 dsd_rsrc_words(const void* ptr) {
+    const unsigned long long a = (unsigned long long)ptr;
+    return dsd_i32x4{(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), (int)0x7FFFFFF0u, 0x00020000};
+}
+template <int AUX>
+__device__ __forceinline__ void dsd_store_b128(dsd_u32x4 data, dsd_i32x4 rsrc, int voff, int soff) {
+    static_assert(AUX == 0 || AUX == 16, "plain or sc1 (write-through)");
+    if (AUX == 16)
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    else
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
 constexpr int kMaxTerms = 8;
@@ -222,6 +247,12 @@ hipError_t wn_layer_init_all();
 hipError_t launch_wn_rowsplit(const WnLayerP& p, int which, int C, int batch, int bn, hipStream_t st);
 hipError_t wn_rowsplit_init_all();
 bool wn_rowsplit_supported(int C, int dil, long Ts);
+
+// wn_rows.hip: the same two launches with 128 or 256 rows per workgroup (4 / 2 workgroups per 32-frame tile), for grids between
+// the one-utterance case and one tile per CU
+hipError_t launch_wn_rows(const WnLayerP& p, int which, int C, int batch, int rows, hipStream_t st);
+hipError_t wn_rows_init_all();
+bool wn_rows_supported(int C, int dil, long Ts);
 
 // wn_edge.hip: the WaveNet's small GEMMs around the residual layers (skip projection -> output projection + solver update ->
 // the next evaluation's input projection) as one launch with one workgroup per frame tile

@@ -46,8 +46,8 @@ __device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, int voff, int sof
 __device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
-__device__ __forceinline__ void st4(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, soff, 0);      // plain: the next kernel re-reads these lines from L2 (write-through measured +0.5 %)
+__device__ __forceinline__ void st4(f32x4 v, dsd_i32x4 r, int voff, int soff) {
+    dsd_store_b128<0>(__builtin_bit_cast(dsd_u32x4, v), r, voff, soff);      // plain: the next kernel re-reads these lines from L2 (write-through measured +0.5 %)
 }
 #ifndef DSD_LX_RCP
 #define DSD_LX_RCP 1
@@ -261,12 +261,12 @@ __global__ __launch_bounds__(256, 1) void lx_pw1_kernel(const LxLayerP p) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
-        const __amdgpu_buffer_rsrc_t r_o = rsrc(p.u + (long)bu * p.u_bstride + (long)ch0 * Ts + t0u);
+        const dsd_i32x4 w_o = dsd_rsrc_words(p.u + (long)bu * p.u_bstride + (long)ch0 * Ts + t0u);
         const int ev0 = ((lane >> 3) * Ts + (lane & 7) * 4) * 4;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int idx = lane + 64 * m;
-            st4(*reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]), r_o, ev0, m * 8 * Ts * 4);
+            st4(*reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]), w_o, ev0, m * 8 * Ts * 4);
         }
     }
 }
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
             }
         }
         // SwiGLU (common_layers.py:116-117: out * silu(gate)) in two halves of 32 channels through the wave's own tile
-        const __amdgpu_buffer_rsrc_t r_o = rsrc(p.u + (long)bu * p.u_bstride + (long)ch0 * Ts + t0u);
+        const dsd_i32x4 w_o = dsd_rsrc_words(p.u + (long)bu * p.u_bstride + (long)ch0 * Ts + t0u);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int idx = lane + 64 * m;
-                st4(*reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]), r_o, ev0, (hf * 32 + m * 8) * Ts * 4);
+                st4(*reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]), w_o, ev0, (hf * 32 + m * 8) * Ts * 4);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                     // the tile is read before the next half overwrites it
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(256, 1) void lx_pw2_kernel(const LxLayerP p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const __amdgpu_buffer_rsrc_t r_xo = rsrc(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
-    const __amdgpu_buffer_rsrc_t r_xi = rsrc((p.xin_out ? p.xin_out : p.x) + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    const dsd_i32x4 w_xo = dsd_rsrc_words(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    const dsd_i32x4 w_xi = dsd_rsrc_words((p.xin_out ? p.xin_out : p.x) + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
     f32x4 xi[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -560,8 +560,8 @@ __global__ __launch_bounds__(256, 1) void lx_pw2_kernel(const LxLayerP p) {
             xo[e] = o;
             xi[m][e] = in;
         }
-        st4(xo, r_xo, ev0, m * 8 * Ts * 4);
-        if (p.xin_out) st4(xi[m], r_xi, ev0, m * 8 * Ts * 4);
+        st4(xo, w_xo, ev0, m * 8 * Ts * 4);
+        if (p.xin_out) st4(xi[m], w_xi, ev0, m * 8 * Ts * 4);
     }
     // LayerNorm partials of xin per 64-row tile (tiles 2w, 2w + 1 of this workgroup's 8): two passes over the registers.
     // A frame's 64 rows sit in 8 slots m of the 8 lanes with equal (lane & 7): sum over m, then over lanes 8, 16, 32 apart.
@@ -735,8 +735,8 @@ __global__ __launch_bounds__(256, 1) void lx_pw2d_kernel(const LxLayerP p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const __amdgpu_buffer_rsrc_t r_xo = rsrc(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
-    const __amdgpu_buffer_rsrc_t r_xi = rsrc((p.xin_out ? p.xin_out : p.x) + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    const dsd_i32x4 w_xo = dsd_rsrc_words(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    const dsd_i32x4 w_xi = dsd_rsrc_words((p.xin_out ? p.xin_out : p.x) + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
     f32x4 xi[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -756,8 +756,8 @@ __global__ __launch_bounds__(256, 1) void lx_pw2d_kernel(const LxLayerP p) {
             xo[e] = o;
             xi[m][e] = in;
         }
-        st4(xo, r_xo, ev0, m * 8 * Ts * 4);
-        if (p.xin_out) st4(xi[m], r_xi, ev0, m * 8 * Ts * 4);
+        st4(xo, w_xo, ev0, m * 8 * Ts * 4);
+        if (p.xin_out) st4(xi[m], w_xi, ev0, m * 8 * Ts * 4);
     }
     // LayerNorm partials of xin per 64-row tile (tiles 2w, 2w + 1 of this workgroup's 8): two passes over the registers.
     // A frame's 64 rows sit in 8 slots m of the 8 lanes with equal (lane & 7): sum over m, then over lanes 8, 16, 32 apart.

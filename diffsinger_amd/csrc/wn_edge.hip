@@ -48,8 +48,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* ptr) {
 __device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-__device__ __forceinline__ void st4(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {      // write-through: dsd_internal.h
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, soff, DSD_ST_AUX);
+__device__ __forceinline__ void st4(f32x4 v, dsd_i32x4 r, int voff, int soff) {      // write-through: dsd_internal.h
+    dsd_store_b128<DSD_ST_AUX>(__builtin_bit_cast(dsd_u32x4, v), r, voff, soff);
 }
 
 // acc[k][n] += W[block k][:, K] * tile[K, column block n]: NS k16 steps, the wave's MB row blocks (1 KiB fragment blocks at
@@ -339,13 +339,13 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
         for (int o = 0; o < kMaxOut; ++o) {
             if (o < nout) {
                 const float* po = pT + (o * K3 + wave * MB2 * 16) * PS;
-                const __amdgpu_buffer_rsrc_t r_d = rsrc(dstv[o] + (long)bu * p.o_bstride + (long)(wave * MB2 * 16) * p.o_rstride + t0u);
+                const dsd_i32x4 w_d = dsd_rsrc_words(dstv[o] + (long)bu * p.o_bstride + (long)(wave * MB2 * 16) * p.o_rstride + t0u);
 #pragma unroll
                 for (int m = 0; m < NE2; ++m) {
                     const int idx = lane + 64 * m;
                     const int row = idx / W4, cc = (idx % W4) * 4;
                     if (wave * MB2 * 16 + row < p.FM)
-                        st4(*reinterpret_cast<const f32x4*>(&po[row * PS + cc]), r_d, (row * p.o_rstride + cc) * 4, 0);
+                        st4(*reinterpret_cast<const f32x4*>(&po[row * PS + cc]), w_d, (row * p.o_rstride + cc) * 4, 0);
                 }
             }
         }
@@ -382,13 +382,13 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const __amdgpu_buffer_rsrc_t r_xo = rsrc(p.xh + (long)bu * p.x_bstride + (long)(wave * MB1 * 16) * Ts + t0u);
+        const dsd_i32x4 w_xo = dsd_rsrc_words(p.xh + (long)bu * p.x_bstride + (long)(wave * MB1 * 16) * Ts + t0u);
         constexpr int NE = MB1 * 16 * W4 / 64;                   // float4 per lane over the wave's rows
 #pragma unroll
         for (int m = 0; m < NE; ++m) {
             const int idx = lane + 64 * m;
             const int row = idx / W4, cc = (idx % W4) * 4;
-            st4(*reinterpret_cast<const f32x4*>(&ew[row * PS + cc]), r_xo, (row * Ts + cc) * 4, 0);
+            st4(*reinterpret_cast<const f32x4*>(&ew[row * PS + cc]), w_xo, (row * Ts + cc) * 4, 0);
         }
     }
     EDGE_STAMP(9);

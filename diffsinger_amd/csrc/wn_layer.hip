@@ -133,7 +133,12 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     // the other chunks travel one float4 per step behind its MFMAs and go to LDS after step 11.
     constexpr int NU0 = W4 / 4;                     // float4 per thread of a 64-channel chunk (idx = tid + 256 u)
     static_assert(64 * W4 == NU0 * 256 && NU - NU0 <= 12, "chunk 0 = the first NU0 staging slots; the rest fit 12 steps");
-    constexpr bool EARLY_LATE = DSD_WN_LATE && NU - NU0 <= 9;    // the late chunks' loads are all issued by step 8
+    // the late chunks' loads are all issued by step 8: one per step, or (the 80-float tile at C = 256: 12 late float4 per
+    // thread) two on steps 1 .. 3 - which the step's schedule below gives a second slot
+    constexpr int NLATE = NU - NU0;
+    constexpr bool EARLY_LATE = DSD_WN_LATE && NLATE <= 12;
+    constexpr int NDBL = NLATE > 9 ? NLATE - 9 : 0;              // steps 1 .. NDBL carry two late loads
+    static_assert(NDBL <= 3, "late loads: at most two on steps 1 .. 3, one on the others up to step 8");
     f32x4 sv[NU];
     auto x_voff = [&](int u) {
         const int idx = tid + 256 * u;
@@ -257,6 +262,20 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     }                                                                                \
     __builtin_amdgcn_sched_barrier(0);
 
+    // a step with TWO extra operand loads (late x chunks of the 80-float tile): one behind each of the first two MFMA groups
+#define WN_SPREAD3()                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
+    _Pragma("unroll") for (int g_ = 1; g_ < MBW; ++g_) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           \
+    }                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+
     // operands fetched during GEMM 1: the hoisted conditioner projection (+ conv bias + its own bias) of this wave's rows
     // as row-major float4 (local row rl = idx >> 3: [0, 8 MBW) gate rows, [8 MBW, 16 MBW) filter rows), and the
     // output-projection bias in the accumulator layout
@@ -276,9 +295,15 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
         else load_w2(W[(s + 2) % 3], s + 2 - NS1);
         // the step's one extra operand load: the rest of the x tile first, then the conditioner projection (filter rows sit
         // C rows below the gate rows), then the out-proj bias
-        if (s < NU - NU0)
+        if (EARLY_LATE && NDBL > 0 && s <= 8) {
+            // late slot index of step s: 0 at step 0, then two per step on steps 1 .. NDBL, one per step after
+            const int first = s == 0 ? 0 : (s <= NDBL ? 2 * s - 1 : s + NDBL);
+            const int cnt = s == 0 ? 1 : (s <= NDBL ? 2 : 1);
+            if (first < NLATE) sv[NU0 + first] = ld4(r_x, x_voff(NU0 + first), 0);
+            if (cnt == 2 && first + 1 < NLATE) sv[NU0 + first + 1] = ld4(r_x, x_voff(NU0 + first + 1), 0);
+        } else if (!(EARLY_LATE && NDBL > 0) && s < NLATE)
             sv[NU0 + s] = ld4(r_x, x_voff(NU0 + s), 0);
-        else if (s >= 12 && s < 12 + NE)
+        else if (s >= 12 && s < 12 + NE)          // (one chain of else-ifs: as separate ifs hipcc no longer folds the register arrays' indices)
             cpv[s - 12] = ld4(r_c, ev0, (((s - 12) % (NE / 2)) * 8 + (s - 12 >= NE / 2 ? C : 0)) * Ts * 4);
         else if (s >= 12 + NE && s < 12 + NE + MBW)
             bo[s - 12 - NE] = ld4(r_b, rq * 4, (s - 12 - NE) * 64);
@@ -286,6 +311,8 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
         mfma_step(W[s % 3], bq[s & 1]);
         if (DSD_WN_RAMP && s == 0) {
             WN_SPREAD2()
+        } else if (EARLY_LATE && NDBL > 0 && s >= 1 && s <= NDBL) {
+            WN_SPREAD3()
         } else {
             WN_SPREAD()
         }
@@ -390,6 +417,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     }
 #undef WN_SPREAD
 #undef WN_SPREAD2
+#undef WN_SPREAD3
     WN_STAMP(5);
 
     // ---------------- epilogue: residual / skip (wavenet.py:45-48) ----------------
@@ -404,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
         const unsigned long long xo = (unsigned long long)p.xout;
-        const __amdgpu_buffer_rsrc_t r_o = rsrc((const float*)(is_res ? xo : sa) + eoff);
+        const dsd_i32x4 w_o = dsd_rsrc_words((const float*)(is_res ? xo : sa) + eoff);
         // (x + o) / sqrt(2) as a multiplication by the fp32 reciprocal, the way torch's CUDA division by a Python scalar
         // evaluates it (the IEEE division sequence is ~10 VALU operations per element: 4 k cycles of this epilogue);
         // the first layer's skip sum is the layer's own output (the buffer holds the previous evaluation's sum)
@@ -417,8 +445,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ((add_pre ? pre[m][e] : 0.f) + a4[e]) * scale;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), r_o, ev0,
-                                                   m * 8 * Ts * 4, DSD_ST_AUX);
+            dsd_store_b128<DSD_ST_AUX>(__builtin_bit_cast(dsd_u32x4, o), w_o, ev0, m * 8 * Ts * 4);
         }
     }
     WN_STAMP(6);

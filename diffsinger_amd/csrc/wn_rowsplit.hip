@@ -47,8 +47,8 @@ __device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, int voff, int sof
 __device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
-__device__ __forceinline__ void st4(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, soff, DSD_ST_AUX);
+__device__ __forceinline__ void st4(f32x4 v, dsd_i32x4 r, int voff, int soff) {
+    dsd_store_b128<DSD_ST_AUX>(__builtin_bit_cast(dsd_u32x4, v), r, voff, soff);
 }
 // The conv's z is read back by the very next launch: kept in L2 (plain).  Same-box A/B of the 50-NFE loop at B = 1, three runs
 // each (tools/ab_store.sh): x / skip write-through + z plain 16.52 ms, both write-through 16.55, x / skip plain + z
@@ -56,8 +56,8 @@ __device__ __forceinline__ void st4(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff,
 #ifndef DSD_ST_AUX_Z
 #define DSD_ST_AUX_Z 0
 #endif
-__device__ __forceinline__ void st4z(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, voff, soff, DSD_ST_AUX_Z);
+__device__ __forceinline__ void st4z(f32x4 v, dsd_i32x4 r, int voff, int soff) {
+    dsd_store_b128<DSD_ST_AUX_Z>(__builtin_bit_cast(dsd_u32x4, v), r, voff, soff);
 }
 
 #ifdef DSD_STAMPS
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rs_kernel(const WnLayerP p) {
         f32x4 z;
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = sigmoid_fast(g[e] + cpg[e]) * tanh_fast(f[e] + cpf[e]);      // wavenet.py:41-42
-        const __amdgpu_buffer_rsrc_t r_z = rsrc(p.z + (long)bu * p.x_bstride + t0u);
-        st4z(z, r_z, row_ts(gch, Ts) + c4 * 16, 0);
+        const dsd_i32x4 w_z = dsd_rsrc_words(p.z + (long)bu * p.x_bstride + t0u);
+        st4z(z, w_z, row_ts(gch, Ts) + c4 * 16, 0);
     }
     RS_STAMP(0, 4);
     RS_STAMP(0, 5);
@@ -599,8 +599,8 @@ __global__ __launch_bounds__(512, 2) void wn_conv_rq_kernel(const WnLayerP p) {
         f32x4 z;
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = sigmoid_fast(g[e] + cpg[e]) * tanh_fast(f[e] + cpf[e]);      // wavenet.py:41-42
-        const __amdgpu_buffer_rsrc_t r_z = rsrc(p.z + (long)bu * p.x_bstride + t0u);
-        st4z(z, r_z, row_ts(gch, Ts) + c4 * 16, 0);
+        const dsd_i32x4 w_z = dsd_rsrc_words(p.z + (long)bu * p.x_bstride + t0u);
+        st4z(z, w_z, row_ts(gch, Ts) + c4 * 16, 0);
     }
     RS_STAMP(0, 4);
     RS_STAMP(0, 5);
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
     }
     __syncthreads();
     if (tid < RP * B4) {
-        const __amdgpu_buffer_rsrc_t r_o = rsrc((const float*)(is_res ? xo : sa) + eoff);
+        const dsd_i32x4 w_o = dsd_rsrc_words((const float*)(is_res ? xo : sa) + eoff);
         const float scale = is_res ? 0.70710678118654752440f : 1.f;     // (x + o) / sqrt(2): times the fp32 reciprocal
         const bool add_pre = is_res || !p.first_layer;                  // the first layer's skip sum is its own output
 #pragma unroll
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void wn_out_rs_kernel(const WnLayerP p) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ((add_pre ? pre[k][e] : 0.f) + a4[e]) * scale;
-            st4(o, r_o, ev0, k * 32 * Ts * 4);
+            st4(o, w_o, ev0, k * 32 * Ts * 4);
         }
     }
     RS_STAMP(1, 4);

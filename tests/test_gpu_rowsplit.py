@@ -87,3 +87,67 @@ def test_rowsplit_conv_layouts_vs_oracle(name):
     else:
         for b, n in enumerate(lengths):
             check(outs["1"][b:b + 1, :, :, :n], outs["0"][b:b + 1, :, :, :n], 2e-6, what=("K quarters vs K halves", name, b))
+
+
+# ---- wide row tiles (wn_rows.hip): 128 / 256 rows per workgroup, forced with DSD_RS_ROWS (+ DSD_FUSED_LAYER=0: the whole layer on them)
+WIDE_CASES = {
+    "acoustic_B2_T1000": (128, dict(num_layers=8, num_channels=256, dilation_cycle_length=4), 2, 1000, None),   # 64 tiles
+    "acoustic_T777": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 1, 777, None),         # last tile cut at 9 frames
+    "acoustic_T13_B3": (128, dict(num_layers=5, num_channels=256, dilation_cycle_length=5), 3, 13, None),        # T < dilation 16
+    "pitch_T900": (64, dict(num_layers=5, num_channels=256, dilation_cycle_length=5), 1, 900, None),             # dilation 16: 80-float stride
+    "ragged_B3": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 3, 640, [640, 333, 70]),   # tile list, per-item ends
+    "pitch_ragged_B2": (64, dict(num_layers=5, num_channels=256, dilation_cycle_length=5), 2, 200, [200, 9]),    # dilation 16, an item of 9 frames
+}
+
+
+@pytest.mark.parametrize("rows", ["128", "256"])
+@pytest.mark.parametrize("name", sorted(WIDE_CASES))
+def test_wide_row_tiles_vs_oracle(name, rows):
+    in_dims, args, bsz, t_len, lengths = WIDE_CASES[name]
+    saved = {k: os.environ.pop(k, None) for k in ("DSD_RS_ROWS", "DSD_FUSED_LAYER", "DSD_WN_PLAN")}
+    os.environ["DSD_RS_ROWS"] = rows
+    os.environ["DSD_FUSED_LAYER"] = "0"
+    try:
+        net, params = make_backbone("wavenet", in_dims, 1, args, 42)
+        x = synth.synth_normal((bsz, 1, in_dims, t_len), 21)
+        cond = synth.synth_normal((bsz, 256, t_len), 22)
+        t = (np.arange(bsz) * 211.5 + 3.25).astype(np.float32)
+        xd = dev(x)
+        if lengths is not None:
+            net.set_lengths(lengths, xd.device)
+        with torch.no_grad():
+            out = net(xd, dev(t), dev(cond))
+            again = net(xd, dev(t), dev(cond))
+        torch.cuda.synchronize()
+        assert torch.equal(out, again)
+        st = net.stats()
+        tiles = sum((n + 31) // 32 for n in lengths) if lengths else bsz * ((t_len + 31) // 32)
+        assert st["layer_launches"] == 2 and st["split_tiles"] == tiles and st["fused_tiles"] == 0, st
+        out = out.cpu().numpy()
+        cyc = args["dilation_cycle_length"]
+        if lengths is None:
+            check(out, ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=cyc), TOL_NFE, what=("wide rows", rows, name))
+        else:
+            for b, n in enumerate(lengths):
+                want_b = ob.wavenet_forward(params, x[b:b + 1, :, :, :n], t[b:b + 1], cond[b:b + 1, :, :n], dilation_cycle_length=cyc)
+                check(out[b:b + 1, :, :, :n], want_b, TOL_NFE, what=("wide rows", rows, name, b))
+        # ... and as the remainder segment of a mixed plan (first half of the tiles on the fused kernel)
+        os.environ.pop("DSD_FUSED_LAYER")
+        os.environ["DSD_WN_PLAN"] = "2"
+        with torch.no_grad():
+            mixed = net(xd, dev(t), dev(cond))
+        torch.cuda.synchronize()
+        st = net.stats()
+        assert st["fused_tiles"] == tiles // 2 and st["split_tiles"] == tiles - tiles // 2, st
+        mixed = mixed.cpu().numpy()
+        if lengths is None:
+            check(mixed, out, 8e-6, what=("wide rows: mixed plan vs whole layer", rows, name))
+        else:
+            for b, n in enumerate(lengths):
+                check(mixed[b:b + 1, :, :, :n], out[b:b + 1, :, :, :n], 8e-6, what=("wide rows: mixed plan vs whole layer", rows, name, b))
+        net.release_native()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
