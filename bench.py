@@ -47,6 +47,11 @@ def parse():
     ap.add_argument("--workload", default="wavenet_dpm50", choices=["wavenet_dpm50", "lynxnet_ddim100", "acoustic_default", "acoustic_e2e", "acoustic_wav", "variance_reflow20"])
     ap.add_argument("--ragged", action="store_true",
                     help="utterance lengths drawn from {512,768,1024,1280,1536} (seed 1234), longest-first shards, ragged batches")
+    ap.add_argument("--ragged-world", type=int, default=8,
+                    help="--ragged: ranks of the partition the shards are taken from (default 8 = BASELINE configs[3]; 0: draw world * B lengths only)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="f32: the reference's arithmetic (every BASELINE number); bf16x3: opt-in split-bf16 layer GEMMs "
+                         "(three bf16 MFMAs per fp32 one, fp32 accumulation; WaveNet C = 256 fused kernel) - a separate workload")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -202,16 +207,36 @@ def main():
         d.denoise_fn.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
         d = d.to(device).eval()
     d.use_graph = not args.no_graph
+    if args.precision != "f32":
+        assert kind == "wavenet" and acoustic is None, "--precision bf16x3 exists for the WaveNet workloads"
+        d.denoise_fn.set_precision(args.precision, device)
+        if variance is not None:
+            variance.velocity_fn.set_precision(args.precision, device)
+        wname += " [precision: split-bf16 layer GEMMs (hi.hi + hi.lo + lo.hi), fp32 accumulation - NOT the BASELINE arithmetic]"
 
     n_utt = world * B
     lengths = None
-    if args.ragged:         # BASELINE configs[3] as specified: T drawn per utterance, seed 1234
+    ragged_note = ""
+    if args.ragged:
+        # BASELINE configs[3] as specified: 64 utterances, T drawn per utterance from {512, ..., 1536} (seed 1234),
+        # partitioned longest-first by 32-frame tiles over 8 ranks.  With fewer ranks than --ragged-world (default 8) rank r
+        # runs shard r of that SAME 8-way partition - per-GPU work stays what it is in the 8-GPU job (weak scaling; --gpus 8 is
+        # the configuration itself).  --ragged-world 0: round 2's stand-in - only world * B lengths are drawn (8 utterances at
+        # N = 1: mean 736 frames, 184 tiles - not a per-GPU share of the 64-utterance job, whose shards hold 232-240 tiles).
         assert args.workload == "wavenet_dpm50", "--ragged is defined for the WaveNet / DPM-Solver++ workload"
         import random
         rnd = random.Random(1234)
-        lengths = [rnd.choice([512, 768, 1024, 1280, 1536]) for _ in range(n_utt)]
+        virt = max(world, args.ragged_world) if args.ragged_world > 0 else world
+        lengths_all = [rnd.choice([512, 768, 1024, 1280, 1536]) for _ in range(virt * B)]
+        vshards = sharding.shard_longest_first(lengths_all, virt)[:world]
+        ids = sorted(i for sh in vshards for i in sh)
+        pos = {g: k for k, g in enumerate(ids)}
+        shards = [[pos[g] for g in sh] for sh in vshards]
+        lengths = [lengths_all[g] for g in ids]
+        n_utt = len(ids)
         T = max(lengths)
-        shards = sharding.shard_longest_first(lengths, world)
+        ragged_note = (f", shard(s) 0..{world - 1} of the longest-first partition of {virt * B} utterances over {virt} ranks "
+                       f"({[sum((lengths_all[g] + 31) // 32 for g in sh) for sh in vshards]} tiles of 32 frames)")
     else:
         shards = [list(r) for r in sharding.shard_ranges(n_utt, world)]
     mine = shards[rank]
@@ -313,8 +338,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(sec_per_step * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wname + (", utterance lengths drawn from {512,768,1024,1280,1536} (seed 1234)" if lengths else ""),
+        "dtype": "f32" if args.precision == "f32" else "bf16x3 (f32 accumulate)", "data": "synthetic",
+        "config": {"workload": wname + (", utterance lengths drawn from {512,768,1024,1280,1536} (seed 1234)" + ragged_note if lengths else ""),
                    "utterances_per_gpu": B, "frames": (round(utt_frames / n_utt, 1) if lengths else T), "nfe": nfe,
                    "hipgraph": bool(d.use_graph),
                    "sharding": f"{world} rank(s) x {B} utterance(s), " + ("longest-first by length, ragged batches, " if lengths else "")

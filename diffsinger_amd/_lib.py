@@ -25,7 +25,7 @@ ACT_IDS = {"PReLU": 0, "SiLU": 1, "ReLU": 2}
 EXPORTS = [
     "dsd_api_version", "dsd_create", "dsd_destroy", "dsd_last_error", "dsd_load_weight",
     "dsd_finalize_weights", "dsd_prepare_cond", "dsd_denoise", "dsd_sample", "dsd_get_stats",
-    "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_kernel_timing_classes", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode", "dsd_vocoder_create", "dsd_vocode",
+    "dsd_kernel_timing", "dsd_kernel_timing_read", "dsd_kernel_timing_classes", "dsd_set_precision", "dsd_aux_decode", "dsd_encoder_create", "dsd_encode", "dsd_vocoder_create", "dsd_vocode",
     "dsd_token_encoder_create", "dsd_token_encode", "dsd_predict_dur", "dsd_cond_assemble", "dsd_set_lengths",
 ]
 POS_ROPE, POS_REL, POS_NONE, POS_SIN = 0, 1, 2, 3       # DSD_POS_*
@@ -105,7 +105,7 @@ class DsdStats(C.Structure):
                 ("flops_per_frame_nfe", C.c_int64), ("bytes_per_frame_nfe", C.c_int64),
                 ("kernels_per_nfe", C.c_int32), ("graphs_cached", C.c_int32),
                 ("layer_launches", C.c_int32), ("fused_tiles", C.c_int32), ("split_tiles", C.c_int32),
-                ("reserved_", C.c_int32)]
+                ("precision", C.c_int32)]
 
 
 class DsdKernelTime(C.Structure):
@@ -154,6 +154,7 @@ def _load():
     lib.dsd_encode.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.POINTER(DsdEncodeExtras), vp, vp]
     lib.dsd_get_stats.argtypes = [vp, C.POINTER(DsdStats)]
     lib.dsd_kernel_timing.argtypes = [vp, i32]
+    lib.dsd_set_precision.argtypes = [vp, i32]
     lib.dsd_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     lib.dsd_kernel_timing_classes.argtypes = [vp, C.POINTER(DsdKernelTime), i32, C.POINTER(i32), C.POINTER(C.c_double)]
     for name in EXPORTS:

@@ -123,6 +123,10 @@ struct dsd_handle {
     size_t blob_floats = 0;
     PackedGemm g_inproj, g_emb0, g_emb1, g_dproj, g_cp, g_tail1, g_out;
     std::vector<PackedGemm> g_conv, g_outp;          // WaveNet per layer
+    // split-bf16 precision mode (wn_layer_x3.hip): 0 = fp32 (default), 1 = bf16x3 where a kernel exists; the layers' weight
+    // streams (float offsets into the blob; empty: not built)
+    int precision = 0;
+    std::vector<size_t> x3_conv, x3_out;
     std::vector<PackedGemm> g_pw1, g_pw2;            // LYNXNet per layer
     std::vector<size_t> dw_w, dw_b, dw_prelu;        // LYNXNet / ConvNeXt depthwise params (float offsets)
     PackedGemm g_ain, g_aout;                        // ConvNeXt aux decoder: dense k-tap in/out convs
@@ -904,6 +908,46 @@ std::vector<std::pair<std::string, std::vector<int64_t>>> expected_for(const dsd
          : is_voc(h) ? expected_params_voc(h->vcfg) : expected_params(h->cfg);
 }
 
+// bf16 (round to nearest even) of an fp32 value, as the 16 upper bits
+inline uint16_t bf16_bits(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);      // inf / nan: truncate
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_value(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float v;
+    memcpy(&v, &u, 4);
+    return v;
+}
+
+// Weight stream of wn_layer_x3.hip for one GEMM of one layer: [wave 4][k32 step][row block 8][hi | lo][lane 64][8 bf16], the
+// order a wave consumes it.  v_mfma_f32_16x16x32_bf16's A operand: lane l holds A[row l & 15][k = 8 (l >> 4) + j], j = 0..7.
+// rows_of(block, m) = the original row of packed block `block` (0..31), row m; col_of(step, kk) = (input channel, tap) of k index
+// kk (0..31) of k32 step `step`.
+size_t pack_x3(dsd_handle* h, int nsteps, const std::function<int(int, int)>& row_of,
+               const std::function<std::pair<int, int>(int, int)>& col_of, const WGet& w) {
+    const size_t nfloats = (size_t)4 * nsteps * 8 * 2 * 64 * 8 / 2;
+    const size_t off = blob_reserve(h, nfloats);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(h->blob_host.data() + off);
+    for (int wave = 0; wave < 4; ++wave)
+        for (int s = 0; s < nsteps; ++s)
+            for (int k = 0; k < 8; ++k) {
+                uint16_t* blk = dst + (((size_t)wave * nsteps + s) * 8 + k) * 2 * 512;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = row_of(8 * wave + k, lane & 15);
+                        const std::pair<int, int> ct = col_of(s, 8 * (lane >> 4) + j);
+                        const float v = (float)w(row, ct.first, ct.second);
+                        const uint16_t hi = bf16_bits(v);
+                        blk[lane * 8 + j] = hi;
+                        blk[512 + lane * 8 + j] = bf16_bits(v - bf16_value(hi));
+                    }
+            }
+    return off;
+}
+
 int build_packed(dsd_handle* h) {
     if (is_aux(h)) return build_packed_aux(h);
     if (is_enc(h)) return build_packed_enc(h);
@@ -986,6 +1030,26 @@ int build_packed(dsd_handle* h) {
             h->g_conv[l] = pack_gemm(h, 2 * C, C, 3, C, w, nullptr);
             auto b = bias_of(p + "output_projection.bias");
             h->g_outp[l] = pack_gemm(h, 2 * C, C, 1, 0, conv1(p + "output_projection.weight"), &b);
+        }
+        // split-bf16 mode: the same two matrices of every layer once more, split hi / lo, as wn_layer_x3.hip's streams
+        h->x3_conv.clear();
+        h->x3_out.clear();
+        const int max_dil = 1 << (std::min(c.dilation_cycle_length, L) - 1);
+        if (h->precision == 1 && c.dilation_cycle_length >= 1 && wn_layer_x3_supported(C, max_dil)) {
+            h->x3_conv.resize(L);
+            h->x3_out.resize(L);
+            for (int l = 0; l < L; ++l) {
+                const std::string p = "residual_layers." + std::to_string(l) + ".";
+                const HostTensor* t = &W(h, p + "dilated_conv.weight");    // [2C, C, 3]
+                WGet w = [t, C](int r, int k, int tap) { return (double)t->data[((size_t)r * C + k) * 3 + tap]; };
+                // conv rows: block 2 q + gf = the gate (gf = 0) / filter (1) rows of channels [16 q, 16 q + 16); k32 step = [tap][chunk]
+                h->x3_conv[l] = pack_x3(h, 3 * C / 32, [C](int blk, int m) { return (blk & 1) * C + (blk >> 1) * 16 + m; },
+                                        [](int s, int kk) { return std::make_pair((s & 7) * 32 + kk, s >> 3); }, w);
+                const HostTensor* to = &W(h, p + "output_projection.weight");    // [2C, C, 1]
+                WGet wo = [to, C](int r, int k, int) { return (double)to->data[(size_t)r * C + k]; };
+                h->x3_out[l] = pack_x3(h, C / 32, [](int blk, int m) { return blk * 16 + m; },
+                                       [](int s, int kk) { return std::make_pair(s * 32 + kk, 0); }, wo);
+            }
         }
         auto b1 = bias_of("skip_projection.bias");
         h->g_tail1 = pack_gemm(h, C, C, 1, 0, conv1("skip_projection.weight"), &b1);
@@ -1294,7 +1358,7 @@ int run_gemm(dsd_handle* h, const GemmCall& c, hipStream_t st) {
 // (profiles/r03_plan_sweep.txt), not absolute times.  DSD_FUSED_LAYER=0/1 forces no / only fused segments, DSD_WN_PLAN=0
 // keeps one launch shape per layer (round 2's rule).  An empty plan = the per-layer choice between the row-split pair
 // and the GEMM pair in run_backbone.
-enum { WN_FUSED = 0, WN_ROWSPLIT = 1 };
+enum { WN_FUSED = 0, WN_ROWSPLIT = 1, WN_FUSED_X3 = 2 };
 struct WnSeg {
     int kind, bn;       // launch shape, frames per tile
     int t0, nt;         // tiles [t0, t0 + nt) of the (item, frame tile) order at this width (ragged: of the valid-tile list)
@@ -1343,14 +1407,19 @@ bool wn_plan_for(const dsd_handle* h, std::vector<WnSeg>& segs) {
     const long tiles = wn_tiles32(h);
     if (tiles == 0 || tiles >= (1L << 22)) return false;
     const bool rs_ok = o.rowsplit != 0 && wn_rowsplit_supported(C, max_dil, h->Ts) && wn_rows_supported(C, max_dil, h->Ts);
+    // split-bf16 mode: the fused segments run wn_layer_x3.hip, whose round takes ~0.55 of an fp32 round (bound by the weight
+    // stream, not the MFMAs); the two-launch kernels have no bf16x3 form, so the remainder of a mixed plan stays fp32
+    const bool x3 = h->precision == 1 && !h->x3_conv.empty();
+    const int fused_kind = x3 ? WN_FUSED_X3 : WN_FUSED;
+    const double round_cost = x3 ? 0.55 : 1.0;
     if (o.fused_layer == 1) {                      // forced: every tile through the fused kernel, whatever the grid
-        segs.push_back({WN_FUSED, 32, 0, (int)tiles, 0});
+        segs.push_back({fused_kind, 32, 0, (int)tiles, 0});
         return true;
     }
     if (o.wn_plan == 2 && rs_ok && o.fused_layer != 0) {
         // test hook: a mixed plan at any size - the first half of the tiles fused, the rest on the two-launch path
         const int nfh = (int)(tiles / 2);
-        if (nfh > 0) segs.push_back({WN_FUSED, 32, 0, nfh, 0});
+        if (nfh > 0) segs.push_back({fused_kind, 32, 0, nfh, 0});
         segs.push_back({WN_ROWSPLIT, 32, nfh, (int)tiles - nfh, wn_rows_for(tiles - nfh, true)});
         return true;
     }
@@ -1362,18 +1431,18 @@ bool wn_plan_for(const dsd_handle* h, std::vector<WnSeg>& segs) {
     if (o.fused_layer == 0) return false;
     const bool plans = rs_ok && o.wn_plan != 0;     // DSD_WN_PLAN=0: one launch shape per layer, no wide row tiles (round 2's rule)
     const long rounds = (tiles + 255) / 256, nf = tiles / 256 * 256, rem = tiles - nf;
-    const double fused_all = tiles >= 128 ? (double)rounds : 1e30;
+    const double fused_all = tiles >= 128 ? round_cost * (double)rounds : 1e30;
     const int rows_all = plans ? wn_rows_for(tiles, false) : 64;
     const double split_all = wn_split_cost(tiles, rows_all, false);
     double mixed = 1e30;
-    if (plans && nf > 0 && rem > 0) mixed = (double)(nf / 256) + wn_split_cost(rem, wn_rows_for(rem, true), true);
+    if (plans && nf > 0 && rem > 0) mixed = round_cost * (double)(nf / 256) + wn_split_cost(rem, wn_rows_for(rem, true), true);
     if (mixed < fused_all && mixed < split_all) {
-        segs.push_back({WN_FUSED, 32, 0, (int)nf, 0});
+        segs.push_back({fused_kind, 32, 0, (int)nf, 0});
         segs.push_back({WN_ROWSPLIT, 32, (int)nf, (int)rem, wn_rows_for(rem, true)});
         return true;
     }
     if (fused_all < split_all) {
-        segs.push_back({WN_FUSED, 32, 0, (int)tiles, 0});
+        segs.push_back({fused_kind, 32, 0, (int)tiles, 0});
         return true;
     }
     if (rows_all > 64) {
@@ -1559,7 +1628,14 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                     if (ragged) { p.lens = h->lens_dev; p.cgmap = h->cg_dev[1] + sg.t0; p.ncg = sg.nt; }
                     const int vkey = (int)k * 4 + (p.dil > 8 ? 2 : 0);
                     hipError_t le;
-                    if (sg.kind == WN_FUSED) {
+                    if (sg.kind == WN_FUSED_X3) {
+                        p.Aconv = h->blob + h->x3_conv[l];
+                        p.Aout = h->blob + h->x3_out[l];
+                        timed_begin(150 + vkey, (fl_conv + fl_out) * seg_fr[k], 24.0 * C * seg_fr[k]);
+                        le = launch_wn_layer_x3(p, C, B, st);
+                        timed_end();
+                        if (le != hipSuccess) return fail(h, DSD_EHIP, "bf16x3 fused WaveNet layer launch failed: %s", hipGetErrorString(le));
+                    } else if (sg.kind == WN_FUSED) {
                         timed_begin(100 + vkey, (fl_conv + fl_out) * seg_fr[k], 24.0 * C * seg_fr[k]);
                         le = launch_wn_layer(p, C, B, st);
                         timed_end();
@@ -1852,11 +1928,14 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_layer_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_rowsplit_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_rows_init_all();
+    if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_layer_x3_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_edge_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_LYNXNET) ie = lx_layer_init_all();
     if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
     dsd_handle* h = new dsd_handle();
     h->cfg = *cfg;
+    refresh_path_opts();
+    h->precision = path_opts().precision == 1 ? 1 : 0;       // DSD_PRECISION=1: split-bf16 layer kernels (dsd_set_precision)
     if (cfg->backbone == DSD_BACKBONE_WAVENET) {      // the kernels run on a multiple of 32 channels (pad_wavenet_weights)
         h->c_user = cfg->num_channels;
         h->cfg.num_channels = (cfg->num_channels + 31) / 32 * 32;
@@ -2730,6 +2809,7 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
         key.append((const char*)&B, sizeof(B));             // batch shape: grids and strides are baked into the launches
         key.append((const char*)&T, sizeof(T));
         key.append((const char*)&path_opts(), sizeof(PathOpts));   // the path switches: a graph is ONE set of launch choices
+        key.append((const char*)&h->precision, sizeof(int));
         key.push_back(h->lens_host.empty() ? 'd' : 'r');       // dense / ragged: other kernels, and grids that follow
         for (int v : h->lens_host) key.append((const char*)&v, sizeof(v));      // the lengths (baked into the launches)
         auto it = h->graphs.find(key);
@@ -2772,6 +2852,21 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
                       (flags & DSD_SAMPLE_TRANSPOSE) ? 1 : 0, (flags & DSD_SAMPLE_TRANSPOSE) ? out_scale : nullptr,
                       (flags & DSD_SAMPLE_TRANSPOSE) ? out_shift : nullptr, st);
     if (e != hipSuccess) return fail(h, DSD_EHIP, "unpack launch failed: %s", hipGetErrorString(e));
+    return DSD_OK;
+}
+
+int dsd_set_precision(dsd_handle* h, int32_t mode) {
+    if (!h) return DSD_EINVAL;
+    if (mode != DSD_PRECISION_F32 && mode != DSD_PRECISION_BF16X3)
+        return fail(h, DSD_EINVAL, "dsd_set_precision: unknown mode %d", mode);
+    if (!is_wavenet(h)) return fail(h, DSD_ESTATE, "dsd_set_precision: only WaveNet denoiser handles have a split-bf16 path");
+    if (mode == h->precision) return DSD_OK;
+    h->precision = mode;
+    if (h->finalized) {                   // the bf16x3 weight streams are built with the packed weights
+        h->finalized = false;
+        destroy_graphs(h);
+        return dsd_finalize_weights(h);
+    }
     return DSD_OK;
 }
 
@@ -2838,8 +2933,9 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
             per_layer = 0;
             out->split_tiles = 0;
             for (const WnSeg& sg : plan) {
-                per_layer += sg.kind == WN_FUSED ? 1 : 2;
-                (sg.kind == WN_FUSED ? out->fused_tiles : out->split_tiles) += sg.nt;
+                per_layer += sg.kind == WN_ROWSPLIT ? 2 : 1;
+                (sg.kind == WN_ROWSPLIT ? out->split_tiles : out->fused_tiles) += sg.nt;
+                if (sg.kind == WN_FUSED_X3) out->precision = DSD_PRECISION_BF16X3;
             }
         }
         out->layer_launches = per_layer;

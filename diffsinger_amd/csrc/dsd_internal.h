@@ -248,6 +248,12 @@ hipError_t launch_wn_rowsplit(const WnLayerP& p, int which, int C, int batch, in
 hipError_t wn_rowsplit_init_all();
 bool wn_rowsplit_supported(int C, int dil, long Ts);
 
+// wn_layer_x3.hip: the fused layer in split-bf16 arithmetic (opt-in precision mode); p.Aconv / p.Aout = the layer's bf16x3
+// weight streams [wave][k32 step][row block][hi | lo][lane][8 bf16]
+hipError_t launch_wn_layer_x3(const WnLayerP& p, int C, int batch, hipStream_t st);
+hipError_t wn_layer_x3_init_all();
+bool wn_layer_x3_supported(int C, int dil);
+
 // wn_rows.hip: the same two launches with 128 or 256 rows per workgroup (4 / 2 workgroups per 32-frame tile), for grids between
 // the one-utterance case and one tile per CU
 hipError_t launch_wn_rows(const WnLayerP& p, int which, int C, int batch, int rows, hipStream_t st);

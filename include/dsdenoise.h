@@ -405,6 +405,21 @@ typedef struct dsd_program {
 int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, const float* noise,
                float* out, const float* out_scale, const float* out_shift, uint32_t flags, void* stream);
 
+/*
+ * Arithmetic of the residual layers' two GEMMs (API v10).  DSD_PRECISION_F32 (default): fp32 operands on
+ * v_mfma_f32_16x16x4_f32 - the reference's arithmetic, what every BASELINE number is measured in.  DSD_PRECISION_BF16X3
+ * (opt-in; SURVEY.md section 7 "hard parts"): every operand split x = hi + lo into two bf16 values, a product evaluated as
+ * hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; activations, FiLM, gate, residual and skip
+ * arithmetic stay fp32.  Measured against the fp32 oracle: 9.9e-6 on one evaluation, 1.9e-6 on the 50-NFE DPM-Solver++
+ * sample (tools/bf16x3_tolerance.py; asserted on the GPU in tests/test_gpu_bf16x3.py at the fp32 tolerances).  Exists for the
+ * fused WaveNet layer kernel at C = 256 (batched grids); other shapes and kernels run fp32 whatever the mode.  Also set for
+ * every handle of the process by the environment variable DSD_PRECISION=1 at dsd_create.  May be called at any time; after
+ * dsd_finalize_weights it re-packs the weights.
+ */
+#define DSD_PRECISION_F32 0
+#define DSD_PRECISION_BF16X3 1
+int dsd_set_precision(dsd_handle* h, int32_t mode);
+
 /* Introspection used by tests, bench.py and the roofline report. */
 typedef struct dsd_stats {
     int64_t weight_bytes;        /* packed weights on the device                        */
@@ -419,7 +434,7 @@ typedef struct dsd_stats {
     int32_t layer_launches;
     int32_t fused_tiles;
     int32_t split_tiles;
-    int32_t reserved_;
+    int32_t precision;           /* DSD_PRECISION_* of the fused segments that ran (dsd_set_precision) */
 } dsd_stats;
 int dsd_get_stats(const dsd_handle* h, dsd_stats* out);
 

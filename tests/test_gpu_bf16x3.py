@@ -1,0 +1,115 @@
+"""The opt-in split-bf16 precision mode of the fused WaveNet layer (wn_layer_x3.hip, dsd_set_precision / DSD_PRECISION=1): every
+operand of the layer's two GEMMs split x = hi + lo into two bf16 values, hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16,
+fp32 accumulation.  Stated tolerance = the fp32 path's own: 2e-5 on one evaluation, 1.5e-5 on a sampler run, both max and
+RMS relative (gpu_util.check) - tools/bf16x3_tolerance.py measures 9.9e-6 / 1.9e-6 for the arithmetic itself on the CPU
+oracle; what the GPU adds is recorded in profiles/r03_parity.json.  Every BASELINE number is measured in fp32; this mode is a
+separate workload of bench.py (--precision bf16x3)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from diffsinger_amd import synth  # noqa: E402
+from gpu_util import check, dev, load_synth, make_backbone, set_hp, synth_params  # noqa: E402
+from oracle import backbones as ob  # noqa: E402
+from oracle import diffusion as od  # noqa: E402
+
+TOL_NFE = 2e-5
+TOL_SAMPLER = 1.5e-5
+SWITCHES = ("DSD_FUSED_LAYER", "DSD_WN_PLAN", "DSD_PRECISION")
+
+
+@pytest.fixture(autouse=True)
+def _clean_env():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    set_hp()
+    saved = {k: os.environ.pop(k, None) for k in SWITCHES}
+    yield
+    for k in SWITCHES:
+        os.environ.pop(k, None)
+        if saved[k] is not None:
+            os.environ[k] = saved[k]
+
+
+NETS = {
+    "c256_cyc4": (128, dict(num_layers=5, num_channels=256, dilation_cycle_length=4)),       # halo 8
+    "c256_cyc5": (64, dict(num_layers=6, num_channels=256, dilation_cycle_length=5)),        # halo 16 in layer 4
+}
+GRIDS = {
+    "dense_T211_B2": (2, 211, None),
+    "dense_T13_B3": (3, 13, None),
+    "ragged_B3": (3, 200, [200, 77, 141]),
+}
+
+
+def _eval(net, x, t, cond, lengths):
+    xd = dev(x)
+    net.set_lengths(lengths, xd.device)
+    with torch.no_grad():
+        out = net(xd, dev(t), dev(cond))
+        again = net(xd, dev(t), dev(cond))
+    torch.cuda.synchronize()
+    assert torch.equal(out, again)
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("grid", sorted(GRIDS))
+@pytest.mark.parametrize("net_name", sorted(NETS))
+def test_bf16x3_fused_layer_vs_oracle(net_name, grid):
+    in_dims, args = NETS[net_name]
+    bsz, t_len, lengths = GRIDS[grid]
+    os.environ["DSD_FUSED_LAYER"] = "1"           # the fused kernel at a size the oracle handles
+    net, params = make_backbone("wavenet", in_dims, 1, args, 42)
+    x = synth.synth_normal((bsz, 1, in_dims, t_len), 21)
+    cond = synth.synth_normal((bsz, 256, t_len), 22)
+    t = (np.arange(bsz) * 173.25 + 7.5).astype(np.float32)
+    f32 = _eval(net, x, t, cond, lengths)
+    assert net.stats()["precision"] == 0
+    net.set_precision("bf16x3")
+    x3 = _eval(net, x, t, cond, lengths)
+    st = net.stats()
+    tiles = sum((n + 31) // 32 for n in lengths) if lengths else bsz * ((t_len + 31) // 32)
+    assert st["precision"] == 1 and st["fused_tiles"] == tiles and st["layer_launches"] == 1, st
+    assert not np.array_equal(x3, f32)            # another arithmetic really ran
+    cyc = args["dilation_cycle_length"]
+    if lengths is None:
+        want = ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=cyc)
+        check(x3, want, TOL_NFE, what=("bf16x3 vs oracle", net_name, grid))
+        check(x3, f32, TOL_NFE, what=("bf16x3 vs fp32 kernels", net_name, grid))
+    else:
+        for b, n in enumerate(lengths):
+            want = ob.wavenet_forward(params, x[b:b + 1, :, :, :n], t[b:b + 1], cond[b:b + 1, :, :n], dilation_cycle_length=cyc)
+            check(x3[b:b + 1, :, :, :n], want, TOL_NFE, what=("bf16x3 vs oracle", net_name, grid, b))
+    net.set_precision("f32")                      # and back: the fp32 weights are the same as before
+    back = _eval(net, x, t, cond, lengths)
+    assert net.stats()["precision"] == 0
+    assert np.array_equal(back, f32)
+    net.release_native()
+
+
+def test_bf16x3_config4_share_vs_oracle():
+    """BASELINE config 4's per-GPU share (8 x 1000 frames, 20 x 256 WaveNet) in split-bf16, DPM-Solver++ shortened to 10 steps so
+    that the oracle finishes in seconds: the fused bf16x3 kernel on its natural grid (256 tiles), hipGraph path."""
+    from diffsinger_amd.diffusion import GaussianDiffusion
+    set_hp(diff_accelerator="dpm-solver", diff_speedup=100, K_step_infer=1000)
+    args = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+    d = GaussianDiffusion(128, 1, timesteps=1000, k_step=1000, backbone_type="wavenet", backbone_args=args,
+                          spec_min=[-12.0], spec_max=[0.0])
+    params = synth_params("wavenet", 128, 1, args, 42)
+    load_synth(d.denoise_fn, params)
+    d = d.cuda().eval()
+    d.denoise_fn.set_precision("bf16x3")
+    bsz, t_len = 8, 1000
+    cond = synth.synth_normal((bsz, t_len, 256), 40)
+    noise = synth.synth_normal((bsz, 1, 128, t_len), 41)
+    out = d(dev(cond), infer=True, noise=dev(noise))
+    st = d.denoise_fn.stats()
+    assert st["precision"] == 1 and st["fused_tiles"] == 256 and st["layer_launches"] == 1, st
+    fn = lambda x, t, c: ob.wavenet_forward(params, x, t, c, dilation_cycle_length=4)   # noqa: E731
+    o = od.GaussianDiffusion(fn, 128, 1, spec_min=[-12.0], spec_max=[0.0])
+    want = o.forward(cond, noise, diff_accelerator="dpm-solver", diff_speedup=100, K_step_infer=1000)
+    check(out, want, TOL_SAMPLER, what="bf16x3, 8 x 1000 frames, 10 NFE")
+    d.denoise_fn.release_native()
