@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # ... v_mfma_f32_*_bf16 dense peak (--precision bf16x3: three bf16 MFMAs per fp32 one)
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 HOP, SR = 512, 44100
 
@@ -347,7 +348,7 @@ def main():
         "rtf": round(sec_per_step / (utt_frames * HOP / SR), 6),
         "ms_per_nfe": round(sec_per_step * 1e3 / nfe, 5),
         "path_tflops": round(stats["flops_per_frame_nfe"] * frames / sec_per_step / 1e12 / world, 3),
-        "path_mfma_frac": round(stats["flops_per_frame_nfe"] * frames / sec_per_step / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),
+        "path_mfma_frac": round(stats["flops_per_frame_nfe"] * frames / sec_per_step / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),      # of the FP32 peak, whatever the precision mode
         "path_hbm_frac": round(stats["bytes_per_frame_nfe"] * frames / sec_per_step / 1e9 / world / PEAK_HBM_GBPS, 5),
     }
     if dist_info is not None:
@@ -383,7 +384,7 @@ def main():
         prof, prof_src = {}, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            ent = tj.get(f"{args.workload}{'_ragged' if lengths else ''}/B{B}/T{T}")
+            ent = tj.get(f"{args.workload}{'_ragged' if lengths else ''}{'_' + args.precision if args.precision != 'f32' else ''}/B{B}/T{T}")
             if ent:
                 prof_src = ent.get("source")
                 prof = ent["kernels"] if "kernels" in ent else {ent["kernel"]: ent}
@@ -394,6 +395,15 @@ def main():
             hits = [v for k, v in prof.items() if ("dsd::" + name + "(") in k]
             return hits[0] if len(hits) == 1 else None
 
+        # split-bf16 kernels execute THREE bf16 MFMA FLOPs per algorithmic fp32 FLOP and are priced against the bf16 peak
+        x3 = args.precision == "bf16x3"
+
+        def peak_of(name):
+            return PEAK_BF16_MFMA_TFLOPS if "x3" in name else PEAK_FP32_MFMA_TFLOPS
+
+        def mult_of(name):
+            return 3.0 if "x3" in name else 1.0
+
         tot_fl = tot_by = tot_ev = tot_rp = tot_tr = 0.0
         n_launch, all_rp, all_tr = 0, bool(classes), bool(classes)
         for c in classes:
@@ -402,8 +412,8 @@ def main():
             c["rocprof_avg_launch_us"] = round(r["rocprof_avg_ns"] / 1e3, 3) if r else None
             c["traffic"] = r.get("traffic_bytes_per_launch") if r else None
             c["mfma_busy_frac_profiled"] = r.get("mfma_busy_frac_profiled") if r else None
-            c["frac_events"] = round(c["flops_per_launch"] / (c["avg_launch_us"] * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
-            c["frac"] = (round(c["flops_per_launch"] / (r["rocprof_avg_ns"] * 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if r else None)
+            c["frac_events"] = round(mult_of(c["kernel"]) * c["flops_per_launch"] / (c["avg_launch_us"] * 1e-6) / 1e12 / peak_of(c["kernel"]), 4)
+            c["frac"] = (round(mult_of(c["kernel"]) * c["flops_per_launch"] / (r["rocprof_avg_ns"] * 1e-9) / 1e12 / peak_of(c["kernel"]), 4) if r else None)
             c["avg_launch_us"] = round(c["avg_launch_us"], 3)
             tot_fl += w * c["flops_per_launch"]
             tot_by += w * c["bytes_per_launch"]
@@ -423,12 +433,16 @@ def main():
         sec = tot_rp if all_rp else tot_ev
         ach = tot_fl / sec / 1e12 if sec > 0 else 0.0
         ach_ev = tot_fl / tot_ev / 1e12 if tot_ev > 0 else 0.0
+        peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
+        if x3:      # executed bf16 FLOPs of the split-bf16 kernels (3 per algorithmic FLOP); the fp32 kernels of the set as they are
+            fl3 = sum(c["launches_per_step"] * c["flops_per_launch"] * mult_of(c["kernel"]) for c in classes)
+            ach, ach_ev = fl3 / sec / 1e12 if sec > 0 else 0.0, fl3 / tot_ev / 1e12 if tot_ev > 0 else 0.0
         result["roofline"] = {
-            "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4),
             "frac_source": ("rocprofv3 --kernel-trace --stats averages of the committed profile: " + str(prof_src)) if all_rp
                            else "hip events on the dispatches of this run (no committed rocprofv3 trace of this configuration)",
-            "frac_events": round(ach_ev / PEAK_FP32_MFMA_TFLOPS, 4),
+            "frac_events": round(ach_ev / peak, 4),
             "traffic": int(round(tot_tr / max(n_launch, 1))) if all_tr else None,
             "traffic_source": prof_src if all_tr else None,
             "scope": "time-weighted over the layer kernels of one step (all launches of `kernels`); per-launch means",
@@ -441,8 +455,12 @@ def main():
             "hbm_achieved_GBps": round(tot_by / sec / 1e9, 1) if sec > 0 else 0.0,
             "hbm_frac": round(tot_by / sec / 1e9 / PEAK_HBM_GBPS, 5) if sec > 0 else 0.0,
             "timing_pass_ms": round(t_pass, 2), "empty_event_pair_us": round(empty_us, 3),
-            "plan": {k: stats[k] for k in ("kernels_per_nfe", "layer_launches", "fused_tiles", "split_tiles")},
+            "plan": {k: stats[k] for k in ("kernels_per_nfe", "layer_launches", "fused_tiles", "split_tiles", "precision")},
             "kernels": classes}
+        if x3:
+            result["roofline"]["note"] = ("split-bf16 mode: `achieved` counts the executed bf16 MFMA FLOPs (3 per algorithmic fp32 FLOP) against "
+                                          "the bf16 peak; the kernel is bound by its weight stream from L2 (2 MB per 32-frame tile, hi + lo = 4 "
+                                          "bytes per weight, at the ~70 GB/s a CU takes from L2), not by the MFMA pipe - DESIGN.md 4.7")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(kind, params, bargs, B, T, bins=64 if variance is not None else 128)
     if rank == 0:

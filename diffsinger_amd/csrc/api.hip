@@ -127,6 +127,7 @@ struct dsd_handle {
     // streams (float offsets into the blob; empty: not built)
     int precision = 0;
     std::vector<size_t> x3_conv, x3_out;
+    int cus = 256;                  // compute units of the device (hipDeviceProp_t::multiProcessorCount): one fused round = `cus` tiles
     std::vector<PackedGemm> g_pw1, g_pw2;            // LYNXNet per layer
     std::vector<size_t> dw_w, dw_b, dw_prelu;        // LYNXNet / ConvNeXt depthwise params (float offsets)
     PackedGemm g_ain, g_aout;                        // ConvNeXt aux decoder: dense k-tap in/out convs
@@ -1430,15 +1431,19 @@ bool wn_plan_for(const dsd_handle* h, std::vector<WnSeg>& segs) {
     }
     if (o.fused_layer == 0) return false;
     const bool plans = rs_ok && o.wn_plan != 0;     // DSD_WN_PLAN=0: one launch shape per layer, no wide row tiles (round 2's rule)
-    const long rounds = (tiles + 255) / 256, nf = tiles / 256 * 256, rem = tiles - nf;
-    const double fused_all = tiles >= 128 ? round_cost * (double)rounds : 1e30;
-    const int rows_all = plans ? wn_rows_for(tiles, false) : 64;
-    const double split_all = wn_split_cost(tiles, rows_all, false);
+    // one fused round = one tile per CU; the two-launch costs were measured on 256 CUs, so their tile counts are taken in
+    // 256ths of the chip (`eq`): a part with fewer CUs sees proportionally "more" tiles
+    const long cus = h->cus;
+    const long rounds = (tiles + cus - 1) / cus, nf = tiles / cus * cus, rem = tiles - nf;
+    auto eq = [cus](long t) { return (t * 256 + cus - 1) / cus; };
+    const double fused_all = 2 * tiles >= cus ? round_cost * (double)rounds : 1e30;
+    const int rows_all = plans ? wn_rows_for(eq(tiles), false) : 64;
+    const double split_all = wn_split_cost(eq(tiles), rows_all, false);
     double mixed = 1e30;
-    if (plans && nf > 0 && rem > 0) mixed = round_cost * (double)(nf / 256) + wn_split_cost(rem, wn_rows_for(rem, true), true);
+    if (plans && nf > 0 && rem > 0) mixed = round_cost * (double)(nf / cus) + wn_split_cost(eq(rem), wn_rows_for(eq(rem), true), true);
     if (mixed < fused_all && mixed < split_all) {
         segs.push_back({fused_kind, 32, 0, (int)nf, 0});
-        segs.push_back({WN_ROWSPLIT, 32, (int)nf, (int)rem, wn_rows_for(rem, true)});
+        segs.push_back({WN_ROWSPLIT, 32, (int)nf, (int)rem, wn_rows_for(eq(rem), true)});
         return true;
     }
     if (fused_all < split_all) {
@@ -1936,6 +1941,10 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
     h->cfg = *cfg;
     refresh_path_opts();
     h->precision = path_opts().precision == 1 ? 1 : 0;       // DSD_PRECISION=1: split-bf16 layer kernels (dsd_set_precision)
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount;
+    }
     if (cfg->backbone == DSD_BACKBONE_WAVENET) {      // the kernels run on a multiple of 32 channels (pad_wavenet_weights)
         h->c_user = cfg->num_channels;
         h->cfg.num_channels = (cfg->num_channels + 31) / 32 * 32;
