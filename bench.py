@@ -447,6 +447,10 @@ def main():
             "traffic_source": prof_src if all_tr else None,
             "scope": "time-weighted over the layer kernels of one step (all launches of `kernels`); per-launch means",
             "kernel": classes[0]["kernel"] if classes else None,
+            # the set's largest member on its own (what round 1 / 2 reported as `frac`): 0.55 for the B = 1 conv kernel
+            "dominant": ({"kernel": classes[0]["kernel"], "frac": classes[0]["frac"], "frac_events": classes[0]["frac_events"],
+                          "share_of_set_time": round(classes[0]["launches_per_step"] * classes[0]["avg_launch_us"] * 1e-6 / tot_ev, 4)}
+                         if classes else None),
             "share_of_step": round(tot_ev / sec_per_step, 4),
             "launches_per_step": int(n_launch),
             "avg_launch_us": round(sec / max(n_launch, 1) * 1e6, 3),

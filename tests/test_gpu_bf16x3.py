@@ -113,3 +113,23 @@ def test_bf16x3_config4_share_vs_oracle():
     want = o.forward(cond, noise, diff_accelerator="dpm-solver", diff_speedup=100, K_step_infer=1000)
     check(out, want, TOL_SAMPLER, what="bf16x3, 8 x 1000 frames, 10 NFE")
     d.denoise_fn.release_native()
+
+
+def test_bf16x3_mixed_plan_vs_oracle():
+    """A mixed plan in split-bf16 mode: the fused half of the tiles on wn_layer_x3.hip, the rest on the (fp32) two-launch form."""
+    in_dims, args = NETS["c256_cyc5"]
+    os.environ["DSD_WN_PLAN"] = "2"
+    net, params = make_backbone("wavenet", in_dims, 1, args, 46)
+    net.set_precision("bf16x3")
+    bsz, t_len, lengths = 3, 200, [200, 77, 141]
+    x = synth.synth_normal((bsz, 1, in_dims, t_len), 61)
+    cond = synth.synth_normal((bsz, 256, t_len), 62)
+    t = (np.arange(bsz) * 173.25 + 7.5).astype(np.float32)
+    out = _eval(net, x, t, cond, lengths)
+    st = net.stats()
+    tiles = sum((n + 31) // 32 for n in lengths)
+    assert st["precision"] == 1 and st["layer_launches"] == 3 and st["fused_tiles"] == tiles // 2, st
+    for b, n in enumerate(lengths):
+        want = ob.wavenet_forward(params, x[b:b + 1, :, :, :n], t[b:b + 1], cond[b:b + 1, :, :n], dilation_cycle_length=5)
+        check(out[b:b + 1, :, :, :n], want, TOL_NFE, what=("bf16x3 mixed plan", b))
+    net.release_native()
