@@ -56,6 +56,9 @@ GRIDS = {
     "dense_T96_B1": (1, 96, None),              # whole tiles
     "ragged_B3": (3, 200, [200, 77, 141]),      # per-item ends inside tiles, different tile counts
     "ragged_short": (2, 64, [5, 64]),           # an item shorter than every dilation > 4
+    # a mixed plan's segment boundary INSIDE an item: 15 tiles split 7 | 8 (dense), 13 tiles split 6 | 7 (ragged)
+    "dense_T160_B3": (3, 160, None),
+    "ragged_mid": (3, 160, [160, 96, 141]),
 }
 
 
@@ -113,7 +116,7 @@ def test_fused_layer_forced_vs_oracle(net_name, grid):
     net.release_native()
 
 
-@pytest.mark.parametrize("grid", ["dense_T211_B2", "dense_T13_B3", "ragged_B3", "ragged_short"])
+@pytest.mark.parametrize("grid", ["dense_T211_B2", "dense_T13_B3", "ragged_B3", "ragged_short", "dense_T160_B3", "ragged_mid"])
 @pytest.mark.parametrize("net_name", ["c256_cyc4", "c256_cyc5"])
 def test_mixed_plan_forced_vs_oracle(net_name, grid):
     """DSD_WN_PLAN=2: the first half of the tiles on the fused kernel, the rest on the row-split pair, both reading the layer's

@@ -97,6 +97,7 @@ WIDE_CASES = {
     "pitch_T900": (64, dict(num_layers=5, num_channels=256, dilation_cycle_length=5), 1, 900, None),             # dilation 16: 80-float stride
     "ragged_B3": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 3, 640, [640, 333, 70]),   # tile list, per-item ends
     "pitch_ragged_B2": (64, dict(num_layers=5, num_channels=256, dilation_cycle_length=5), 2, 200, [200, 9]),    # dilation 16, an item of 9 frames
+    "acoustic_T160_B3": (128, dict(num_layers=4, num_channels=256, dilation_cycle_length=4), 3, 160, None),     # mixed plan: 15 tiles split 7 | 8, inside item 1
 }
 
 
