@@ -204,6 +204,20 @@ class _NativeBackbone(nn.Module):
                    "dsd_denoise")
         return out
 
+    def kernel_timing(self, enable):
+        """dsd_kernel_timing: while enabled, every 7th launch of each layer-kernel class carries events (graph replay is bypassed)."""
+        _lib.check(self._handle, _lib.lib().dsd_kernel_timing(self._handle, 1 if enable else 0), "dsd_kernel_timing")
+
+    def kernel_classes(self):
+        """dsd_kernel_timing_classes: [{name, mean_ms, launches, evaluations, flops_per_launch, bytes_per_launch}] of the pass so far -
+        which instantiations of the layer kernels actually ran (tests assert on the names)."""
+        arr = (_lib.DsdKernelTime * 16)()
+        n, empty = C.c_int32(), C.c_double()
+        _lib.check(self._handle, _lib.lib().dsd_kernel_timing_classes(self._handle, arr, 16, C.byref(n), C.byref(empty)),
+                   "dsd_kernel_timing_classes")
+        return [{"name": k.name.decode(), "mean_ms": k.mean_ms, "launches": k.launches, "evaluations": k.evaluations,
+                 "flops_per_launch": k.flops_per_launch, "bytes_per_launch": k.bytes_per_launch} for k in arr[:n.value]]
+
     def stats(self):
         st = _lib.DsdStats()
         _lib.check(self._handle, _lib.lib().dsd_get_stats(self._handle, C.byref(st)), "dsd_get_stats")

@@ -35,7 +35,7 @@ using namespace dsd;
 // path switches: read from the environment once per C-ABI entry point (dsd_internal.h, PathOpts)
 // ------------------------------------------------------------------------------------------
 namespace dsd {
-static PathOpts g_path_opts = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 512};
+static PathOpts g_path_opts = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 512};
 const PathOpts& path_opts() { return g_path_opts; }
 void refresh_path_opts() {
     auto geti = [](const char* name, int dflt) {
@@ -54,6 +54,7 @@ void refresh_path_opts() {
     o.lynx_resident = geti("DSD_LYNX_RESIDENT", -1);
     o.lynx_pw1p = geti("DSD_LYNX_PW1P", -1);
     o.lynx_pw2d = geti("DSD_LYNX_PW2D", -1);
+    o.lynx_pw2q = geti("DSD_LYNX_PW2Q", -1);
     o.narrow = geti("DSD_NARROW", -1);
     o.gm_shift = geti("DSD_GM_SHIFT", -1);
     o.film_t = geti("DSD_FILM_T", -1);
@@ -1825,11 +1826,17 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                               h->blob + h->dw_w[l], h->blob + h->dw_b[l], h->cfg.kernel_size, h->cfg.activation,
                               h->dw_prelu[l] == SIZE_MAX ? nullptr : h->blob + h->dw_prelu[l], st);
             if (e != hipSuccess) return fail(h, DSD_EHIP, "dwconv launch failed: %s", hipGetErrorString(e));
-            if (lx_res2) {
+            if (lx_res2 && path_opts().lynx_pw2q != 1) {
                 timed_begin(610, lx_fl2 * lx_fr, lx_by2 * lx_fr);
                 le = launch_lx_layer(p, 1, C, st);
                 timed_end();
                 if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw2 launch failed: %s", hipGetErrorString(le));
+            } else if (path_opts().lynx_pw2q != 0 && lx_pw2q_supported(C, inner)) {
+                // one-utterance grids: 128 rows per workgroup, C / 128 workgroups per frame tile (lynx_layer.hip, lx_pw2q_kernel)
+                timed_begin(615, lx_fl2 * lx_fr, lx_by2 * lx_fr);
+                le = launch_lx_pw2q(p, C, st);
+                timed_end();
+                if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw2 (128-row) launch failed: %s", hipGetErrorString(le));
             } else {
                 GemmCall o = make_gemm(h, h->g_pw2[l], h->vbuf, us, Ts, B, T, ST_PLAIN, EP_LYNX_NEXT, 0);
                 o.p.act = ACT_NONE;

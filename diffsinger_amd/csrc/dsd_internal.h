@@ -52,6 +52,7 @@ struct PathOpts {
     int lynx_resident;      // DSD_LYNX_RESIDENT   0: never lynx_layer.hip, 1: on every supported grid
     int lynx_pw1p;          // DSD_LYNX_PW1P
     int lynx_pw2d;          // DSD_LYNX_PW2D
+    int lynx_pw2q;          // DSD_LYNX_PW2Q       0: never the 128-row pw2 of one-utterance grids (gemm.hip instead), 1: on every grid
     int narrow;             // DSD_NARROW          gemm.hip: 16-frame tiles off / on
     int gm_shift;           // DSD_GM_SHIFT        gemm.hip: L2 blocking of the work order
     int film_t;             // DSD_FILM_T          0: FiLM vectors from D [L*C][Ns] instead of the transposed table
@@ -103,8 +104,11 @@ inline hipError_t launch_timed(K kern, dim3 grid, dim3 block, int lds, hipStream
 typedef unsigned dsd_u32x4 __attribute__((ext_vector_type(4)));
 typedef int dsd_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ dsd_i32x4 dsd_rsrc_words(const void* ptr) {
+    // (readfirstlane: the words must be in SGPRs for the asm's "s" operand - when the compiler cannot prove the pointer
+    // wave-uniform, or has spilled it to a VGPR, it would otherwise print a VGPR range into the descriptor slot)
     const unsigned long long a = (unsigned long long)ptr;
-    return dsd_i32x4{(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), (int)0x7FFFFFF0u, 0x00020000};
+    return dsd_i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu)),
+                     (int)0x7FFFFFF0u, 0x00020000};
 }
 template <int AUX>
 __device__ __forceinline__ void dsd_store_b128(dsd_u32x4 data, dsd_i32x4 rsrc, int voff, int soff) {
@@ -325,6 +329,8 @@ struct LxLayerP {
 };
 hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st);      // which: 0 = pw1, 1 = pw2
 bool lx_layer_supported(int C, int inner);
+hipError_t launch_lx_pw2q(const LxLayerP& p, int C, hipStream_t st);      // pw2 with 128 rows per workgroup: one-utterance grids
+bool lx_pw2q_supported(int C, int inner);
 hipError_t lx_layer_init_all();
 bool lx_pw1_merges_stats(const LxLayerP& p, int C);
 

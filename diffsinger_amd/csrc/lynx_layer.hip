@@ -797,6 +797,269 @@ __global__ __launch_bounds__(256, 1) void lx_pw2d_kernel(const LxLayerP p) {
 }
 #undef LX_SPREAD
 
+// ---------------------------------------------------------------------------------------------------------------
+// pw2 for ONE-UTTERANCE grids (round 3): 128 output rows per workgroup - C / 128 workgroups per frame tile, 256 for one
+// utterance of ~1000 frames at C = 1024 - where lx_pw2d_kernel's 512-row workgroups leave three quarters of the CUs idle and
+// gemm.hip's EP_LYNX_NEXT GEMM (64-row tiles, 16 MFMAs per k16 step, a barrier per 64-channel chunk) ran at 0.53 of peak.
+// 512 threads = 8 waves = four K QUARTERS (kq: inner / 4 channels each) x two row waves (wr: 64 rows = 4 row blocks): a B
+// fragment read from LDS feeds 8 MFMAs, a k16 step is 32 MFMAs, two waves share a SIMD - the layout that made the WaveNet's
+// two-launch conv MFMA-bound (wn_rows.hip).  Each quarter's channels travel through LDS in sub-phases of 128 (8 steps):
+// while sub-phase i runs from one 64 KiB buffer (4 quarters x 128 channels x 32 frames), sub-phase i + 1 is fetched (two
+// 16-byte loads per thread and step over steps 0-3) and written to the other (steps 4-7); one barrier per sub-phase.  The
+// quarters' partial sums meet in LDS over the dead buffers; the transition (bias, residual, the next layer's conditioner /
+// step projections; LayerNorm partials per 64-row tile) is lx_pw2d_kernel's, on 2 items per thread.
+// ---------------------------------------------------------------------------------------------------------------
+#define LXQ_SPREAD()                                                                 \
+    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);                           \
+    }                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+
+template <int KQ, int RAG>
+__global__ __launch_bounds__(512, 1) void lx_pw2q_kernel(const LxLayerP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SUB = 128;                         // channels of a quarter per sub-phase
+    constexpr int NSUB = KQ / SUB;                   // sub-phases: 4 (inner 2048), 2 (inner 1024)
+    constexpr int SS = SUB / 16;                     // k16 steps per sub-phase: 8
+    constexpr int MB = 4;                            // row blocks per wave
+    constexpr int NSA = 4 * KQ / 16;                 // k16 steps of a row block's whole weight stream
+    constexpr int BUF = 4 * SUB * BN;                // one buffer: [quarter][SUB][32] floats = 64 KiB
+    float* tbl = lds + 2 * BUF;                      // bias [128], next layer's step-projection scalar [128]
+    float* red = tbl + 256;                          // LayerNorm partial sums: [2 tiles][8 waves][32 frames]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = wave >> 1, wr = wave & 1;
+    const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
+    const int work = xcd_work();
+    const int nft = RAG ? p.ncg : p.nft;
+    const int mtile = fdiv_floor(work, p.inv_nft);               // row tile of 128 rows (slowest: an XCD keeps one row tile's weights)
+    const int ft = work - mtile * nft;
+    const int rest = RAG ? p.cgmap[ft] : ft;
+    const int b = fdiv_floor(rest, p.inv_tiles_per_b);
+    const int t0 = (rest - b * p.tiles_per_b) * BN;
+    const int Ts = p.Ts;
+    const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
+    const int mu = __builtin_amdgcn_readfirstlane(mtile);
+
+    // ---------------- prologue: tables, sub-phase 0 of every quarter, the first two weight steps ----------------
+    const int c4 = tid & 7, srow = tid >> 3;                     // staging: row srow + 64 u of the 512 staged rows, frames 4 c4 .. + 3
+    const __amdgpu_buffer_rsrc_t r_v = rsrc(p.v + (long)bu * p.u_bstride + t0u);
+    const int xv0 = (srow * Ts + c4 * 4) * 4;
+    // staged row srow + 64 u = quarter u >> 1, channel (u & 1) * 64 + srow of the sub-phase
+    auto v_soff = [&](int sp, int u) { return (((u >> 1) * KQ + sp * SUB + (u & 1) * 64) * Ts) * 4; };
+    auto lds_off = [&](int u) {
+        const int r = (u & 1) * 64 + srow;
+        return ((u >> 1) * SUB + r) * BN + ((c4 * 4) ^ ((r & 1) << 4));
+    };
+    f32x4 nx[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) nx[u] = ld4(r_v, xv0, v_soff(0, u));
+    const __amdgpu_buffer_rsrc_t r_w = rsrc(p.A2 + ((long)(8 * mu + MB * wr) * NSA + kq * (KQ / 16)) * 256);
+    int wk[MB];
+#pragma unroll
+    for (int k = 0; k < MB; ++k) wk[k] = lane * 16 + k * NSA * 1024;
+    f32x4 W[3][MB];
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+        W[0][k] = ld4(r_w, wk[k], 0);
+        W[1][k] = ld4(r_w, wk[k] + 1024, 0);
+    }
+    if (tid < 128) {
+        tbl[tid] = ld1(rsrc(p.bias2 + 128 * mu), tid * 4, 0);
+        float f = 0.f;
+        if (p.film) f = ld1(rsrc(p.film + p.film_col0 + bu * p.film_colb + (long)128 * mu * p.film_cstride), tid * p.film_cstride * 4, 0);
+        tbl[128 + tid] = f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(&lds[lds_off(u)]) = nx[u];
+    __syncthreads();
+
+    // ---------------- K walk: NSUB sub-phases of 8 steps ----------------
+    f32x4 acc[MB][2];
+#pragma unroll
+    for (int k = 0; k < MB; ++k) acc[k][0] = acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sw = (lrow & 1) << 4;
+    const int zoff0 = (kq * SUB + lrow) * BN + (lcol ^ sw), zoff1 = (kq * SUB + lrow) * BN + ((16 + lcol) ^ sw);
+    // epilogue operands: item i = tid + 512 k -> row i >> 3 of the workgroup's 128, frames 4 (i & 7): residual x, next layer's
+    // hoisted conditioner projection
+    const int row0 = 128 * mu;
+    const int ev0 = ((tid >> 3) * Ts + (tid & 7) * 4) * 4;
+    const __amdgpu_buffer_rsrc_t r_a = rsrc(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    const __amdgpu_buffer_rsrc_t r_c = rsrc((p.cpn ? p.cpn : p.x) + (long)bu * (p.cpn ? p.cpn_bstride : p.x_bstride) + (long)row0 * Ts + t0u);
+    f32x4 aux[2], cpv[2];
+    float bq[2][4][2];
+#pragma unroll
+    for (int sp = 0; sp < NSUB; ++sp) {
+        const float* cur = lds + (sp & 1) * BUF;
+        float* nxt = lds + ((sp + 1) & 1) * BUF;
+        if (sp == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bq[0][j][0] = cur[zoff0 + (j * 4) * BN];
+                bq[0][j][1] = cur[zoff1 + (j * 4) * BN];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < SS; ++s) {
+            const int g = sp * SS + s;                           // k16 step of the quarter
+            if (g + 2 < NSUB * SS) {
+#pragma unroll
+                for (int k = 0; k < MB; ++k) W[(g + 2) % 3][k] = ld4(r_w, wk[k] + ((g + 2) & 3) * 1024, ((g + 2) >> 2) * 4096);
+            }
+            if (sp + 1 < NSUB) {                                 // the next sub-phase: loads over steps 0-3, LDS stores over steps 4-7
+                if (s < 4) {
+                    nx[2 * s] = ld4(r_v, xv0, v_soff(sp + 1, 2 * s));
+                    nx[2 * s + 1] = ld4(r_v, xv0, v_soff(sp + 1, 2 * s + 1));
+                } else {
+                    *reinterpret_cast<f32x4*>(&nxt[lds_off(2 * (s - 4))]) = nx[2 * (s - 4)];
+                    *reinterpret_cast<f32x4*>(&nxt[lds_off(2 * (s - 4) + 1)]) = nx[2 * (s - 4) + 1];
+                }
+            } else if (s < 2) {                                  // the last sub-phase carries the epilogue operands
+                aux[s] = ld4(r_a, ev0, s * 64 * Ts * 4);
+            } else if (s < 4) {
+                cpv[s - 2] = ld4(r_c, ev0, (s - 2) * 64 * Ts * 4);
+            }
+            if (s + 1 < SS) {                                    // B fragments of the next step (the next sub-phase's first: behind the barrier)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bq[(g + 1) & 1][j][0] = cur[zoff0 + ((s + 1) * 16 + j * 4) * BN];
+                    bq[(g + 1) & 1][j][1] = cur[zoff1 + ((s + 1) * 16 + j * 4) * BN];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < MB; ++k) {
+                    acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[g % 3][k][j], bq[g & 1][j][0], acc[k][0], 0, 0, 0);
+                    acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[g % 3][k][j], bq[g & 1][j][1], acc[k][1], 0, 0, 0);
+                }
+            LXQ_SPREAD()
+        }
+        __syncthreads();                                         // the other buffer is complete; every wave is done with this one
+        if (sp + 1 < NSUB) {
+            const float* nb = lds + ((sp + 1) & 1) * BUF;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bq[((sp + 1) * SS) & 1][j][0] = nb[zoff0 + (j * 4) * BN];
+                bq[((sp + 1) * SS) & 1][j][1] = nb[zoff1 + (j * 4) * BN];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---------------- the quarters' partial sums -> LDS tiles [kq][128 rows][ES] over the dead buffers ----------------
+    {
+        float* tk = lds + kq * (128 * ES);
+#pragma unroll
+        for (int k = 0; k < MB; ++k)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tk[((MB * wr + k) * 16 + rq + r) * ES + n * 16 + lcol] = acc[k][n][r];
+    }
+    __syncthreads();
+    // ---------------- transition (gemm.hip EP_LYNX_NEXT; lynxnet.py:76-84 of the next layer), row-major ----------------
+    const dsd_i32x4 w_xo = dsd_rsrc_words(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    const dsd_i32x4 w_xi = dsd_rsrc_words((p.xin_out ? p.xin_out : p.x) + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+    f32x4 xi[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int row = (tid >> 3) + 64 * k;
+        f32x4 a4 = *reinterpret_cast<const f32x4*>(&lds[row * ES + (tid & 7) * 4]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) a4 += *reinterpret_cast<const f32x4*>(&lds[q * (128 * ES) + row * ES + (tid & 7) * 4]);
+        const float brow = tbl[row], frow = tbl[128 + row];
+        f32x4 xo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = (a4[e] + brow) + aux[k][e];              // + bias, + residual (lynxnet.py:86)
+            float o = v, in = v;
+            if (p.cpn) {
+                in = v + cpv[k][e];
+                if (p.strong) o = in;
+            }
+            if (p.film) in = in + frow;
+            xo[e] = o;
+            xi[k][e] = in;
+        }
+        st4(xo, w_xo, ev0, k * 64 * Ts * 4);
+        if (p.xin_out) st4(xi[k], w_xi, ev0, k * 64 * Ts * 4);
+    }
+    // LayerNorm partials of xin per 64-row tile (item k of every thread = tile k of this workgroup): two passes.  A frame quad's 64
+    // rows sit in the 8 lanes with equal (lane & 7) of each of the 8 waves: lanes 8, 16, 32 apart, then the waves through LDS.
+    if (p.lnpart) {
+        auto wave_sum = [&](f32x4 v) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += __shfl_xor(v[e], 8, 64);
+                v[e] += __shfl_xor(v[e], 16, 64);
+                v[e] += __shfl_xor(v[e], 32, 64);
+            }
+            return v;
+        };
+        auto all_sum = [&](int k) {                              // over the 8 waves, in wave order
+            f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += *reinterpret_cast<const f32x4*>(&red[(k * 8 + w) * 32 + (tid & 7) * 4]);
+            return t;
+        };
+        f32x4 mu4[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const f32x4 sv = wave_sum(xi[k]);
+            if (lane < 8) *reinterpret_cast<f32x4*>(&red[(k * 8 + wave) * 32 + lane * 4]) = sv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) mu4[k] = all_sum(k) * (1.f / 64.f);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const f32x4 d = xi[k] - mu4[k];
+            const f32x4 qv = wave_sum(d * d);
+            if (lane < 8) *reinterpret_cast<f32x4*>(&red[(k * 8 + wave) * 32 + lane * 4]) = qv;
+        }
+        __syncthreads();
+        if (tid < 16) {                                          // tile k = tid >> 3, frame quad tid & 7
+            const int k = tid >> 3;
+            const f32x4 q4 = all_sum(k);
+            float* lp = p.lnpart + ((long)bu * p.ln_tiles + 2 * mu + k) * 2 * p.lnpart_ts + t0u + (tid & 7) * 4;
+            *reinterpret_cast<f32x4*>(lp) = mu4[k];
+            *reinterpret_cast<f32x4*>(lp + p.lnpart_ts) = q4;
+        }
+    }
+}
+#undef LXQ_SPREAD
+
+int lx_pw2q_lds_bytes() { return (2 * 4 * 128 * 32 + 256 + 2 * 8 * 32) * 4; }
+bool lx_pw2q_supported(int C, int inner) { return (C == 1024 && inner == 2048) || (C == 512 && inner == 1024); }
+
+template <int KQ, int RAG>
+static hipError_t lx_launch_pw2q(const LxLayerP& p, int nwg, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lx_pw2q_kernel<KQ, RAG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    if (nwg == 0) return hipSuccess;
+    return launch_timed(lx_pw2q_kernel<KQ, RAG>, dim3(nwg), dim3(512), lx_pw2q_lds_bytes(), st, p, "lx_pw2q_kernel<%d, %d>", KQ, RAG);
+}
+
+// pw2 with 128 rows per workgroup (one-utterance grids); p as for launch_lx_layer
+hipError_t launch_lx_pw2q(const LxLayerP& p, int C, hipStream_t st) {
+    if (!lx_pw2q_supported(C, p.inner)) return hipErrorInvalidValue;
+    const int nft = p.cgmap ? p.ncg : p.nft;
+    const int nwg = nft * (C / 128);
+    if (p.inner == 2048) return p.cgmap ? lx_launch_pw2q<512, 1>(p, nwg, st) : lx_launch_pw2q<512, 0>(p, nwg, st);
+    return p.cgmap ? lx_launch_pw2q<256, 1>(p, nwg, st) : lx_launch_pw2q<256, 0>(p, nwg, st);
+}
+
 int lx_lds_bytes(int kt) { return (kt * 32 * 4 > 4 * 128 * 36 * 4 ? kt * 32 * 4 : 4 * 128 * 36 * 4) + 1024 * 4; }
 int lx_pw1p_lds_bytes(int kt) { return kt * 32 * 4 + 4 * 32 * ES * 4; }        // activation tile + the four waves' half tiles
 
@@ -912,6 +1175,7 @@ hipError_t lx_layer_init_all() {
             p.nft = 0;
             if ((e = launch_lx_layer(p, 0, C, nullptr)) != hipSuccess) return e;
             if ((e = launch_lx_layer(p, 1, C, nullptr)) != hipSuccess) return e;
+            if ((e = launch_lx_pw2q(p, C, nullptr)) != hipSuccess) return e;
         }
     return hipSuccess;
 }
