@@ -809,6 +809,10 @@ __global__ __launch_bounds__(256, 1) void lx_pw2d_kernel(const LxLayerP p) {
 // quarters' partial sums meet in LDS over the dead buffers; the transition (bias, residual, the next layer's conditioner /
 // step projections; LayerNorm partials per 64-row tile) is lx_pw2d_kernel's, on 2 items per thread.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef DSD_LXQ_SPREAD
+#define DSD_LXQ_SPREAD 1
+#endif
+#if DSD_LXQ_SPREAD == 1
 #define LXQ_SPREAD()                                                                 \
     _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                               \
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                           \
@@ -816,6 +820,19 @@ __global__ __launch_bounds__(256, 1) void lx_pw2d_kernel(const LxLayerP p) {
         __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);                           \
     }                                                                                \
     __builtin_amdgcn_sched_barrier(0);
+#elif DSD_LXQ_SPREAD == 2
+#define LXQ_SPREAD()                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                               \
+    _Pragma("unroll") for (int g_ = 0; g_ < 7; ++g_) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                           \
+    }                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define LXQ_SPREAD() __builtin_amdgcn_sched_barrier(0);
+#endif
 
 template <int KQ, int RAG>
 __global__ __launch_bounds__(512, 1) void lx_pw2q_kernel(const LxLayerP p) {
