@@ -353,11 +353,9 @@ __global__ __launch_bounds__(512, 1) void wn_out_rw_kernel(const WnLayerP p) {
 #pragma unroll
     for (int k = 0; k < MP; ++k) {
         bo[k] = f32x4{0.f, 0.f, 0.f, 0.f};                       // the bias rides in the first K half: only its waves fetch it
-#ifndef DSD_RW_DBG
-#define DSD_RW_DBG 0
-#endif
-        if ((DSD_RW_DBG & 2) || kh == 0) bo[k] = ld4(rsrc(p.bias_out + orow + 16 * k), rq * 4, 0);
-        if ((DSD_RW_DBG & 2) && kh != 0) bo[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (every wave fetches it, the second K half multiplies it away: a load under `if (kh == 0)` made hipcc wait for each of
+        // the MP loads with vmcnt(0) - four exposed round trips in a 9 us kernel)
+        bo[k] = ld4(rsrc(p.bias_out + orow + 16 * k), rq * 4, 0);
     }
 #pragma unroll
     for (int k = 0; k < MP; ++k) w_load(0, k);
@@ -371,10 +369,6 @@ __global__ __launch_bounds__(512, 1) void wn_out_rw_kernel(const WnLayerP p) {
     const int erow = tid >> 3, ec4 = tid & 7;
     const int ev0 = row_ts(erow, Ts) + ec4 * 16;
     f32x4 pre[MP];
-    if (DSD_RW_DBG & 1) {
-#pragma unroll
-        for (int k = 0; k < MP; ++k) pre[k] = ld4(r_e, ev0, k * 64 * Ts * 4);
-    }
 #pragma unroll
     for (int u = 0; u < NZ; ++u) {
         const int idx = tid + 512 * u, row = idx >> 3;
@@ -384,12 +378,13 @@ __global__ __launch_bounds__(512, 1) void wn_out_rw_kernel(const WnLayerP p) {
 
     // ---------------- K walk ----------------
     f32x4 acc[MP][2];
+    const float bsel = kh == 0 ? 1.f : 0.f;                      // the bias rides in the first K half
 #pragma unroll
     for (int k = 0; k < MP; ++k)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            acc[k][0][r] = bo[k][r];
-            acc[k][1][r] = bo[k][r];
+            acc[k][0][r] = bo[k][r] * bsel;
+            acc[k][1][r] = bo[k][r] * bsel;
         }
     const float* zt = zs + (kh * 128 + lrow) * SZ + lcol;
     float bq[2][4][2];
@@ -423,38 +418,22 @@ __global__ __launch_bounds__(512, 1) void wn_out_rw_kernel(const WnLayerP p) {
                             bn[jj][1] = zt[((s + 1) * 16 + jj * 4) * SZ + 16];
                         }
                     }
-                    if (!(DSD_RW_DBG & 1) && s >= 1 && s <= MP && m == 3) pre[s - 1] = ld4(r_e, ev0, (s - 1) * 64 * Ts * 4);
-                    if (!(DSD_RW_DBG & 4)) RW_PIN();
+                    if (s >= 1 && s <= MP && m == 3) pre[s - 1] = ld4(r_e, ev0, (s - 1) * 64 * Ts * 4);
+                    RW_PIN();
                 }
     });
 
     // ---------------- the two K halves' sums; residual / skip (wavenet.py:45-48), row-major ----------------
     {
         float* tk = kh == 0 ? et : red;
-        if (DSD_RW_DBG & 16) {
-            volatile float* tv = tk;
-#pragma unroll
-            for (int k = 0; k < MP; ++k)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tv[(16 * (MP * w + k) + rq + r) * ES + n * 16 + lcol] = acc[k][n][r];
-        } else {
 #pragma unroll
         for (int k = 0; k < MP; ++k)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tk[(16 * (MP * w + k) + rq + r) * ES + n * 16 + lcol] = acc[k][n][r];
-        }
     }
     __syncthreads();
-    if (DSD_RW_DBG & 8) {
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __syncthreads();
-    }
     {
         const dsd_i32x4 w_o = dsd_rsrc_words((const float*)(is_res ? xo : sa) + eoff);
         const float scale = is_res ? 0.70710678118654752440f : 1.f;     // (x + o) / sqrt(2): times the fp32 reciprocal
