@@ -209,7 +209,6 @@ def main():
         d = d.to(device).eval()
     d.use_graph = not args.no_graph
     if args.precision != "f32":
-        assert kind == "wavenet" and acoustic is None, "--precision bf16x3 exists for the WaveNet workloads"
         d.denoise_fn.set_precision(args.precision, device)
         if variance is not None:
             variance.velocity_fn.set_precision(args.precision, device)

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdsdenoise.so")
-SOURCES = ["gemm.hip", "wn_layer.hip", "wn_layer_x3.hip", "wn_rowsplit.hip", "wn_rows.hip", "wn_edge.hip", "lynx_layer.hip", "aux_kernels.hip", "encoder_kernels.hip", "vocoder_kernels.hip", "tconv.hip", "api.hip"]
+SOURCES = ["gemm.hip", "wn_layer.hip", "wn_layer_x3.hip", "wn_rowsplit.hip", "wn_rows.hip", "wn_edge.hip", "lynx_layer.hip", "lynx_x3.hip", "aux_kernels.hip", "encoder_kernels.hip", "vocoder_kernels.hip", "tconv.hip", "api.hip"]
 HEADERS = [os.path.join(CSRC, "dsd_internal.h"), os.path.join(os.path.dirname(HERE), "include", "dsdenoise.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -928,25 +928,27 @@ inline float bf16_value(uint16_t b) {
 // order a wave consumes it.  v_mfma_f32_16x16x32_bf16's A operand: lane l holds A[row l & 15][k = 8 (l >> 4) + j], j = 0..7.
 // rows_of(block, m) = the original row of packed block `block` (0..31), row m; col_of(step, kk) = (input channel, tap) of k index
 // kk (0..31) of k32 step `step`.
-size_t pack_x3(dsd_handle* h, int nsteps, const std::function<int(int, int)>& row_of,
+size_t pack_x3(dsd_handle* h, int nrt, int nsteps, const std::function<int(int, int, int)>& row_of,
                const std::function<std::pair<int, int>(int, int)>& col_of, const WGet& w) {
-    const size_t nfloats = (size_t)4 * nsteps * 8 * 2 * 64 * 8 / 2;
+    // nrt row tiles of 4 waves x 8 row blocks; row_of(row tile, 8 * wave + k, m)
+    const size_t nfloats = (size_t)nrt * 4 * nsteps * 8 * 2 * 64 * 8 / 2;
     const size_t off = blob_reserve(h, nfloats);
     uint16_t* dst = reinterpret_cast<uint16_t*>(h->blob_host.data() + off);
-    for (int wave = 0; wave < 4; ++wave)
-        for (int s = 0; s < nsteps; ++s)
-            for (int k = 0; k < 8; ++k) {
-                uint16_t* blk = dst + (((size_t)wave * nsteps + s) * 8 + k) * 2 * 512;
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int row = row_of(8 * wave + k, lane & 15);
-                        const std::pair<int, int> ct = col_of(s, 8 * (lane >> 4) + j);
-                        const float v = (float)w(row, ct.first, ct.second);
-                        const uint16_t hi = bf16_bits(v);
-                        blk[lane * 8 + j] = hi;
-                        blk[512 + lane * 8 + j] = bf16_bits(v - bf16_value(hi));
-                    }
-            }
+    for (int rt = 0; rt < nrt; ++rt)
+        for (int wave = 0; wave < 4; ++wave)
+            for (int s = 0; s < nsteps; ++s)
+                for (int k = 0; k < 8; ++k) {
+                    uint16_t* blk = dst + ((((size_t)rt * 4 + wave) * nsteps + s) * 8 + k) * 2 * 512;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = row_of(rt, 8 * wave + k, lane & 15);
+                            const std::pair<int, int> ct = col_of(s, 8 * (lane >> 4) + j);
+                            const float v = (float)w(row, ct.first, ct.second);
+                            const uint16_t hi = bf16_bits(v);
+                            blk[lane * 8 + j] = hi;
+                            blk[512 + lane * 8 + j] = bf16_bits(v - bf16_value(hi));
+                        }
+                }
     return off;
 }
 
@@ -1045,11 +1047,11 @@ int build_packed(dsd_handle* h) {
                 const HostTensor* t = &W(h, p + "dilated_conv.weight");    // [2C, C, 3]
                 WGet w = [t, C](int r, int k, int tap) { return (double)t->data[((size_t)r * C + k) * 3 + tap]; };
                 // conv rows: block 2 q + gf = the gate (gf = 0) / filter (1) rows of channels [16 q, 16 q + 16); k32 step = [tap][chunk]
-                h->x3_conv[l] = pack_x3(h, 3 * C / 32, [C](int blk, int m) { return (blk & 1) * C + (blk >> 1) * 16 + m; },
+                h->x3_conv[l] = pack_x3(h, 1, 3 * C / 32, [C](int, int blk, int m) { return (blk & 1) * C + (blk >> 1) * 16 + m; },
                                         [](int s, int kk) { return std::make_pair((s & 7) * 32 + kk, s >> 3); }, w);
                 const HostTensor* to = &W(h, p + "output_projection.weight");    // [2C, C, 1]
                 WGet wo = [to, C](int r, int k, int) { return (double)to->data[(size_t)r * C + k]; };
-                h->x3_out[l] = pack_x3(h, C / 32, [](int blk, int m) { return blk * 16 + m; },
+                h->x3_out[l] = pack_x3(h, 1, C / 32, [](int, int blk, int m) { return blk * 16 + m; },
                                        [](int s, int kk) { return std::make_pair(s * 32 + kk, 0); }, wo);
             }
         }
@@ -1065,6 +1067,7 @@ int build_packed(dsd_handle* h) {
         h->dw_b.resize(L);
         h->dw_prelu.assign(L, SIZE_MAX);
         // LayerNorm affine folded into the following 1x1 conv:  W (g*n + beta) + b = (W diag g) n + (W beta + b)
+        WGet last_folded;                                        // the LayerNorm-folded matrix of the last fold_ln call (split-bf16 packing)
         auto fold_ln = [&](const std::string& wname, const std::string& bname, const std::string& gname,
                            const std::string& betaname, int rows, int pairC) {
             const HostTensor* w = &W(h, wname);
@@ -1072,6 +1075,7 @@ int build_packed(dsd_handle* h) {
             const HostTensor* g = &W(h, gname);
             const HostTensor* be = &W(h, betaname);
             WGet wf = [w, g, C](int r, int k, int) { return (double)w->data[(size_t)r * C + k] * (double)g->data[k]; };
+            last_folded = wf;
             std::function<double(int)> bf = [w, bb, be, C](int r) {
                 double s = bb->data[r];
                 for (int k = 0; k < C; ++k) s += (double)w->data[(size_t)r * C + k] * (double)be->data[k];
@@ -1079,11 +1083,26 @@ int build_packed(dsd_handle* h) {
             };
             return pack_gemm(h, rows, C, 1, pairC, wf, &bf);
         };
+        const bool x3 = h->precision == 1 && lx_x3_supported(C, inner);
+        h->x3_conv.clear();
+        h->x3_out.clear();
+        if (x3) {
+            h->x3_conv.resize(L);                                // (LYNXNet: x3_conv = pw1 streams, x3_out = pw2 streams)
+            h->x3_out.resize(L);
+        }
         for (int l = 0; l < L; ++l) {
             const std::string p = "residual_layers." + std::to_string(l) + ".convmodule.net.";
             h->g_pw1[l] = fold_ln(p + "2.weight", p + "2.bias", p + "0.weight", p + "0.bias", 2 * inner, inner);
             auto b = bias_of(p + "6.bias");
             h->g_pw2[l] = pack_gemm(h, C, inner, 1, 0, conv1(p + "6.weight"), &b);
+            if (x3) {
+                // pw1: row tile rt = u channels [256 rt, +256); wave w, block k: pair k >> 1 = 16 channels, k & 1 = out (0) / gate (1) rows
+                h->x3_conv[l] = pack_x3(h, 2 * inner / 512, C / 32,
+                                        [inner](int rt, int blk, int m) { return (blk & 1) * inner + 256 * rt + (blk >> 3) * 64 + ((blk & 7) >> 1) * 16 + m; },
+                                        [](int s, int kk) { return std::make_pair(s * 32 + kk, 0); }, last_folded);
+                h->x3_out[l] = pack_x3(h, C / 512, inner / 32, [](int rt, int blk, int m) { return 512 * rt + blk * 16 + m; },
+                                       [](int s, int kk) { return std::make_pair(s * 32 + kk, 0); }, conv1(p + "6.weight"));
+            }
             const auto& dw = W(h, p + "4.weight").data;
             h->dw_w[l] = blob_reserve(h, (size_t)inner * ks);
             memcpy(h->blob_host.data() + h->dw_w[l], dw.data(), sizeof(float) * inner * ks);
@@ -1808,7 +1827,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             p.strong = h->cfg.strong_cond;
             p.lnpart = h->lnpart; p.lnpart_ts = Ts; p.ln_tiles = ln_tiles;
             p.lnpart_in = h->lnpart;        // (read by pw1 before pw2 of this layer replaces it with the next layer's partials)
-            if (!lx_pw1_merges_stats(p, C)) {      // one workgroup per frame tile merges its own frames' partials itself
+            if (!(h->precision == 1 && !h->x3_conv.empty()) && !lx_pw1_merges_stats(p, C)) {      // (both fp32 forms and the bf16x3 one merge their own frames' partials)
                 hipError_t me = launch_ln_merge(h->lnpart, ln_tiles, C, B, T, Ts, 1e-5f, h->stats, st);
                 if (me != hipSuccess) return fail(h, DSD_EHIP, "LayerNorm merge launch failed: %s", hipGetErrorString(me));
             }
@@ -1818,15 +1837,35 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                 p.cpn = h->cp + (long)next * C * Ts; p.cpn_bstride = (long)L * C * Ts;
                 film_of(h, next, film_col0, film_colb, p.film, p.film_cstride, p.film_col0, p.film_colb);
             }
-            timed_begin(600, lx_fl1 * lx_fr, lx_by1 * lx_fr);
-            hipError_t le = launch_lx_layer(p, 0, C, st);
-            timed_end();
+            // split-bf16 mode (lynx_x3.hip): both pointwise GEMMs as weight-stream-bound bf16x3 kernels; pw2 only where its C / 512
+            // workgroups per frame tile fill at least half the chip (one utterance: the fp32 128-row kernel is faster)
+            const bool x3 = h->precision == 1 && !h->x3_conv.empty();
+            const bool x3_pw2 = x3 && lx_tiles * (C / 512) >= h->cus / 2;
+            hipError_t le;
+            if (x3) {
+                LxLayerP q = p;
+                q.A1 = h->blob + h->x3_conv[l];
+                timed_begin(650, lx_fl1 * lx_fr, lx_by1 * lx_fr);
+                le = launch_lx_x3(q, 0, C, st);
+                timed_end();
+            } else {
+                timed_begin(600, lx_fl1 * lx_fr, lx_by1 * lx_fr);
+                le = launch_lx_layer(p, 0, C, st);
+                timed_end();
+            }
             if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw1 launch failed: %s", hipGetErrorString(le));
             e = launch_dwconv(h->ubuf, h->vbuf, us, Ts, inner, B, T, h->lens_host.empty() ? nullptr : h->lens_dev,
                               h->blob + h->dw_w[l], h->blob + h->dw_b[l], h->cfg.kernel_size, h->cfg.activation,
                               h->dw_prelu[l] == SIZE_MAX ? nullptr : h->blob + h->dw_prelu[l], st);
             if (e != hipSuccess) return fail(h, DSD_EHIP, "dwconv launch failed: %s", hipGetErrorString(e));
-            if (lx_res2 && path_opts().lynx_pw2q != 1) {
+            if (x3_pw2) {
+                LxLayerP q = p;
+                q.A2 = h->blob + h->x3_out[l];
+                timed_begin(660, lx_fl2 * lx_fr, lx_by2 * lx_fr);
+                le = launch_lx_x3(q, 1, C, st);
+                timed_end();
+                if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw2 (bf16x3) launch failed: %s", hipGetErrorString(le));
+            } else if (lx_res2 && path_opts().lynx_pw2q != 1) {
                 timed_begin(610, lx_fl2 * lx_fr, lx_by2 * lx_fr);
                 le = launch_lx_layer(p, 1, C, st);
                 timed_end();
@@ -1941,6 +1980,7 @@ int dsd_create(const dsd_config* cfg, dsd_handle** out) {
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_rowsplit_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_rows_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_layer_x3_init_all();
+    if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_LYNXNET) ie = lx_x3_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_WAVENET) ie = wn_edge_init_all();
     if (ie == hipSuccess && cfg->backbone == DSD_BACKBONE_LYNXNET) ie = lx_layer_init_all();
     if (ie != hipSuccess) return fail(nullptr, DSD_EHIP, "dsd_create: kernel attribute setup failed: %s", hipGetErrorString(ie));
@@ -2875,7 +2915,8 @@ int dsd_set_precision(dsd_handle* h, int32_t mode) {
     if (!h) return DSD_EINVAL;
     if (mode != DSD_PRECISION_F32 && mode != DSD_PRECISION_BF16X3)
         return fail(h, DSD_EINVAL, "dsd_set_precision: unknown mode %d", mode);
-    if (!is_wavenet(h)) return fail(h, DSD_ESTATE, "dsd_set_precision: only WaveNet denoiser handles have a split-bf16 path");
+    if (!is_wavenet(h) && h->cfg.backbone != DSD_BACKBONE_LYNXNET)
+        return fail(h, DSD_ESTATE, "dsd_set_precision: only denoiser handles have a split-bf16 path");
     if (mode == h->precision) return DSD_OK;
     h->precision = mode;
     if (h->finalized) {                   // the bf16x3 weight streams are built with the packed weights
@@ -2961,6 +3002,7 @@ int dsd_get_stats(const dsd_handle* h, dsd_stats* out) {
         out->flops_per_frame_nfe = 2 * (M * C + L * (C * 2 * inner + ks * inner + inner * C) + C * M);
         out->bytes_per_frame_nfe = L * 12 * C + 8 * M;
         out->kernels_per_nfe = 1 + 4 * (int)L + 2;
+        if (h->precision == 1 && !h->x3_conv.empty()) out->precision = DSD_PRECISION_BF16X3;
     }
     out->graphs_cached = (int)h->graphs.size();
     return DSD_OK;

@@ -334,6 +334,12 @@ bool lx_pw2q_supported(int C, int inner);
 hipError_t lx_layer_init_all();
 bool lx_pw1_merges_stats(const LxLayerP& p, int C);
 
+// lynx_x3.hip: the two pointwise GEMMs in split-bf16 arithmetic (opt-in precision mode); p.A1 / p.A2 = the layer's bf16x3 weight
+// streams [row tile][wave][k32 step][row block][hi | lo][lane][8 bf16]
+hipError_t launch_lx_x3(const LxLayerP& p, int which, int C, hipStream_t st);
+hipError_t lx_x3_init_all();
+bool lx_x3_supported(int C, int inner);
+
 // aux_kernels.hip
 hipError_t launch_pack(const float* src, long sb, long sr, long st, float* dst, int B, int R, int T, int Ts,
                        hipStream_t stream);

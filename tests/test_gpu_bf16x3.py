@@ -133,3 +133,57 @@ def test_bf16x3_mixed_plan_vs_oracle():
         want = ob.wavenet_forward(params, x[b:b + 1, :, :, :n], t[b:b + 1], cond[b:b + 1, :, :n], dilation_cycle_length=5)
         check(out[b:b + 1, :, :, :n], want, TOL_NFE, what=("bf16x3 mixed plan", b))
     net.release_native()
+
+
+# ---- LYNXNet's pointwise GEMMs in split-bf16 (lynx_x3.hip)
+LX_NETS = {
+    "c1024_strong": dict(num_layers=2, num_channels=1024, expansion_factor=2, kernel_size=31, activation="PReLU", strong_cond=True),
+    "c512_default": dict(num_layers=3, num_channels=512, expansion_factor=2, kernel_size=31, activation="SiLU", strong_cond=False),
+}
+
+
+def _lx_case(net_name, bsz, t_len, lengths, expect_pw2_x3, force_resident):
+    args = LX_NETS[net_name]
+    if force_resident:
+        os.environ["DSD_LYNX_RESIDENT"] = "1"
+    try:
+        net, params = make_backbone("lynxnet", 128, 1, args, 59)
+        x = synth.synth_normal((bsz, 1, 128, t_len), 21)
+        cond = synth.synth_normal((bsz, 256, t_len), 22)
+        t = (np.arange(bsz) * 173.25 + 7.5).astype(np.float32)
+        f32 = _eval(net, x, t, cond, lengths)
+        net.set_precision("bf16x3")
+        out = _eval(net, x, t, cond, lengths)
+        assert net.stats()["precision"] == 1 and not np.array_equal(out, f32)
+        net.kernel_timing(True)
+        _eval(net, x, t, cond, lengths)
+        names = [k["name"] for k in net.kernel_classes()]
+        net.kernel_timing(False)
+        assert any(n.startswith("lx_x3_kernel<0") for n in names), names
+        assert any(n.startswith("lx_x3_kernel<1") for n in names) == expect_pw2_x3, names
+        fwd = lambda xx, tt, cc: ob.lynxnet_forward(params, xx, tt, cc, activation=args["activation"], strong_cond=args["strong_cond"])   # noqa: E731
+        if lengths is None:
+            check(out, fwd(x, t, cond), TOL_NFE, what=("lynx bf16x3", net_name, bsz, t_len))
+        else:
+            for b, n in enumerate(lengths):
+                check(out[b:b + 1, :, :, :n], fwd(x[b:b + 1, :, :, :n], t[b:b + 1], cond[b:b + 1, :, :n]), TOL_NFE,
+                      what=("lynx bf16x3", net_name, b))
+        net.set_precision("f32")
+        assert np.array_equal(_eval(net, x, t, cond, lengths), f32)
+        net.release_native()
+    finally:
+        os.environ.pop("DSD_LYNX_RESIDENT", None)
+
+
+@pytest.mark.parametrize("net_name", sorted(LX_NETS))
+def test_lynx_bf16x3_small_grid_vs_oracle(net_name):
+    """pw1 in split-bf16 (forced onto a grid the oracle handles; pw2 stays on the fp32 one-utterance kernels), cut tile, ragged"""
+    _lx_case(net_name, 2, 211, None, False, True)
+    _lx_case(net_name, 3, 200, [200, 77, 141], False, True)
+
+
+def test_lynx_bf16x3_batched_grid_vs_oracle():
+    """both pointwise GEMMs in split-bf16 on grids that give pw2 half a chip of workgroups: C = 1024 at 2 x 1000 frames (64 frame
+    tiles x 2 row tiles), the class-default C = 512 at 5 x 1000 frames"""
+    _lx_case("c1024_strong", 2, 1000, None, True, False)
+    _lx_case("c512_default", 5, 1000, None, True, False)
