@@ -35,7 +35,7 @@ using namespace dsd;
 // path switches: read from the environment once per C-ABI entry point (dsd_internal.h, PathOpts)
 // ------------------------------------------------------------------------------------------
 namespace dsd {
-static PathOpts g_path_opts = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 512};
+static PathOpts g_path_opts = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 512};
 const PathOpts& path_opts() { return g_path_opts; }
 void refresh_path_opts() {
     auto geti = [](const char* name, int dflt) {
@@ -60,6 +60,7 @@ void refresh_path_opts() {
     o.film_t = geti("DSD_FILM_T", -1);
     o.dwconv_rows = geti("DSD_DWCONV_ROWS", -1);
     o.precision = geti("DSD_PRECISION", -1);
+    o.x3_wide = geti("DSD_X3_WIDE", -1);
     const char* nb = getenv("DSD_NB2_MIN_WG");
     o.nb2_min = nb && *nb ? atol(nb) : 512;
 }
@@ -1841,12 +1842,25 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             // workgroups per frame tile fill at least half the chip (one utterance: the fp32 128-row kernel is faster)
             const bool x3 = h->precision == 1 && !h->x3_conv.empty();
             const bool x3_pw2 = x3 && lx_tiles * (C / 512) >= h->cus / 2;
+            // ... on 64-frame tiles where those still fill the chip: the same weight stream then serves twice the frames
+            const long lx_t64 = lx_ragged ? (long)h->cg_n[2] : (long)B * ((T + 63) / 64);
+            const int xw = path_opts().x3_wide;
+            const bool wide1 = x3 && xw != 0 && (xw == 1 || lx_t64 * (2 * inner / 512) >= h->cus);
+            const bool wide2 = x3_pw2 && xw != 0 && (xw == 1 || lx_t64 * (C / 512) >= h->cus);
+            auto widen = [&](LxLayerP& q) {                      // the tile bookkeeping of a launch on 64-frame tiles
+                q.tiles_per_b = (T + 63) / 64;
+                q.inv_tiles_per_b = 1.0f / (float)q.tiles_per_b;
+                q.nft = B * q.tiles_per_b;
+                if (lx_ragged) { q.cgmap = h->cg_dev[2]; q.ncg = h->cg_n[2]; }
+                q.inv_nft = 1.0f / (float)std::max(1, lx_ragged ? q.ncg : q.nft);
+            };
             hipError_t le;
             if (x3) {
                 LxLayerP q = p;
                 q.A1 = h->blob + h->x3_conv[l];
-                timed_begin(650, lx_fl1 * lx_fr, lx_by1 * lx_fr);
-                le = launch_lx_x3(q, 0, C, st);
+                if (wide1) widen(q);
+                timed_begin(650 + (wide1 ? 1 : 0), lx_fl1 * lx_fr, lx_by1 * lx_fr);
+                le = launch_lx_x3(q, 0, C, wide1 ? 4 : 2, st);
                 timed_end();
             } else {
                 timed_begin(600, lx_fl1 * lx_fr, lx_by1 * lx_fr);
@@ -1861,8 +1875,9 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             if (x3_pw2) {
                 LxLayerP q = p;
                 q.A2 = h->blob + h->x3_out[l];
-                timed_begin(660, lx_fl2 * lx_fr, lx_by2 * lx_fr);
-                le = launch_lx_x3(q, 1, C, st);
+                if (wide2) widen(q);
+                timed_begin(660 + (wide2 ? 1 : 0), lx_fl2 * lx_fr, lx_by2 * lx_fr);
+                le = launch_lx_x3(q, 1, C, wide2 ? 4 : 2, st);
                 timed_end();
                 if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw2 (bf16x3) launch failed: %s", hipGetErrorString(le));
             } else if (lx_res2 && path_opts().lynx_pw2q != 1) {

@@ -58,6 +58,7 @@ struct PathOpts {
     int film_t;             // DSD_FILM_T          0: FiLM vectors from D [L*C][Ns] instead of the transposed table
     int dwconv_rows;        // DSD_DWCONV_ROWS     0: the first depthwise-convolution kernel
     int precision;          // DSD_PRECISION       1: split-bf16 (bf16x3) layer kernels where they exist (opt-in, own tolerance)
+    int x3_wide;            // DSD_X3_WIDE         0: never 64-frame tiles in the split-bf16 LYNXNet kernels, 1: wherever they exist
     long nb2_min;           // DSD_NB2_MIN_WG      gemm.hip: workgroups from which 64-frame tiles are used (default 512)
 };
 const PathOpts& path_opts();
@@ -336,7 +337,7 @@ bool lx_pw1_merges_stats(const LxLayerP& p, int C);
 
 // lynx_x3.hip: the two pointwise GEMMs in split-bf16 arithmetic (opt-in precision mode); p.A1 / p.A2 = the layer's bf16x3 weight
 // streams [row tile][wave][k32 step][row block][hi | lo][lane][8 bf16]
-hipError_t launch_lx_x3(const LxLayerP& p, int which, int C, hipStream_t st);
+hipError_t launch_lx_x3(const LxLayerP& p, int which, int C, int ncb, hipStream_t st);     // ncb: 2 = 32-frame tiles, 4 = 64-frame tiles
 hipError_t lx_x3_init_all();
 bool lx_x3_supported(int C, int inner);
 

@@ -52,34 +52,39 @@ __device__ __forceinline__ int xcd_work() {
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
 }
 
-// one row block x both column blocks of a k32 step: lo.hi, hi.lo, hi.hi, the two accumulators alternating
-__device__ __forceinline__ void x3_products(f32x4 (&a)[2], bf16x8 wh, bf16x8 wl, const bf16x8 (&bh)[2], const bf16x8 (&bl)[2]) {
-    a[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bh[0], a[0], 0, 0, 0);
-    a[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bh[1], a[1], 0, 0, 0);
-    a[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bl[0], a[0], 0, 0, 0);
-    a[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bl[1], a[1], 0, 0, 0);
-    a[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bh[0], a[0], 0, 0, 0);
-    a[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bh[1], a[1], 0, 0, 0);
+// one row block x all NCB column blocks of a k32 step: lo.hi, hi.lo, hi.hi, the accumulators alternating
+template <int NCB>
+__device__ __forceinline__ void x3_products(f32x4 (&a)[NCB], bf16x8 wh, bf16x8 wl, const bf16x8 (&bh)[NCB], const bf16x8 (&bl)[NCB]) {
+#pragma unroll
+    for (int n = 0; n < NCB; ++n) a[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bh[n], a[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NCB; ++n) a[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bl[n], a[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NCB; ++n) a[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bh[n], a[n], 0, 0, 0);
 }
 
 }  // namespace
 
-// MODE 0: pw1, KT = C (512 / 1024); MODE 1: pw2, KT = inner (1024 / 2048)
-template <int MODE, int KT, int RAG>
+// MODE 0: pw1, KT = C (512 / 1024); MODE 1: pw2, KT = inner (1024 / 2048); NCB: 16-frame column blocks of the tile - 2 (32
+// frames, K phases of <= 1024 channels) or 4 (64 frames in phases of 512: the SAME weight stream serves twice the frames, which
+// is what a stream-bound kernel needs; for grids that still fill the chip with half the frame tiles)
+template <int MODE, int KT, int RAG, int NCB>
 __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int KP = KT < 1024 ? KT : 1024;        // channels of a resident phase
+    constexpr int BNW = 16 * NCB;                    // frames of the tile
+    constexpr int FQ = BNW / 4;                      // frame quads
+    constexpr int KP = NCB == 4 ? 512 : (KT < 1024 ? KT : 1024);        // channels of a resident phase
     constexpr int NPH = KT / KP;
     constexpr int RS = KP + 8;                       // image row stride (bf16 elements): 16 lanes x 16 B on 64 distinct banks
     constexpr int NSP = KP / 32;                     // k32 steps per phase
     constexpr int NST = KT / 32;                     // ... of the whole weight stream
     constexpr int NB = NST * MBW;                    // row-block loads of a wave's stream
     constexpr int RB = 14;                           // weight ring: row-block slots (hi + lo = 8 VGPRs each)
-    constexpr int NUT = (KP / 8) * 8 / 256;          // staging units (8 channels x 4 frames) per thread: 4 (KP 1024), 2 (512)
-    __bf16* xhi = reinterpret_cast<__bf16*>(lds_raw);            // [32][RS]
-    __bf16* xlo = xhi + BN * RS;
+    constexpr int NUT = (KP / 8) * FQ / 256;         // staging units (8 channels x 4 frames) per thread: 4 (2 at KP 512, 32 frames)
+    __bf16* xhi = reinterpret_cast<__bf16*>(lds_raw);            // [BNW][RS]
+    __bf16* xlo = xhi + BNW * RS;
     float* ep = reinterpret_cast<float*>(lds_raw);               // epilogue tiles over the dead images
-    constexpr int IMG_B = 2 * BN * RS * 2, EPT_B = 4 * 128 * ES * 4;
+    constexpr int IMG_B = 2 * BNW * RS * 2, EPT_B = 4 * 128 * ES * 4;
     float* tbl = reinterpret_cast<float*>(lds_raw + (IMG_B > EPT_B ? IMG_B : EPT_B));      // pw2: bias [512], step-projection scalar [512]
 
     const int tid = threadIdx.x;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
     const int ft = work - mtile * nft;
     const int rest = RAG ? p.cgmap[ft] : ft;
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
-    const int t0 = (rest - b * p.tiles_per_b) * BN;
+    const int t0 = (rest - b * p.tiles_per_b) * BNW;
     const int Ts = p.Ts;
     const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
     const int mu = __builtin_amdgcn_readfirstlane(mtile);
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
     __builtin_amdgcn_sched_barrier(0);
 
     // ---------------- staging of a phase: 8 channels x 4 frames per unit, transposed, split hi / lo ----------------
-    const int fq = tid & 7;                                      // the thread's frame quad, for every unit
+    const int fq = tid % FQ;                                     // the thread's frame quad, for every unit
     f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, rstd = f32x4{1.f, 1.f, 1.f, 1.f};
     if (MODE == 0) {
         // LayerNorm statistics of the tile's frames from the producer's per-64-row partials (ln_merge_kernel's arithmetic and order)
@@ -144,13 +149,13 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
             f32x4 sv[2][8];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int co = (tid >> 3) + 32 * (i0 + i);           // channel octet of the phase
+                const int co = tid / FQ + (256 / FQ) * (i0 + i);     // channel octet of the phase
 #pragma unroll
                 for (int c = 0; c < 8; ++c) sv[i][c] = ld4(r_in, ((8 * co + c) * Ts + 4 * fq) * 4, ph * KP * Ts * 4);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int co = (tid >> 3) + 32 * (i0 + i);
+                const int co = tid / FQ + (256 / FQ) * (i0 + i);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     bf16x8 h8, l8;
@@ -185,9 +190,11 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
     __syncthreads();
 
     // ---------------- K walk: NPH resident phases of NSP k32 steps ----------------
-    f32x4 acc[MBW][2];
+    f32x4 acc[MBW][NCB];
 #pragma unroll
-    for (int k = 0; k < MBW; ++k) acc[k][0] = acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < MBW; ++k)
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) acc[k][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int bbase = lcol * RS + 8 * lrow;
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
@@ -198,9 +205,9 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
         }
 #pragma unroll
         for (int s = 0; s < NSP; ++s) {
-            bf16x8 bh[2], bl[2];
+            bf16x8 bh[NCB], bl[NCB];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NCB; ++n) {
                 const int off = bbase + 16 * n * RS + 32 * s;
                 bh[n] = *reinterpret_cast<const bf16x8*>(&xhi[off]);
                 bl[n] = *reinterpret_cast<const bf16x8*>(&xlo[off]);
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
 #pragma unroll
             for (int k = 0; k < MBW; ++k) {
                 const int i = (ph * NSP + s) * MBW + k;
-                x3_products(acc[k], Whi[i % RB], Wlo[i % RB], bh, bl);
+                x3_products<NCB>(acc[k], Whi[i % RB], Wlo[i % RB], bh, bl);
                 w_issue(i + RB);
                 __builtin_amdgcn_sched_barrier(0);               // (pinned: see wn_layer_x3.hip)
             }
@@ -216,149 +223,164 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
     }
     __syncthreads();                                             // the images are dead: the epilogue tiles go over them
 
+    // ---------------- epilogues: one 32-frame half of the tile at a time (hf), through the wave's LDS tile ----------------
     const int ev0 = ((lane >> 3) * Ts + (lane & 7) * 4) * 4;
-    if (MODE == 0) {
-        // ---------------- bias + SwiGLU (common_layers.py:116-117: out * silu(gate)), transposed through LDS, float4 stores ----------------
-        const int ch0 = 256 * mu + 64 * wave;                    // first u channel of this wave
-        const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias1);
-        f32x4 bo[MBW];
 #pragma unroll
-        for (int k = 0; k < MBW; ++k) bo[k] = ld4(r_b, rq * 4, ((k & 1) * p.inner + ch0 + (k >> 1) * 16) * 4);
-        float* ew = ep + wave * (64 * ES);
+    for (int hf = 0; hf < NCB / 2; ++hf) {
+        const int th = t0u + 32 * hf;                            // first frame of this half
+        if (MODE == 0) {
+            // bias + SwiGLU (common_layers.py:116-117: out * silu(gate)), transposed through LDS, float4 stores
+            const int ch0 = 256 * mu + 64 * wave;                // first u channel of this wave
+            const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias1);
+            f32x4 bo[MBW];
 #pragma unroll
-        for (int i = 0; i < MBW / 2; ++i)
+            for (int k = 0; k < MBW; ++k) bo[k] = ld4(r_b, rq * 4, ((k & 1) * p.inner + ch0 + (k >> 1) * 16) * 4);
+            float* ew = ep + wave * (64 * ES);
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int i = 0; i < MBW / 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float u0 = acc[2 * i][n][r] + bo[2 * i][r];
-                    const float u1 = acc[2 * i + 1][n][r] + bo[2 * i + 1][r];
-                    ew[(i * 16 + rq + r) * ES + n * 16 + lcol] = u0 * (u1 * sigmoid_f(u1));
-                }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const dsd_i32x4 w_o = dsd_rsrc_words(p.u + (long)bu * p.u_bstride + (long)ch0 * Ts + t0u);
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int idx = lane + 64 * m;
-            st4(*reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]), w_o, ev0, m * 8 * Ts * 4);
-        }
-    } else {
-        // ---------------- transition (gemm.hip EP_LYNX_NEXT; lynxnet.py:76-84 of the next layer), row-major ----------------
-        const int row0 = 512 * mu + 128 * wave;
-        const __amdgpu_buffer_rsrc_t r_a = rsrc(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
-        const __amdgpu_buffer_rsrc_t r_c = rsrc((p.cpn ? p.cpn : p.x) + (long)bu * (p.cpn ? p.cpn_bstride : p.x_bstride) + (long)row0 * Ts + t0u);
-        f32x4 aux[16], cpv[16];
+                    for (int r = 0; r < 4; ++r) {
+                        const float u0 = acc[2 * i][2 * hf + n][r] + bo[2 * i][r];
+                        const float u1 = acc[2 * i + 1][2 * hf + n][r] + bo[2 * i + 1][r];
+                        ew[(i * 16 + rq + r) * ES + n * 16 + lcol] = u0 * (u1 * sigmoid_f(u1));
+                    }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const dsd_i32x4 w_o = dsd_rsrc_words(p.u + (long)bu * p.u_bstride + (long)ch0 * Ts + th);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            aux[m] = ld4(r_a, ev0, m * 8 * Ts * 4);
-            cpv[m] = ld4(r_c, ev0, m * 8 * Ts * 4);
-        }
-        const float* tb = tbl;
-        const float* tf = tbl + 512;
-        float* ew = ep + wave * (128 * ES);
-#pragma unroll
-        for (int k = 0; k < MBW; ++k)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ew[(k * 16 + rq + r) * ES + n * 16 + lcol] = acc[k][n][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const dsd_i32x4 w_xo = dsd_rsrc_words(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
-        const dsd_i32x4 w_xi = dsd_rsrc_words((p.xin_out ? p.xin_out : p.x) + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
-        f32x4 xi[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int idx = lane + 64 * m;
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]);
-            const float brow = tb[128 * wave + (idx >> 3)], frow = tf[128 * wave + (idx >> 3)];
-            f32x4 xo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = (a4[e] + brow) + aux[m][e];          // + bias, + residual (lynxnet.py:86)
-                float o = v, in = v;
-                if (p.cpn) {
-                    in = v + cpv[m][e];
-                    if (p.strong) o = in;
-                }
-                if (p.film) in = in + frow;
-                xo[e] = o;
-                xi[m][e] = in;
+            for (int m = 0; m < 8; ++m) {
+                const int idx = lane + 64 * m;
+                st4(*reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]), w_o, ev0, m * 8 * Ts * 4);
             }
-            st4(xo, w_xo, ev0, m * 8 * Ts * 4);
-            if (p.xin_out) st4(xi[m], w_xi, ev0, m * 8 * Ts * 4);
-        }
-        // LayerNorm partials of xin per 64-row tile (tiles 2w, 2w + 1 of this workgroup's 8): two passes over the registers
-        if (p.lnpart) {
+        } else {
+            // transition (gemm.hip EP_LYNX_NEXT; lynxnet.py:76-84 of the next layer), row-major
+            const int row0 = 512 * mu + 128 * wave;
+            const __amdgpu_buffer_rsrc_t r_a = rsrc(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + th);
+            const __amdgpu_buffer_rsrc_t r_c = rsrc((p.cpn ? p.cpn : p.x) + (long)bu * (p.cpn ? p.cpn_bstride : p.x_bstride) + (long)row0 * Ts + th);
+            f32x4 aux[16], cpv[16];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < 16; ++m) {
+                aux[m] = ld4(r_a, ev0, m * 8 * Ts * 4);
+                cpv[m] = ld4(r_c, ev0, m * 8 * Ts * 4);
+            }
+            const float* tb = tbl;
+            const float* tf = tbl + 512;
+            float* ew = ep + wave * (128 * ES);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) s += xi[8 * h + m];
+            for (int k = 0; k < MBW; ++k)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ew[(k * 16 + rq + r) * ES + n * 16 + lcol] = acc[k][2 * hf + n][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const dsd_i32x4 w_xo = dsd_rsrc_words(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + th);
+            const dsd_i32x4 w_xi = dsd_rsrc_words((p.xin_out ? p.xin_out : p.x) + (long)bu * p.x_bstride + (long)row0 * Ts + th);
+            f32x4 xi[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int idx = lane + 64 * m;
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]);
+                const float brow = tb[128 * wave + (idx >> 3)], frow = tf[128 * wave + (idx >> 3)];
+                f32x4 xo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    s[e] += __shfl_xor(s[e], 8, 64);
-                    s[e] += __shfl_xor(s[e], 16, 64);
-                    s[e] += __shfl_xor(s[e], 32, 64);
+                    const float v = (a4[e] + brow) + aux[m][e];      // + bias, + residual (lynxnet.py:86)
+                    float o = v, in = v;
+                    if (p.cpn) {
+                        in = v + cpv[m][e];
+                        if (p.strong) o = in;
+                    }
+                    if (p.film) in = in + frow;
+                    xo[e] = o;
+                    xi[m][e] = in;
                 }
-                const f32x4 mu4 = s * (1.f / 64.f);
-                f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+                st4(xo, w_xo, ev0, m * 8 * Ts * 4);
+                if (p.xin_out) st4(xi[m], w_xi, ev0, m * 8 * Ts * 4);
+            }
+            // LayerNorm partials of xin per 64-row tile (tiles 2w, 2w + 1 of this workgroup's 8): two passes over the registers
+            if (p.lnpart) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const f32x4 d = xi[8 * h + m] - mu4;
-                    q += d * d;
-                }
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 sm = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    q[e] += __shfl_xor(q[e], 8, 64);
-                    q[e] += __shfl_xor(q[e], 16, 64);
-                    q[e] += __shfl_xor(q[e], 32, 64);
-                }
-                if (lane < 8) {
-                    const int tile = 8 * mu + 2 * wave + h;
-                    float* lp = p.lnpart + ((long)bu * p.ln_tiles + tile) * 2 * p.lnpart_ts + t0u + lane * 4;
-                    *reinterpret_cast<f32x4*>(lp) = mu4;
-                    *reinterpret_cast<f32x4*>(lp + p.lnpart_ts) = q;
+                    for (int m = 0; m < 8; ++m) sm += xi[8 * h + m];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sm[e] += __shfl_xor(sm[e], 8, 64);
+                        sm[e] += __shfl_xor(sm[e], 16, 64);
+                        sm[e] += __shfl_xor(sm[e], 32, 64);
+                    }
+                    const f32x4 mu4 = sm * (1.f / 64.f);
+                    f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const f32x4 d = xi[8 * h + m] - mu4;
+                        q += d * d;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        q[e] += __shfl_xor(q[e], 8, 64);
+                        q[e] += __shfl_xor(q[e], 16, 64);
+                        q[e] += __shfl_xor(q[e], 32, 64);
+                    }
+                    if (lane < 8) {
+                        const int tile = 8 * mu + 2 * wave + h;
+                        float* lp = p.lnpart + ((long)bu * p.ln_tiles + tile) * 2 * p.lnpart_ts + th + lane * 4;
+                        *reinterpret_cast<f32x4*>(lp) = mu4;
+                        *reinterpret_cast<f32x4*>(lp + p.lnpart_ts) = q;
+                    }
                 }
             }
+        }
+        if (hf + 1 < NCB / 2) {                                  // the wave's tile is reused by the next half
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
 
-int lx_x3_lds_bytes(int kt) {
-    const int kp = kt < 1024 ? kt : 1024;
-    const int img = 2 * 32 * (kp + 8) * 2, ept = 4 * 128 * 36 * 4;
+int lx_x3_lds_bytes(int kt, int ncb) {
+    const int kp = ncb == 4 ? 512 : (kt < 1024 ? kt : 1024);
+    const int img = 2 * 16 * ncb * (kp + 8) * 2, ept = 4 * 128 * 36 * 4;
     return (img > ept ? img : ept) + 1024 * 4;
 }
 
 bool lx_x3_supported(int C, int inner) { return (C == 1024 && inner == 2048) || (C == 512 && inner == 1024); }
 
-template <int MODE, int KT, int RAG>
+template <int MODE, int KT, int RAG, int NCB>
 static hipError_t lx_x3_launch(const LxLayerP& p, int nwg, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lx_x3_kernel<MODE, KT, RAG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lx_x3_kernel<MODE, KT, RAG, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
     if (nwg == 0) return hipSuccess;
-    return launch_timed(lx_x3_kernel<MODE, KT, RAG>, dim3(nwg), dim3(256), lx_x3_lds_bytes(KT), st, p, "lx_x3_kernel<%d, %d, %d>", MODE, KT, RAG);
+    return launch_timed(lx_x3_kernel<MODE, KT, RAG, NCB>, dim3(nwg), dim3(256), lx_x3_lds_bytes(KT, NCB), st, p, "lx_x3_kernel<%d, %d, %d, %d>", MODE, KT, RAG, NCB);
 }
 
-// which = 0: pw1 (p.A1 = the bf16x3 stream), 1: pw2 (p.A2); p otherwise as for launch_lx_layer
-hipError_t launch_lx_x3(const LxLayerP& p, int which, int C, hipStream_t st) {
-    if (!lx_x3_supported(C, p.inner)) return hipErrorInvalidValue;
+// which = 0: pw1 (p.A1 = the bf16x3 stream), 1: pw2 (p.A2); ncb = 2: 32-frame tiles, 4: 64-frame tiles (p.tiles_per_b / nft / cgmap
+// count tiles of that width); p otherwise as for launch_lx_layer
+hipError_t launch_lx_x3(const LxLayerP& p, int which, int C, int ncb, hipStream_t st) {
+    if (!lx_x3_supported(C, p.inner) || (ncb != 2 && ncb != 4)) return hipErrorInvalidValue;
     const int nft = p.cgmap ? p.ncg : p.nft;
     const int nwg = nft * (which == 0 ? (2 * p.inner) / 512 : C / 512);
-#define LX3_CASE(MODE_, KT_) return p.cgmap ? lx_x3_launch<MODE_, KT_, 1>(p, nwg, st) : lx_x3_launch<MODE_, KT_, 0>(p, nwg, st);
+#define LX3_CASE(MODE_, KT_)                                                                                                   \
+    {                                                                                                                          \
+        if (ncb == 2) return p.cgmap ? lx_x3_launch<MODE_, KT_, 1, 2>(p, nwg, st) : lx_x3_launch<MODE_, KT_, 0, 2>(p, nwg, st);   \
+        return p.cgmap ? lx_x3_launch<MODE_, KT_, 1, 4>(p, nwg, st) : lx_x3_launch<MODE_, KT_, 0, 4>(p, nwg, st);                 \
+    }
     if (which == 0) {
-        if (C == 1024) { LX3_CASE(0, 1024) }
+        if (C == 1024) LX3_CASE(0, 1024)
         LX3_CASE(0, 512)
     }
-    if (p.inner == 2048) { LX3_CASE(1, 2048) }
+    if (p.inner == 2048) LX3_CASE(1, 2048)
     LX3_CASE(1, 1024)
 #undef LX3_CASE
 }
@@ -367,14 +389,15 @@ hipError_t lx_x3_init_all() {
     LxLayerP p{};
     hipError_t e;
     for (int C : {512, 1024})
-        for (int rag = 0; rag < 2; ++rag) {
-            p.inner = 2 * C;
-            p.cgmap = rag ? reinterpret_cast<const int*>(&p) : nullptr;
-            p.ncg = 0;
-            p.nft = 0;
-            if ((e = launch_lx_x3(p, 0, C, nullptr)) != hipSuccess) return e;
-            if ((e = launch_lx_x3(p, 1, C, nullptr)) != hipSuccess) return e;
-        }
+        for (int rag = 0; rag < 2; ++rag)
+            for (int ncb : {2, 4}) {
+                p.inner = 2 * C;
+                p.cgmap = rag ? reinterpret_cast<const int*>(&p) : nullptr;
+                p.ncg = 0;
+                p.nft = 0;
+                if ((e = launch_lx_x3(p, 0, C, ncb, nullptr)) != hipSuccess) return e;
+                if ((e = launch_lx_x3(p, 1, C, ncb, nullptr)) != hipSuccess) return e;
+            }
     return hipSuccess;
 }
 

@@ -412,7 +412,8 @@ int dsd_sample(dsd_handle* h, const dsd_program* prog, const float* x_init, cons
  * hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; activations, FiLM, gate, residual and skip
  * arithmetic stay fp32.  Measured against the fp32 oracle: 9.9e-6 on one evaluation, 1.9e-6 on the 50-NFE DPM-Solver++
  * sample (tools/bf16x3_tolerance.py; asserted on the GPU in tests/test_gpu_bf16x3.py at the fp32 tolerances).  Exists for the
- * fused WaveNet layer kernel at C = 256 (batched grids); other shapes and kernels run fp32 whatever the mode.  Also set for
+ * fused WaveNet layer kernel at C = 256 (batched grids) and for LYNXNet's two pointwise GEMMs at C = 1024 / 512 with
+ * expansion 2; other shapes and kernels run fp32 whatever the mode.  Also set for
  * every handle of the process by the environment variable DSD_PRECISION=1 at dsd_create.  May be called at any time; after
  * dsd_finalize_weights it re-packs the weights.
  */
