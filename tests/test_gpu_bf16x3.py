@@ -19,7 +19,7 @@ from oracle import diffusion as od  # noqa: E402
 
 TOL_NFE = 2e-5
 TOL_SAMPLER = 1.5e-5
-SWITCHES = ("DSD_FUSED_LAYER", "DSD_WN_PLAN", "DSD_PRECISION")
+SWITCHES = ("DSD_FUSED_LAYER", "DSD_WN_PLAN", "DSD_PRECISION", "DSD_X3_WIDE", "DSD_LYNX_RESIDENT")
 
 
 @pytest.fixture(autouse=True)
@@ -142,10 +142,12 @@ LX_NETS = {
 }
 
 
-def _lx_case(net_name, bsz, t_len, lengths, expect_pw2_x3, force_resident):
+def _lx_case(net_name, bsz, t_len, lengths, expect_pw2_x3, force_resident, wide=None):
     args = LX_NETS[net_name]
     if force_resident:
         os.environ["DSD_LYNX_RESIDENT"] = "1"
+    if wide is not None:
+        os.environ["DSD_X3_WIDE"] = "1" if wide else "0"
     try:
         net, params = make_backbone("lynxnet", 128, 1, args, 59)
         x = synth.synth_normal((bsz, 1, 128, t_len), 21)
@@ -161,6 +163,8 @@ def _lx_case(net_name, bsz, t_len, lengths, expect_pw2_x3, force_resident):
         net.kernel_timing(False)
         assert any(n.startswith("lx_x3_kernel<0") for n in names), names
         assert any(n.startswith("lx_x3_kernel<1") for n in names) == expect_pw2_x3, names
+        if wide is not None:                                     # ", 4>" = 64-frame tiles, ", 2>" = 32-frame tiles
+            assert all(n.endswith(", 4>" if wide else ", 2>") for n in names if n.startswith("lx_x3_kernel")), names
         fwd = lambda xx, tt, cc: ob.lynxnet_forward(params, xx, tt, cc, activation=args["activation"], strong_cond=args["strong_cond"])   # noqa: E731
         if lengths is None:
             check(out, fwd(x, t, cond), TOL_NFE, what=("lynx bf16x3", net_name, bsz, t_len))
@@ -173,17 +177,30 @@ def _lx_case(net_name, bsz, t_len, lengths, expect_pw2_x3, force_resident):
         net.release_native()
     finally:
         os.environ.pop("DSD_LYNX_RESIDENT", None)
+        os.environ.pop("DSD_X3_WIDE", None)
 
 
 @pytest.mark.parametrize("net_name", sorted(LX_NETS))
 def test_lynx_bf16x3_small_grid_vs_oracle(net_name):
     """pw1 in split-bf16 (forced onto a grid the oracle handles; pw2 stays on the fp32 one-utterance kernels), cut tile, ragged"""
-    _lx_case(net_name, 2, 211, None, False, True)
-    _lx_case(net_name, 3, 200, [200, 77, 141], False, True)
+    _lx_case(net_name, 2, 211, None, False, True, wide=False)
+    _lx_case(net_name, 3, 200, [200, 77, 141], False, True, wide=False)
+
+
+@pytest.mark.parametrize("net_name", sorted(LX_NETS))
+def test_lynx_bf16x3_wide_tiles_vs_oracle(net_name):
+    """64-frame tiles (the weight stream serves twice the frames) forced at small sizes: tiles cut by the utterance end inside the
+    first and the second 32-frame half, a ragged batch on the 64-frame tile list; pw2 too where the grid gives it (forced grids
+    run pw1 only - the batched test below covers pw2)"""
+    _lx_case(net_name, 2, 211, None, False, True, wide=True)
+    _lx_case(net_name, 1, 90, None, False, True, wide=True)
+    _lx_case(net_name, 3, 200, [200, 77, 141], False, True, wide=True)
 
 
 def test_lynx_bf16x3_batched_grid_vs_oracle():
     """both pointwise GEMMs in split-bf16 on grids that give pw2 half a chip of workgroups: C = 1024 at 2 x 1000 frames (64 frame
     tiles x 2 row tiles), the class-default C = 512 at 5 x 1000 frames"""
-    _lx_case("c1024_strong", 2, 1000, None, True, False)
-    _lx_case("c512_default", 5, 1000, None, True, False)
+    _lx_case("c1024_strong", 2, 1000, None, True, False, wide=False)
+    _lx_case("c512_default", 5, 1000, None, True, False, wide=False)
+    _lx_case("c1024_strong", 2, 1000, None, True, False, wide=True)          # both GEMMs on 64-frame tiles
+    _lx_case("c512_default", 5, 1000, None, True, False, wide=True)
