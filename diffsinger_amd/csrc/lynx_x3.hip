@@ -17,6 +17,10 @@
 
 #include "dsd_internal.h"
 
+#ifndef DSD_X3_DIAG
+#define DSD_X3_DIAG 0       // 1 / 2: timing diagnostics (wrong results) - the K walk without its MFMAs / without its weight stream
+#endif
+
 namespace dsd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -106,7 +110,11 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
     const __amdgpu_buffer_rsrc_t r_w = rsrc(reinterpret_cast<const unsigned char*>(MODE == 0 ? p.A1 : p.A2) + ((long)mu * 4 + wave) * NB * 2048);
     bf16x8 Whi[RB], Wlo[RB];
     auto w_issue = [&](int i) {
+#if DSD_X3_DIAG == 2
+        if (i < RB) {                                            // diagnostic: no weight stream after the ring fill
+#else
         if (i < NB) {
+#endif
             Whi[i % RB] = ldw(r_w, lane * 16, i * 2048);
             Wlo[i % RB] = ldw(r_w, lane * 16, i * 2048 + 1024);
         }
@@ -215,7 +223,15 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
 #pragma unroll
             for (int k = 0; k < MBW; ++k) {
                 const int i = (ph * NSP + s) * MBW + k;
+#if DSD_X3_DIAG == 1
+                {                                                // diagnostic: the stream and the LDS reads without the MFMAs
+                    const f32x4 wv = __builtin_bit_cast(f32x4, Whi[i % RB]) + __builtin_bit_cast(f32x4, Wlo[i % RB]);
+#pragma unroll
+                    for (int n = 0; n < NCB; ++n) acc[k][n] += wv + __builtin_bit_cast(f32x4, bh[n]) + __builtin_bit_cast(f32x4, bl[n]);
+                }
+#else
                 x3_products<NCB>(acc[k], Whi[i % RB], Wlo[i % RB], bh, bl);
+#endif
                 w_issue(i + RB);
                 __builtin_amdgcn_sched_barrier(0);               // (pinned: see wn_layer_x3.hip)
             }

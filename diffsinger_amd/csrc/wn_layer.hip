@@ -73,7 +73,7 @@ extern "C" int dsd_dbg_read_wn_stamps(unsigned long long* host_out) {
 }
 #endif
 
-// NCH = C / 64 (3: multi-variance nets, 4: acoustic / pitch nets); SW = LDS row stride of the x tile in floats,
+// NCH = C / 64 (3: multi-variance nets, 4: acoustic / pitch nets, 2: C = 128 nets); SW = LDS row stride of the x tile in floats,
 // 48 (halo 8: dilation <= 8) or 80 (halo 16: dilation 16), both 16 (mod 32) so the 4 k-rows x 16 columns of a B
 // fragment read hit 64 distinct banks; RAG = 1: ragged batch (valid-tile list + per-item lengths, as in gemm.hip).
 template <int NCH, int SW, int RAG>
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
 
 int wn_layer_lds_bytes(int nch, int sw) { return (64 * nch * sw + 4 * 16 * 2 * nch * 36) * 4; }
 
-bool wn_layer_supported(int C, int dil) { return (C == 256 || C == 192) && dil >= 1 && dil <= 16; }
+bool wn_layer_supported(int C, int dil) { return (C == 256 || C == 192 || C == 128) && dil >= 1 && dil <= 16; }
 
 template <int NCH, int SW, int RAG>
 static hipError_t wn_launch(const WnLayerP& p, int ntiles, hipStream_t st) {
@@ -479,6 +479,8 @@ hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st) 
     WN_CASE(4, 80)
     WN_CASE(3, 48)
     WN_CASE(3, 80)
+    WN_CASE(2, 48)
+    WN_CASE(2, 80)
 #undef WN_CASE
     return hipErrorInvalidValue;
 }
@@ -494,6 +496,8 @@ hipError_t wn_layer_init_all() {
     WN_INIT(4, 80)
     WN_INIT(3, 48)
     WN_INIT(3, 80)
+    WN_INIT(2, 48)
+    WN_INIT(2, 80)
 #undef WN_INIT
     return hipSuccess;
 }

@@ -42,12 +42,14 @@ def _clean_env():
             os.environ[k] = saved[k]
 
 
-# (in_dims, n_feats, backbone args): the four (C, halo) shapes of the kernel
+# (in_dims, n_feats, backbone args): the six (C, halo) shapes of the kernel
 NETS = {
     "c256_cyc4": (128, 1, dict(num_layers=5, num_channels=256, dilation_cycle_length=4)),       # <4, 48>: dilation 1..8
     "c256_cyc5": (64, 1, dict(num_layers=6, num_channels=256, dilation_cycle_length=5)),        # <4, 80> in layer 4 (dilation 16)
     "c192_cyc4": (24, 2, dict(num_layers=5, num_channels=192, dilation_cycle_length=4)),        # <3, 48>
     "c192_cyc5": (24, 2, dict(num_layers=6, num_channels=192, dilation_cycle_length=5)),        # <3, 80>
+    "c128_cyc4": (80, 1, dict(num_layers=5, num_channels=128, dilation_cycle_length=4)),        # <2, 48>
+    "c128_cyc5": (80, 1, dict(num_layers=6, num_channels=128, dilation_cycle_length=5)),        # <2, 80>
 }
 # (B, T, lengths): T cut inside a tile, T < dilation (a tile that is all halo on one side), several tiles, ragged lists
 GRIDS = {
