@@ -115,8 +115,8 @@ __device__ __forceinline__ void edge_walk(f32x4 (&acc)[MB][NCB], f32x4 (&W)[D][M
 
 }  // namespace
 
-// NCH = C / 64 (3, 4); FMB = 16-row blocks of the F*M output rows (8: 128 mel bins, 4: 64 pitch bins, 3: 2 x 24 variance
-// bins); NCB = 16-frame column blocks per tile (2: batched grids, 1: one-utterance grids); RAG: ragged batch (tile list)
+// NCH = C / 64 (2, 3, 4); FMB = 16-row blocks of the F*M output rows (8: 128 mel bins, 5: 80 mel bins, 4: 64 pitch bins,
+// 3: 2 x 24 variance bins); NCB = 16-frame column blocks per tile (2: batched grids, 1: one-utterance grids); RAG: ragged batch (tile list)
 template <int NCH, int FMB, int NCB, int RAG>
 __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
     const __amdgpu_buffer_rsrc_t r_w2 = rsrc(p.A2);
     int wk2[MB2];
 #pragma unroll
-    for (int k = 0; k < MB2; ++k) wk2[k] = wl + (wave * MB2 + k) * NS1 * 1024;
+    for (int k = 0; k < MB2; ++k) wk2[k] = wl + min(wave * MB2 + k, FMB - 1) * NS1 * 1024;      // (FMB = 5: the last wave's second block does not exist)
     f32x4 W2[D2][MB2];
 
     // ---------------- h = relu(W1 s + b1) -> LDS ----------------
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
                 const float cm = cmv[o];
                 float* po = pT + o * K3 * PS;
 #pragma unroll
-                for (int k = 0; k < MB2; ++k)
+                for (int k = 0; k < MB2; ++k) {
+                    if (FMB % MB2 != 0 && wave * MB2 + k >= FMB) continue;      // (wave-uniform; a row block past F*M has no LDS rows)
 #pragma unroll
                     for (int n = 0; n < NCB; ++n)
 #pragma unroll
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(256, 1) void wn_edge_kernel(const WnEdgeP p) {
                             *q = v;
                             if (o == next_src) sT[row * BNW + ((n * 16 + lcol) ^ swz(row))] = v;
                         }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -400,7 +402,7 @@ int wn_edge_lds_bytes(int C, int fmb, int ncb) {
     return (2 * C * bnw + sums > C * bnw + ep ? 2 * C * bnw + sums : C * bnw + ep) * 4;      // rows run from the h tile into them
 }
 
-bool wn_edge_supported(int C, int FM) { return (C == 256 || C == 192) && (FM == 128 || FM == 64 || FM == 48); }
+bool wn_edge_supported(int C, int FM) { return (C == 256 || C == 192 || C == 128) && (FM == 128 || FM == 80 || FM == 64 || FM == 48); }
 
 template <int NCH, int FMB, int NCB, int RAG>
 static hipError_t edge_launch(const WnEdgeP& p, int nwg, hipStream_t st) {
@@ -433,14 +435,20 @@ hipError_t launch_wn_edge(const WnEdgeP& p, int C, int ncb, int nwg, hipStream_t
     if (C == 256 && p.FM == 48) return edge_dispatch<4, 3>(p, ncb, nwg, st);
     if (C == 192 && p.FM == 128) return edge_dispatch<3, 8>(p, ncb, nwg, st);
     if (C == 192 && p.FM == 64) return edge_dispatch<3, 4>(p, ncb, nwg, st);
+    if (C == 256 && p.FM == 80) return edge_dispatch<4, 5>(p, ncb, nwg, st);
+    if (C == 192 && p.FM == 80) return edge_dispatch<3, 5>(p, ncb, nwg, st);
+    if (C == 128 && p.FM == 128) return edge_dispatch<2, 8>(p, ncb, nwg, st);
+    if (C == 128 && p.FM == 80) return edge_dispatch<2, 5>(p, ncb, nwg, st);
+    if (C == 128 && p.FM == 64) return edge_dispatch<2, 4>(p, ncb, nwg, st);
+    if (C == 128 && p.FM == 48) return edge_dispatch<2, 3>(p, ncb, nwg, st);
     return hipErrorInvalidValue;
 }
 
 hipError_t wn_edge_init_all() {
     WnEdgeP p{};
     hipError_t e;
-    for (int C : {256, 192})
-        for (int fm : {128, 64, 48})
+    for (int C : {256, 192, 128})
+        for (int fm : {128, 80, 64, 48})
             for (int ncb = 2; ncb <= 2; ++ncb)
                 for (int rag = 0; rag < 2; ++rag) {
                     p.FM = fm;

@@ -127,3 +127,62 @@ def test_edge_kernel_ragged_shallow_and_ancestral_fallback():
     check(got, want.cpu().numpy(), 2e-6, what="ancestral DDPM, 20 steps with injected noise")
     on.denoise_fn.release_native()
     off.denoise_fn.release_native()
+
+
+# the shapes added in round 3: C = 128 with every F*M the kernel has, and 80 mel bins (five 16-row blocks over four waves: the
+# last wave's second block does not exist) at every C
+WIDE_SHAPES = [(128, 128), (128, 80), (128, 64), (128, 48), (256, 80), (192, 80)]
+
+
+@pytest.mark.parametrize("shape", WIDE_SHAPES, ids=lambda s: f"c{s[0]}_fm{s[1]}")
+def test_edge_kernel_c128_and_80_bins_vs_three_gemms_and_oracle(shape):
+    from diffsinger_amd.diffusion import GaussianDiffusion
+    from oracle import backbones as ob
+    c, fm = shape
+    n_feats = 2 if fm == 48 else 1
+    in_dims = fm // n_feats
+    args = dict(num_layers=3, num_channels=c, dilation_cycle_length=3)
+    set_hp(K_step_infer=1000, diff_accelerator="dpm-solver", diff_speedup=100)
+    kw = dict(spec_min=[-12.0], spec_max=[0.0])
+    if n_feats == 1:
+        on, off = _pair(GaussianDiffusion, in_dims, 1, args, **kw)
+        net_on, net_off = on.denoise_fn, off.denoise_fn
+        cond = dev(synth.synth_normal((3, 150, 256), 70))
+        noise = dev(synth.synth_normal((3, 1, in_dims, 150), 71))
+        lens = [150, 61, 97]
+        with _edge("0"):
+            want = off(cond, infer=True, noise=noise)
+            want_r = off(cond, infer=True, noise=noise, lengths=lens)
+        with _edge("1"):
+            got = on(cond, infer=True, noise=noise)
+            assert net_on.stats()["kernels_per_nfe"] in (2 * 3 + 1, 3 + 1), net_on.stats()
+            got_r = on(cond, infer=True, noise=noise, lengths=lens)
+        check(got, want.cpu().numpy(), 2e-6, what=("edge kernel vs three GEMMs", shape))
+        for b, n in enumerate(lens):
+            check(got_r[b, :n], want_r[b, :n].cpu().numpy(), 2e-6, what=("edge kernel vs three GEMMs, ragged item", shape, b))
+    else:
+        from diffsinger_amd.diffusion import MultiVarianceRectifiedFlow
+        set_hp(sampling_algorithm="euler", sampling_steps=6)
+        mk = lambda i, f, **k2: MultiVarianceRectifiedFlow(ranges=[(-96.0, -12.0), (-96.0, -20.0)], clamps=[(-96.0, 0.0), (-96.0, 0.0)],  # noqa: E731
+                                                           repeat_bins=24, **k2)
+        on, off = _pair(mk, 24, 2, args)
+        net_on, net_off = on.velocity_fn, off.velocity_fn
+        cond = dev(synth.synth_normal((2, 133, 256), 50))
+        noise = dev(synth.synth_normal((2, 2, 24, 133), 52))
+        with _edge("0"):
+            want = off(cond, infer=True, noise=noise)
+        with _edge("1"):
+            got = on(cond, infer=True, noise=noise)
+        for g, w in zip(got, want):
+            check(g, w.cpu().numpy(), 2e-6, what=("multi-variance reflow", shape))
+    # one evaluation of the backbone itself against the oracle with the edge kernel forced
+    params = synth_params("wavenet", in_dims, n_feats, args, 42)
+    x = synth.synth_normal((2, n_feats, in_dims, 77), 81)
+    cnd = synth.synth_normal((2, 256, 77), 82)
+    t = np.array([12.0, 700.5], np.float32)
+    with _edge("1"):
+        with torch.no_grad():
+            out = net_on(dev(x), dev(t), dev(cnd))
+    check(out, ob.wavenet_forward(params, x, t, cnd, dilation_cycle_length=3), 1.5e-5, what=("edge forced, one evaluation vs oracle", shape))
+    net_on.release_native()
+    net_off.release_native()
