@@ -17,6 +17,8 @@ SOURCES = ["gemm.hip", "wn_layer.hip", "wn_layer_x3.hip", "wn_rowsplit.hip", "wn
 HEADERS = [os.path.join(CSRC, "dsd_internal.h"), os.path.join(os.path.dirname(HERE), "include", "dsdenoise.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# per file: lynx_x3.hip's fully unrolled K walks (512 row blocks of ~60 IR instructions) are past the default budget of `#pragma unroll`
+FILE_FLAGS = {"lynx_x3.hip": ["-mllvm", "-pragma-unroll-threshold=262144"]}
 FLAGS += os.environ.get("DSD_EXTRA_HIPCC_FLAGS", "").split()      # diagnostic A/B builds (e.g. -DDSD_ST_AUX=0)
 
 
@@ -35,7 +37,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -1845,8 +1845,8 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             // ... on 64-frame tiles where those still fill the chip: the same weight stream then serves twice the frames
             const long lx_t64 = lx_ragged ? (long)h->cg_n[2] : (long)B * ((T + 63) / 64);
             const int xw = path_opts().x3_wide;
-            const bool wide1 = x3 && xw != 0 && (xw == 1 || lx_t64 * (2 * inner / 512) >= h->cus);
-            const bool wide2 = x3_pw2 && xw != 0 && (xw == 1 || lx_t64 * (C / 512) >= h->cus);
+            const bool wide1 = x3 && xw != 0 && (xw >= 1 || lx_t64 * (2 * inner / 512) >= h->cus);
+            const bool wide2 = x3_pw2 && xw != 0 && (xw >= 1 || lx_t64 * (C / 512) >= h->cus);
             auto widen = [&](LxLayerP& q) {                      // the tile bookkeeping of a launch on 64-frame tiles
                 q.tiles_per_b = (T + 63) / 64;
                 q.inv_tiles_per_b = 1.0f / (float)q.tiles_per_b;
@@ -1860,7 +1860,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                 q.A1 = h->blob + h->x3_conv[l];
                 if (wide1) widen(q);
                 timed_begin(650 + (wide1 ? 1 : 0), lx_fl1 * lx_fr, lx_by1 * lx_fr);
-                le = launch_lx_x3(q, 0, C, wide1 ? 4 : 2, st);
+                le = launch_lx_x3(q, 0, C, wide1 ? (xw == 2 ? 5 : 4) : 2, st);
                 timed_end();
             } else {
                 timed_begin(600, lx_fl1 * lx_fr, lx_by1 * lx_fr);
@@ -1877,7 +1877,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                 q.A2 = h->blob + h->x3_out[l];
                 if (wide2) widen(q);
                 timed_begin(660 + (wide2 ? 1 : 0), lx_fl2 * lx_fr, lx_by2 * lx_fr);
-                le = launch_lx_x3(q, 1, C, wide2 ? 4 : 2, st);
+                le = launch_lx_x3(q, 1, C, wide2 ? (xw == 2 ? 5 : 4) : 2, st);
                 timed_end();
                 if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw2 (bf16x3) launch failed: %s", hipGetErrorString(le));
             } else if (lx_res2 && path_opts().lynx_pw2q != 1) {

@@ -17,11 +17,35 @@
 
 #include "dsd_internal.h"
 
+#ifndef DSD_X3W_VARIANT
+#define DSD_X3W_VARIANT 0   // diagnostics: 1 = the phases staged by ordinary loads + LDS writes at the phase switch; 2 = no operand pipelining
+#endif
+#ifndef DSD_X3W_DRAIN
+#define DSD_X3W_DRAIN 1     // 1: every vector load of the wave has returned before a phase barrier (see lx_x3w_kernel)
+#endif
 #ifndef DSD_X3_DIAG
 #define DSD_X3_DIAG 0       // 1 / 2: timing diagnostics (wrong results) - the K walk without its MFMAs / without its weight stream
 #endif
 
 namespace dsd {
+
+#ifdef DSD_STAMPS
+// [pw1 / pw2][workgroup][0..7]: s_memtime at the phase boundaries of wave 0 (tools/stamp_lynx_x3.py)
+__device__ unsigned long long g_x3_stamps[2][4096][8];
+#define X3_STAMP(i)                                                                     \
+    do {                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                    \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+            g_x3_stamps[MODE][blockIdx.x][i] = __builtin_amdgcn_s_memtime();            \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+        }                                                                               \
+    } while (0)
+extern "C" int dsd_dbg_read_x3_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x3_stamps), sizeof(g_x3_stamps));
+}
+#else
+#define X3_STAMP(i)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -105,6 +129,7 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
     const int Ts = p.Ts;
     const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
     const int mu = __builtin_amdgcn_readfirstlane(mtile);
+    X3_STAMP(0);
 
     // ---------------- weight stream of this wave; ring fill ----------------
     const __amdgpu_buffer_rsrc_t r_w = rsrc(reinterpret_cast<const unsigned char*>(MODE == 0 ? p.A1 : p.A2) + ((long)mu * 4 + wave) * NB * 2048);
@@ -194,8 +219,10 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
         tbl[512 + tid] = f0;
         tbl[768 + tid] = f1;
     }
+    X3_STAMP(1);
     stage(0);
     __syncthreads();
+    X3_STAMP(2);
 
     // ---------------- K walk: NPH resident phases of NSP k32 steps ----------------
     f32x4 acc[MBW][NCB];
@@ -207,9 +234,11 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         if (ph > 0) {
+            X3_STAMP(5);                                         // (the last phase switch survives)
             __syncthreads();                                     // every wave is done with the previous phase's images
             stage(ph);
             __syncthreads();
+            X3_STAMP(6);
         }
 #pragma unroll
         for (int s = 0; s < NSP; ++s) {
@@ -237,6 +266,7 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
             }
         }
     }
+    X3_STAMP(3);
     __syncthreads();                                             // the images are dead: the epilogue tiles go over them
 
     // ---------------- epilogues: one 32-frame half of the tile at a time (hf), through the wave's LDS tile ----------------
@@ -359,7 +389,376 @@ __global__ __launch_bounds__(256, 1) void lx_x3_kernel(const LxLayerP p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+    X3_STAMP(4);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The 64-frame tile, second build (lx_x3w_kernel): NO staging phase.  lx_x3_kernel<.., 4> spent 26 % of a pw1 workgroup's life
+// (two phases x ~10-16 k cycles: 128 wave-loads, the split, the LDS writes, two barriers - tools/stamp_lynx_x3.py) staging
+// transposed bf16 images with the MFMA pipe idle.  Here the tile stays what it is in memory - fp32 [channel][64 frames], phases
+// of 256 channels, two 64 KiB buffers - and
+//   * travels by LDS-direct loads (buffer_load_dwordx4 ... lds: no registers, no VALU, no ds_write), the next phase's 16
+//     wave-loads issued one per row block behind the MFMAs of the current phase's first two steps;
+//   * column block n of the MFMA tile is frames {4 j + n}: a lane's B operands of a k32 step - 8 channels x its 4 frames - are
+//     8 ds_read_b128 of the raw tile (16 lanes x 16 B = one 256-byte row: conflict-free without padding);
+//   * the hi / lo split (and pw1's mean subtraction; 1 / sigma moves to the epilogue: W ((x - m) r) = r W (x - m)) runs on the
+//     VALU between the MFMAs of the step before, one frame per row block.
+// In-order return of vector loads makes a wave's LDS-direct data visible to itself once any younger ring load has been waited
+// for; one barrier per phase publishes it to the other waves.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void dma_b128(dsd_i32x4 rsrc_words, unsigned lds_byte, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte), "v"(voff), "s"(rsrc_words), "s"(soff)
+                 : "memory");      // (m0 is not allocatable: nothing else in this kernel uses it)
+}
+}  // namespace
+
+template <int MODE, int KT, int RAG>
+__global__ __launch_bounds__(256, 1) void lx_x3w_kernel(const LxLayerP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int NCB = 4, BNW = 64;
+    constexpr int KP = 256, NPH = KT / KP, NSP = KP / 32, NST = KT / 32, NB = NST * MBW, RB = 14;
+    constexpr int BUF_F = KP * BNW;                  // floats of one phase buffer (64 KiB)
+    constexpr int EW = BNW + 4;                      // epilogue tile row stride
+    float* raw = reinterpret_cast<float*>(lds_raw);  // [2][KP][64]
+    float* ep = raw;                                 // epilogue tiles over the dead buffers: [4 waves][64][EW]
+    float* tbl = raw + 2 * BUF_F;                    // pw2: bias [512], step-projection scalar [512]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
+    const int work = xcd_work();
+    const int nft = RAG ? p.ncg : p.nft;
+    const int mtile = fdiv_floor(work, p.inv_nft);
+    const int ft = work - mtile * nft;
+    const int rest = RAG ? p.cgmap[ft] : ft;
+    const int b = fdiv_floor(rest, p.inv_tiles_per_b);
+    const int t0 = (rest - b * p.tiles_per_b) * BNW;
+    const int Ts = p.Ts;
+    const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
+    const int mu = __builtin_amdgcn_readfirstlane(mtile);
+    X3_STAMP(0);
+
+    // ---------------- weight stream of this wave; ring fill ----------------
+    const __amdgpu_buffer_rsrc_t r_w = rsrc(reinterpret_cast<const unsigned char*>(MODE == 0 ? p.A1 : p.A2) + ((long)mu * 4 + wave) * NB * 2048);
+    bf16x8 Whi[RB], Wlo[RB];
+    auto w_issue = [&](int i) {
+        if (i < NB) {
+            Whi[i % RB] = ldw(r_w, lane * 16, i * 2048);
+            Wlo[i % RB] = ldw(r_w, lane * 16, i * 2048 + 1024);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < RB; ++i) w_issue(i);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------- the tile's phases by LDS-direct loads: wave w moves channels [64 w, 64 w + 64) of a phase, 4 rows a load ----
+    const dsd_i32x4 w_in = dsd_rsrc_words(MODE == 0 ? p.xin + (long)bu * p.x_bstride + t0u : p.v + (long)bu * p.u_bstride + t0u);
+    const int dvoff = ((64 * wave + lrow) * Ts + lcol * 4) * 4;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)raw;
+#if DSD_X3W_VARIANT == 1
+    const __amdgpu_buffer_rsrc_t r_in = MODE == 0 ? rsrc(p.xin + (long)bu * p.x_bstride + t0u) : rsrc(p.v + (long)bu * p.u_bstride + t0u);
+    auto dma = [&](int ph, int j) {};
+    auto stage_sync = [&](int ph) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const f32x4 t4 = ld4(r_in, dvoff, (ph * KP + 4 * j) * Ts * 4);
+            *reinterpret_cast<f32x4*>(&raw[(ph & 1) * BUF_F + (64 * wave + 4 * j + lrow) * BNW + lcol * 4]) = t4;
+        }
+    };
+    stage_sync(0);
+#else
+    auto dma = [&](int ph, int j) {                              // load j (of 16) of phase ph -> buffer ph & 1
+        dma_b128(w_in, lds0 + (unsigned)(((ph & 1) * BUF_F + (64 * wave + 4 * j) * BNW) * 4), dvoff, (ph * KP + 4 * j) * Ts * 4);
+    };
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dma(0, j);
+#endif
+
+    f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, rstd = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (MODE == 0) {
+        // LayerNorm statistics of the lane's four frames from the producer's per-64-row partials (ln_merge_kernel's arithmetic; the
+        // four lane groups that share the frames take a quarter of the partial tiles each and meet by shuffles: 8 loads per lane)
+#if DSD_X3W_VARIANT == 3
+        constexpr int NT = KT / 64;
+        const __amdgpu_buffer_rsrc_t r_p = rsrc(p.lnpart_in + (long)bu * NT * 2 * p.lnpart_ts + t0u);
+        f32x4 sm = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NT; ++i) sm += 64.f * ld4(r_p, lcol * 16, i * 2 * p.lnpart_ts * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mean[e] = sm[e] / (float)KT;
+        f32x4 m2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const f32x4 d = ld4(r_p, lcol * 16, i * 2 * p.lnpart_ts * 4) - mean;
+            m2 += ld4(r_p, lcol * 16, (i * 2 + 1) * p.lnpart_ts * 4) + 64.f * d * d;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(m2[e] / (float)KT + 1e-5f);
+    }
+#else
+        constexpr int NT = KT / 64, NQ = NT / 4;
+        const __amdgpu_buffer_rsrc_t r_p = rsrc(p.lnpart_in + (long)bu * NT * 2 * p.lnpart_ts + t0u);
+        f32x4 pm[NQ], pq[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            pm[i] = ld4(r_p, (lrow * NQ * 2 * p.lnpart_ts + lcol * 4) * 4, i * 2 * p.lnpart_ts * 4);
+            pq[i] = ld4(r_p, (lrow * NQ * 2 * p.lnpart_ts + lcol * 4) * 4, (i * 2 + 1) * p.lnpart_ts * 4);
+        }
+        f32x4 sm = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) sm += 64.f * pm[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sm[e] += __shfl_xor(sm[e], 16, 64);
+            sm[e] += __shfl_xor(sm[e], 32, 64);
+            mean[e] = sm[e] / (float)KT;
+        }
+        f32x4 m2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const f32x4 d = pm[i] - mean;
+            m2 += pq[i] + 64.f * d * d;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m2[e] += __shfl_xor(m2[e], 16, 64);
+            m2[e] += __shfl_xor(m2[e], 32, 64);
+            rstd[e] = 1.f / sqrtf(m2[e] / (float)KT + 1e-5f);
+        }
+    }
+#endif
+    if (MODE == 1) {                                             // bias and step-projection scalar of the workgroup's 512 rows
+        const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias2 + 512 * mu);
+        const float b0 = ld1(r_b, tid * 4, 0), b1 = ld1(r_b, tid * 4, 1024);
+        float f0 = 0.f, f1 = 0.f;
+        if (p.film) {
+            const __amdgpu_buffer_rsrc_t r_f = rsrc(p.film + p.film_col0 + bu * p.film_colb + (long)512 * mu * p.film_cstride);
+            f0 = ld1(r_f, tid * p.film_cstride * 4, 0);
+            f1 = ld1(r_f, (tid + 256) * p.film_cstride * 4, 0);
+        }
+        tbl[tid] = b0;
+        tbl[256 + tid] = b1;
+        tbl[512 + tid] = f0;
+        tbl[768 + tid] = f1;
+    }
+    X3_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // phase 0 has landed (this wave's part)
+    __syncthreads();
+    X3_STAMP(2);
+
+    // ---------------- K walk ----------------
+    f32x4 acc[MBW][NCB];
+#pragma unroll
+    for (int k = 0; k < MBW; ++k)
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) acc[k][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* rb0 = raw + (8 * lrow) * BNW + 4 * lcol;         // channel 8 lrow of a step, the lane's four frames
+    f32x4 vr[8];                                                 // raw operands of the NEXT step: vr[c][n] = x[channel c][frame n]
+    bf16x8 bh[NCB], bl[NCB], nh[NCB], nl[NCB];
+    auto read_raw = [&](int ph, int s, int c0, int c1) {
+#pragma unroll
+        for (int c = c0; c < c1; ++c) vr[c] = *reinterpret_cast<const f32x4*>(&rb0[(ph & 1) * BUF_F + (32 * s + c) * BNW]);
+    };
+    auto split = [&](int n, bf16x8& h8, bf16x8& l8) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            // (plain v_sub_f32 through asm: written as C++ the subtractions become v_pk_add_f32 with op_sel on register pairs
+            // assembled by v_mov, and the odd frames of the tile came out DIFFERENT FROM RUN TO RUN on MI355X - hipcc 7.2,
+            // tools/harness/x3_harness.hip; with scalar subtractions the kernel is repeatable and agrees with the first build)
+            float v = vr[c][n];
+            if (MODE == 0) asm("v_sub_f32_e32 %0, %1, %2" : "=v"(v) : "v"(vr[c][n]), "v"(mean[n]));
+            const __bf16 hv = (__bf16)v;
+            h8[c] = hv;
+            float lo;
+            asm("v_sub_f32_e32 %0, %1, %2" : "=v"(lo) : "v"(v), "v"((float)hv));
+            l8[c] = (__bf16)lo;
+        }
+    };
+    read_raw(0, 0, 0, 8);
+#pragma unroll
+    for (int n = 0; n < NCB; ++n) split(n, bh[n], bl[n]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+#pragma unroll
+        for (int s = 0; s < NSP; ++s) {
+#if DSD_X3W_VARIANT == 2
+            const bool more = false;
+            if (s > 0) {
+                read_raw(ph, s, 0, 8);
+#pragma unroll
+                for (int n = 0; n < NCB; ++n) split(n, bh[n], bl[n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
+            const bool more = s + 1 < NSP;                       // the next step is in this phase: its operands are prepared here
+#endif
+#pragma unroll
+            for (int k = 0; k < MBW; ++k) {
+                const int i = (ph * NSP + s) * MBW + k;
+                x3_products<NCB>(acc[k], Whi[i % RB], Wlo[i % RB], bh, bl);
+                w_issue(i + RB);
+                if (ph + 1 < NPH && s < 2) dma(ph + 1, s * MBW + k);     // the next phase travels behind steps 0 and 1
+                if (more && k == 0) read_raw(ph, s + 1, 0, 4);
+                if (more && k == 1) read_raw(ph, s + 1, 4, 8);
+                if (more && k >= 3 && k < 3 + NCB) split(k - 3, nh[k - 3], nl[k - 3]);
+                __builtin_amdgcn_sched_barrier(0);               // (pinned: see wn_layer_x3.hip)
+            }
+            if (more) {
+#pragma unroll
+                for (int n = 0; n < NCB; ++n) {
+                    bh[n] = nh[n];
+                    bl[n] = nl[n];
+                }
+            }
+        }
+        if (ph + 1 < NPH) {
+            // every wave's part of phase ph + 1 has landed (its loads are older than ring loads this wave has consumed), and
+            // every wave is done reading buffer ph & 1, which phase ph + 2 will overwrite
+            X3_STAMP(5);
+#if DSD_X3W_DRAIN
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if DSD_X3W_VARIANT == 1
+            stage_sync(ph + 1);
+#endif
+            __syncthreads();
+            read_raw(ph + 1, 0, 0, 8);
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) split(n, bh[n], bl[n]);
+            __builtin_amdgcn_sched_barrier(0);
+            X3_STAMP(6);
+        }
+    }
+    X3_STAMP(3);
+    __syncthreads();                                             // the buffers are dead: the epilogue tiles go over them
+
+    // ---------------- epilogues: accumulator (row block k, frame 4 lcol + n) -> the wave's row-major LDS tile -> float4 rows ----------------
+    float* ew = ep + wave * (64 * EW);
+    const int ev0 = ((lane >> 4) * Ts + (lane & 15) * 4) * 4;    // lane's float4 of row (lane >> 4); + 4 rows per m
+    if (MODE == 0) {
+        // 1 / sigma of the frame, bias, SwiGLU (common_layers.py:116-117: out * silu(gate))
+        const int ch0 = 256 * mu + 64 * wave;                    // first u channel of this wave
+        const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias1);
+        f32x4 bo[MBW];
+#pragma unroll
+        for (int k = 0; k < MBW; ++k) bo[k] = ld4(r_b, rq * 4, ((k & 1) * p.inner + ch0 + (k >> 1) * 16) * 4);
+#pragma unroll
+        for (int i = 0; i < MBW / 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 o;
+#pragma unroll
+                for (int n = 0; n < NCB; ++n) {
+                    const float u0 = acc[2 * i][n][r] * rstd[n] + bo[2 * i][r];
+                    const float u1 = acc[2 * i + 1][n][r] * rstd[n] + bo[2 * i + 1][r];
+                    o[n] = u0 * (u1 * sigmoid_f(u1));
+                }
+                *reinterpret_cast<f32x4*>(&ew[(i * 16 + rq + r) * EW + 4 * lcol]) = o;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const dsd_i32x4 w_o = dsd_rsrc_words(p.u + (long)bu * p.u_bstride + (long)ch0 * Ts + t0u);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int idx = lane + 64 * m;
+            st4(*reinterpret_cast<const f32x4*>(&ew[(idx >> 4) * EW + (idx & 15) * 4]), w_o, ev0, m * 4 * Ts * 4);
+        }
+    } else {
+        // transition (gemm.hip EP_LYNX_NEXT; lynxnet.py:76-84 of the next layer), row-major, one 64-row half (= one LayerNorm
+        // tile) of the wave's 128 rows at a time
+        const float* tb = tbl;
+        const float* tf = tbl + 512;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row0 = 512 * mu + 128 * wave + 64 * h;
+            const __amdgpu_buffer_rsrc_t r_a = rsrc(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+            const __amdgpu_buffer_rsrc_t r_c = rsrc((p.cpn ? p.cpn : p.x) + (long)bu * (p.cpn ? p.cpn_bstride : p.x_bstride) + (long)row0 * Ts + t0u);
+            f32x4 aux[16], cpv[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                aux[m] = ld4(r_a, ev0, m * 4 * Ts * 4);
+                cpv[m] = ld4(r_c, ev0, m * 4 * Ts * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x4 o;
+#pragma unroll
+                    for (int n = 0; n < NCB; ++n) o[n] = acc[4 * h + k][n][r];
+                    *reinterpret_cast<f32x4*>(&ew[(k * 16 + rq + r) * EW + 4 * lcol]) = o;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const dsd_i32x4 w_xo = dsd_rsrc_words(p.x + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+            const dsd_i32x4 w_xi = dsd_rsrc_words((p.xin_out ? p.xin_out : p.x) + (long)bu * p.x_bstride + (long)row0 * Ts + t0u);
+            f32x4 xi[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int idx = lane + 64 * m;
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ew[(idx >> 4) * EW + (idx & 15) * 4]);
+                const float brow = tb[128 * wave + 64 * h + (idx >> 4)], frow = tf[128 * wave + 64 * h + (idx >> 4)];
+                f32x4 xo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (a4[e] + brow) + aux[m][e];      // + bias, + residual (lynxnet.py:86)
+                    float o = v, in = v;
+                    if (p.cpn) {
+                        in = v + cpv[m][e];
+                        if (p.strong) o = in;
+                    }
+                    if (p.film) in = in + frow;
+                    xo[e] = o;
+                    xi[m][e] = in;
+                }
+                st4(xo, w_xo, ev0, m * 4 * Ts * 4);
+                if (p.xin_out) st4(xi[m], w_xi, ev0, m * 4 * Ts * 4);
+            }
+            // LayerNorm partials of xin over this 64-row tile: the lane holds rows (lane >> 4) + 4 m of its four frames
+            if (p.lnpart) {
+                f32x4 sm = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 16; ++m) sm += xi[m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sm[e] += __shfl_xor(sm[e], 16, 64);
+                    sm[e] += __shfl_xor(sm[e], 32, 64);
+                }
+                const f32x4 mu4 = sm * (1.f / 64.f);
+                f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const f32x4 d = xi[m] - mu4;
+                    q += d * d;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q[e] += __shfl_xor(q[e], 16, 64);
+                    q[e] += __shfl_xor(q[e], 32, 64);
+                }
+                if (lane < 16) {
+                    const int tile = 8 * mu + 2 * wave + h;
+                    float* lp = p.lnpart + ((long)bu * p.ln_tiles + tile) * 2 * p.lnpart_ts + t0u + lane * 4;
+                    *reinterpret_cast<f32x4*>(lp) = mu4;
+                    *reinterpret_cast<f32x4*>(lp + p.lnpart_ts) = q;
+                }
+            }
+            if (h == 0) {                                        // the wave's tile is reused by the second half
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+    X3_STAMP(4);
+}
+
+constexpr int kX3wLds = (2 * 256 * 64 + 1024) * 4;
 
 int lx_x3_lds_bytes(int kt, int ncb) {
     const int kp = ncb == 4 ? 512 : (kt < 1024 ? kt : 1024);
@@ -381,16 +780,30 @@ static hipError_t lx_x3_launch(const LxLayerP& p, int nwg, hipStream_t st) {
     return launch_timed(lx_x3_kernel<MODE, KT, RAG, NCB>, dim3(nwg), dim3(256), lx_x3_lds_bytes(KT, NCB), st, p, "lx_x3_kernel<%d, %d, %d, %d>", MODE, KT, RAG, NCB);
 }
 
-// which = 0: pw1 (p.A1 = the bf16x3 stream), 1: pw2 (p.A2); ncb = 2: 32-frame tiles, 4: 64-frame tiles (p.tiles_per_b / nft / cgmap
-// count tiles of that width); p otherwise as for launch_lx_layer
+template <int MODE, int KT, int RAG>
+static hipError_t lx_x3w_launch(const LxLayerP& p, int nwg, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lx_x3w_kernel<MODE, KT, RAG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    if (nwg == 0) return hipSuccess;
+    return launch_timed(lx_x3w_kernel<MODE, KT, RAG>, dim3(nwg), dim3(256), kX3wLds, st, p, "lx_x3w_kernel<%d, %d, %d>", MODE, KT, RAG);
+}
+
+// which = 0: pw1 (p.A1 = the bf16x3 stream), 1: pw2 (p.A2); ncb = 2: 32-frame tiles, 4: 64-frame tiles (lx_x3w_kernel; p.tiles_per_b /
+// nft / cgmap count tiles of that width), 5: 64-frame tiles on the first build (lx_x3_kernel<.., 4>: A/B only); p otherwise as for
+// launch_lx_layer
 hipError_t launch_lx_x3(const LxLayerP& p, int which, int C, int ncb, hipStream_t st) {
-    if (!lx_x3_supported(C, p.inner) || (ncb != 2 && ncb != 4)) return hipErrorInvalidValue;
+    if (!lx_x3_supported(C, p.inner) || (ncb != 2 && ncb != 4 && ncb != 5)) return hipErrorInvalidValue;
     const int nft = p.cgmap ? p.ncg : p.nft;
     const int nwg = nft * (which == 0 ? (2 * p.inner) / 512 : C / 512);
 #define LX3_CASE(MODE_, KT_)                                                                                                   \
     {                                                                                                                          \
         if (ncb == 2) return p.cgmap ? lx_x3_launch<MODE_, KT_, 1, 2>(p, nwg, st) : lx_x3_launch<MODE_, KT_, 0, 2>(p, nwg, st);   \
-        return p.cgmap ? lx_x3_launch<MODE_, KT_, 1, 4>(p, nwg, st) : lx_x3_launch<MODE_, KT_, 0, 4>(p, nwg, st);                 \
+        if (ncb == 5) return p.cgmap ? lx_x3_launch<MODE_, KT_, 1, 4>(p, nwg, st) : lx_x3_launch<MODE_, KT_, 0, 4>(p, nwg, st);   \
+        return p.cgmap ? lx_x3w_launch<MODE_, KT_, 1>(p, nwg, st) : lx_x3w_launch<MODE_, KT_, 0>(p, nwg, st);                     \
     }
     if (which == 0) {
         if (C == 1024) LX3_CASE(0, 1024)
@@ -406,7 +819,7 @@ hipError_t lx_x3_init_all() {
     hipError_t e;
     for (int C : {512, 1024})
         for (int rag = 0; rag < 2; ++rag)
-            for (int ncb : {2, 4}) {
+            for (int ncb : {2, 4, 5}) {
                 p.inner = 2 * C;
                 p.cgmap = rag ? reinterpret_cast<const int*>(&p) : nullptr;
                 p.ncg = 0;

@@ -161,10 +161,11 @@ def _lx_case(net_name, bsz, t_len, lengths, expect_pw2_x3, force_resident, wide=
         _eval(net, x, t, cond, lengths)
         names = [k["name"] for k in net.kernel_classes()]
         net.kernel_timing(False)
-        assert any(n.startswith("lx_x3_kernel<0") for n in names), names
-        assert any(n.startswith("lx_x3_kernel<1") for n in names) == expect_pw2_x3, names
-        if wide is not None:                                     # ", 4>" = 64-frame tiles, ", 2>" = 32-frame tiles
-            assert all(n.endswith(", 4>" if wide else ", 2>") for n in names if n.startswith("lx_x3_kernel")), names
+        x3n = [n for n in names if n.startswith(("lx_x3_kernel<", "lx_x3w_kernel<"))]
+        assert any(n.split("<")[1].startswith("0") for n in x3n), names
+        assert any(n.split("<")[1].startswith("1") for n in x3n) == expect_pw2_x3, names
+        if wide is not None:                                     # lx_x3w_kernel = 64-frame tiles; lx_x3_kernel<.., 2> = 32-frame tiles
+            assert all(n.startswith("lx_x3w_kernel<") if wide else n.endswith(", 2>") for n in x3n), names
         fwd = lambda xx, tt, cc: ob.lynxnet_forward(params, xx, tt, cc, activation=args["activation"], strong_cond=args["strong_cond"])   # noqa: E731
         if lengths is None:
             check(out, fwd(x, t, cond), TOL_NFE, what=("lynx bf16x3", net_name, bsz, t_len))

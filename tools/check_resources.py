@@ -16,12 +16,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "diffsinger_amd", "csrc")
 FILES = ["wn_layer.hip", "wn_layer_x3.hip", "wn_rowsplit.hip", "wn_rows.hip", "wn_edge.hip", "lynx_layer.hip", "lynx_x3.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffsinger_amd.build_native import FILE_FLAGS  # noqa: E402  (the per-file flags of the product build)
 
 
 def analyse(path):
     with tempfile.TemporaryDirectory() as tmp:
         r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-w",
-                            "-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", os.path.join(tmp, "x.o")],
+                            "-Rpass-analysis=kernel-resource-usage"] + FILE_FLAGS.get(os.path.basename(path), []) +
+                           ["-c", path, "-o", os.path.join(tmp, "x.o")],
                            capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-2000:])

@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "diffsinger_amd", "csrc")
 OUT = os.path.join(ROOT, "diffsinger_amd", "libdsdenoise_stamps.so")
-srcs = [os.path.join(CSRC, f) for f in ("gemm.hip", "wn_layer.hip", "wn_rowsplit.hip", "wn_edge.hip", "lynx_layer.hip", "aux_kernels.hip", "encoder_kernels.hip",
-                                        "vocoder_kernels.hip", "tconv.hip", "api.hip")]
+from diffsinger_amd.build_native import SOURCES  # noqa: E402
+srcs = [os.path.join(CSRC, f) for f in SOURCES]
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DDSD_STAMPS",
                 "-w", "-shared", "-o", OUT] + extra + srcs, check=True)
@@ -34,7 +34,9 @@ from diffsinger_amd.backbones import build_backbone
 args = [a for a in sys.argv[1:] if not a.startswith("-")]
 B = int(args[0]) if args else 8
 T = int(args[1]) if len(args) > 1 else 1000
-bargs = dict(num_layers=20, num_channels=256, dilation_cycle_length=4)
+CH = int(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--channels=")), 256))      # --channels=192 --cycle=5
+CYC = int(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--cycle=")), 4))
+bargs = dict(num_layers=CYC * 2, num_channels=CH, dilation_cycle_length=CYC)       # the LAST layer (the one stamped) has the widest dilation
 net = build_backbone(128, 1, "wavenet", bargs)
 sd = synth.synth_state_dict(synth.backbone_param_shapes("wavenet", 128, 1, **bargs), 42)
 net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})

@@ -13,7 +13,8 @@ points = [("wavenet_dpm50", b, 1000) for b in (1, 2, 3, 4, 5, 6, 8, 9, 12, 16, 2
          [("wavenet_dpm50", 1, t) for t in (128, 256, 512, 768, 1100, 1536, 2048, 4096)] + \
          [("lynxnet_ddim100", b, 1000) for b in (1, 8)] + [("variance_reflow20", b, 1000) for b in (1, 8)] + \
          [("acoustic_default", 1, 1000), ("acoustic_wav", 1, 1000)] + \
-         [("wavenet_dpm50_bf16x3", b, 1000) for b in (8, 16, 24)] + [("variance_reflow20_bf16x3", 8, 1000)]
+         [("wavenet_dpm50_bf16x3", b, 1000) for b in (8, 16, 24)] + [("variance_reflow20_bf16x3", 8, 1000)] + \
+         [("lynxnet_ddim100_bf16x3", b, 1000) for b in (1, 2, 8)] + [("acoustic_default_bf16x3", 1, 1000)]
 out = []
 for wl, b, t in points:
     steps = 10 if b * t <= 4000 else 4
