@@ -10,7 +10,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "diffsinger_amd", "csrc")
-OUT = os.path.join(ROOT, "tools", "diag", "lib_stamps.so")
+EXTRA = [a for a in sys.argv[1:] if a.startswith("-D")]
+TAG = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--tag=")), "")
+OUT = os.path.join(ROOT, "tools", "diag", f"lib_stamps{TAG}.so")
 if "--build" in sys.argv:
     from diffsinger_amd import build_native
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
@@ -18,8 +20,8 @@ if "--build" in sys.argv:
     for f in build_native.SOURCES:
         o = os.path.join(CSRC, f.replace(".hip", ".o"))
         if f == "lynx_x3.hip":
-            o = "/tmp/lynx_x3_stamps.o"
-            subprocess.run([build_native.HIPCC] + build_native.FLAGS + build_native.FILE_FLAGS.get(f, []) + ["-DDSD_STAMPS", "-c", os.path.join(CSRC, f), "-o", o], check=True)
+            o = f"/tmp/lynx_x3_stamps{TAG}.o"
+            subprocess.run([build_native.HIPCC] + build_native.FLAGS + build_native.FILE_FLAGS.get(f, []) + ["-DDSD_STAMPS"] + EXTRA + ["-c", os.path.join(CSRC, f), "-o", o], check=True)
         objs.append(o)
     subprocess.run([build_native.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs, check=True)
     print(OUT)
