@@ -17,8 +17,7 @@ SOURCES = ["gemm.hip", "wn_layer.hip", "wn_layer_x3.hip", "wn_rowsplit.hip", "wn
 HEADERS = [os.path.join(CSRC, "dsd_internal.h"), os.path.join(os.path.dirname(HERE), "include", "dsdenoise.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
-# per file: lynx_x3.hip's fully unrolled K walks (512 row blocks of ~60 IR instructions) are past the default budget of `#pragma unroll`
-FILE_FLAGS = {"lynx_x3.hip": ["-mllvm", "-pragma-unroll-threshold=262144"]}
+FILE_FLAGS = {}           # per-file extra flags (none needed today; tools/check_resources.py and the stamp tools honour them)
 FLAGS += os.environ.get("DSD_EXTRA_HIPCC_FLAGS", "").split()      # diagnostic A/B builds (e.g. -DDSD_ST_AUX=0)
 
 

@@ -182,9 +182,9 @@ struct dsd_handle {
     int lens_cap = 0;
     std::vector<int> lens_host;
     // ... and, per tile width (16 / 32 / 64 frames), the list of column groups (item, frame tile) with valid frames
-    int* cg_dev[4] = {nullptr, nullptr, nullptr, nullptr};      // valid-tile lists of a ragged batch at 16 / 32 / 64 / 128 frames per tile
-    int cg_cap[4] = {0, 0, 0, 0}, cg_n[4] = {0, 0, 0, 0};
-    std::vector<int> cg_host[4];
+    int* cg_dev[3] = {nullptr, nullptr, nullptr};
+    int cg_cap[3] = {0, 0, 0}, cg_n[3] = {0, 0, 0};
+    std::vector<int> cg_host[3];
     int cg_T = -1;                  // the T the lists were built for (-1: stale)
     bool use_cg = false;            // set around the launch sequences that may skip padded tiles
     // sampler state buffers
@@ -257,8 +257,8 @@ inline int check_lens(dsd_handle* h, const char* who, int B, int T, hipStream_t 
     for (int v : h->lens_host)
         if (v > T) return fail(h, DSD_EINVAL, "%s: a length (%d) exceeds T = %d", who, v, T);
     if (h->cg_T == T) return DSD_OK;
-    for (int k = 0; k < 4; ++k) {
-        const int BN = 16 << k, tiles = (T + BN - 1) / BN;
+    for (int k = 0; k < 3; ++k) {
+        const int BN = k == 0 ? 16 : 32 * k, tiles = (T + BN - 1) / BN;
         std::vector<int>& v = h->cg_host[k];
         v.clear();
         for (int b = 0; b < B; ++b)
@@ -1842,33 +1842,25 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             // workgroups per frame tile fill at least half the chip (one utterance: the fp32 128-row kernel is faster)
             const bool x3 = h->precision == 1 && !h->x3_conv.empty();
             const bool x3_pw2 = x3 && lx_tiles * (C / 512) >= h->cus / 2;
-            // ... on wider frame tiles where those still fill the chip: 128 frames x 256 rows per workgroup (lx_x3t_kernel: 1.5 x fewer
-            // bytes per MAC through the CU's vector-memory path than 64 x 512), else 64 x 512 (the weight stream serves twice the
-            // frames of the 32-frame tile).  DSD_X3_WIDE: 0 = 32-frame tiles only, 1 / 2 = force 64 / 128 wherever legal.
+            // ... on 64-frame tiles where those still fill the chip: the same weight stream then serves twice the frames
             const long lx_t64 = lx_ragged ? (long)h->cg_n[2] : (long)B * ((T + 63) / 64);
-            const long lx_t128 = lx_ragged ? (long)h->cg_n[3] : (long)B * ((T + 127) / 128);
             const int xw = path_opts().x3_wide;
-            const bool tall_ok = ((T + 127) / 128) * 128 <= Ts;          // a 128-frame tile must end inside the padded row
-            const bool tall1 = x3 && tall_ok && (xw == 2 || (xw < 0 && lx_t128 * (2 * inner / 256) >= h->cus));
-            const bool tall2 = x3_pw2 && tall_ok && (xw == 2 || (xw < 0 && lx_t128 * (C / 256) >= h->cus));
-            const bool wide1 = x3 && !tall1 && xw != 0 && (xw >= 1 || lx_t64 * (2 * inner / 512) >= h->cus);
-            const bool wide2 = x3_pw2 && !tall2 && xw != 0 && (xw >= 1 || lx_t64 * (C / 512) >= h->cus);
-            auto widen = [&](LxLayerP& q, int bn) {              // the tile bookkeeping of a launch on bn-frame tiles (64 / 128)
-                const int k = bn == 128 ? 3 : 2;
-                q.tiles_per_b = (T + bn - 1) / bn;
+            const bool wide1 = x3 && xw != 0 && (xw == 1 || lx_t64 * (2 * inner / 512) >= h->cus);
+            const bool wide2 = x3_pw2 && xw != 0 && (xw == 1 || lx_t64 * (C / 512) >= h->cus);
+            auto widen = [&](LxLayerP& q) {                      // the tile bookkeeping of a launch on 64-frame tiles
+                q.tiles_per_b = (T + 63) / 64;
                 q.inv_tiles_per_b = 1.0f / (float)q.tiles_per_b;
                 q.nft = B * q.tiles_per_b;
-                if (lx_ragged) { q.cgmap = h->cg_dev[k]; q.ncg = h->cg_n[k]; }
+                if (lx_ragged) { q.cgmap = h->cg_dev[2]; q.ncg = h->cg_n[2]; }
                 q.inv_nft = 1.0f / (float)std::max(1, lx_ragged ? q.ncg : q.nft);
             };
             hipError_t le;
             if (x3) {
                 LxLayerP q = p;
                 q.A1 = h->blob + h->x3_conv[l];
-                if (tall1) widen(q, 128);
-                else if (wide1) widen(q, 64);
-                timed_begin(650 + (tall1 ? 2 : wide1 ? 1 : 0), lx_fl1 * lx_fr, lx_by1 * lx_fr);
-                le = launch_lx_x3(q, 0, C, tall1 ? 8 : wide1 ? 4 : 2, st);
+                if (wide1) widen(q);
+                timed_begin(650 + (wide1 ? 1 : 0), lx_fl1 * lx_fr, lx_by1 * lx_fr);
+                le = launch_lx_x3(q, 0, C, wide1 ? 4 : 2, st);
                 timed_end();
             } else {
                 timed_begin(600, lx_fl1 * lx_fr, lx_by1 * lx_fr);
@@ -1883,10 +1875,9 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
             if (x3_pw2) {
                 LxLayerP q = p;
                 q.A2 = h->blob + h->x3_out[l];
-                if (tall2) widen(q, 128);
-                else if (wide2) widen(q, 64);
-                timed_begin(660 + (tall2 ? 2 : wide2 ? 1 : 0), lx_fl2 * lx_fr, lx_by2 * lx_fr);
-                le = launch_lx_x3(q, 1, C, tall2 ? 8 : wide2 ? 4 : 2, st);
+                if (wide2) widen(q);
+                timed_begin(660 + (wide2 ? 1 : 0), lx_fl2 * lx_fr, lx_by2 * lx_fr);
+                le = launch_lx_x3(q, 1, C, wide2 ? 4 : 2, st);
                 timed_end();
                 if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw2 (bf16x3) launch failed: %s", hipGetErrorString(le));
             } else if (lx_res2 && path_opts().lynx_pw2q != 1) {
@@ -2041,7 +2032,7 @@ void dsd_destroy(dsd_handle* h) {
     if (h->state) (void)hipFree(h->state);
     if (h->emb_arena) (void)hipFree(h->emb_arena);
     if (h->lens_dev) (void)hipFree(h->lens_dev);
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 3; ++k)
         if (h->cg_dev[k]) (void)hipFree(h->cg_dev[k]);
     if (h->e_arena) (void)hipFree(h->e_arena);
     if (h->v_arena) (void)hipFree(h->v_arena);

@@ -146,8 +146,8 @@ def _lx_case(net_name, bsz, t_len, lengths, expect_pw2_x3, force_resident, wide=
     args = LX_NETS[net_name]
     if force_resident:
         os.environ["DSD_LYNX_RESIDENT"] = "1"
-    if wide is not None:                                         # False: 32-frame tiles, True: 64-frame tiles, "tall": 128 frames x 256 rows
-        os.environ["DSD_X3_WIDE"] = "2" if wide == "tall" else "1" if wide else "0"
+    if wide is not None:
+        os.environ["DSD_X3_WIDE"] = "1" if wide else "0"
     try:
         net, params = make_backbone("lynxnet", 128, 1, args, 59)
         x = synth.synth_normal((bsz, 1, 128, t_len), 21)
@@ -161,13 +161,10 @@ def _lx_case(net_name, bsz, t_len, lengths, expect_pw2_x3, force_resident, wide=
         _eval(net, x, t, cond, lengths)
         names = [k["name"] for k in net.kernel_classes()]
         net.kernel_timing(False)
-        x3n = [n for n in names if n.startswith(("lx_x3_kernel<", "lx_x3t_kernel<"))]
-        assert any(n.split("<")[1].startswith("0") for n in x3n), names
-        assert any(n.split("<")[1].startswith("1") for n in x3n) == expect_pw2_x3, names
-        if wide == "tall":
-            assert all(n.startswith("lx_x3t_kernel<") for n in x3n), names
-        elif wide is not None:                                   # ", 4>" = 64-frame tiles, ", 2>" = 32-frame tiles
-            assert all(n.endswith(", 4>" if wide else ", 2>") for n in x3n), names
+        assert any(n.startswith("lx_x3_kernel<0") for n in names), names
+        assert any(n.startswith("lx_x3_kernel<1") for n in names) == expect_pw2_x3, names
+        if wide is not None:                                     # ", 4>" = 64-frame tiles, ", 2>" = 32-frame tiles
+            assert all(n.endswith(", 4>" if wide else ", 2>") for n in names if n.startswith("lx_x3_kernel")), names
         fwd = lambda xx, tt, cc: ob.lynxnet_forward(params, xx, tt, cc, activation=args["activation"], strong_cond=args["strong_cond"])   # noqa: E731
         if lengths is None:
             check(out, fwd(x, t, cond), TOL_NFE, what=("lynx bf16x3", net_name, bsz, t_len))
@@ -200,15 +197,6 @@ def test_lynx_bf16x3_wide_tiles_vs_oracle(net_name):
     _lx_case(net_name, 3, 200, [200, 77, 141], False, True, wide=True)
 
 
-@pytest.mark.parametrize("net_name", sorted(LX_NETS))
-def test_lynx_bf16x3_tall_tiles_vs_oracle(net_name):
-    """128-frame x 256-row tiles (lx_x3t_kernel) forced at small sizes: tiles cut by the utterance end in every 32-frame quarter, a
-    ragged batch on the 128-frame tile list, one tile only"""
-    _lx_case(net_name, 2, 211, None, False, True, wide="tall")
-    _lx_case(net_name, 1, 90, None, False, True, wide="tall")
-    _lx_case(net_name, 3, 250, [250, 77, 141], False, True, wide="tall")
-
-
 def test_lynx_bf16x3_batched_grid_vs_oracle():
     """both pointwise GEMMs in split-bf16 on grids that give pw2 half a chip of workgroups: C = 1024 at 2 x 1000 frames (64 frame
     tiles x 2 row tiles), the class-default C = 512 at 5 x 1000 frames"""
@@ -216,5 +204,3 @@ def test_lynx_bf16x3_batched_grid_vs_oracle():
     _lx_case("c512_default", 5, 1000, None, True, False, wide=False)
     _lx_case("c1024_strong", 2, 1000, None, True, False, wide=True)          # both GEMMs on 64-frame tiles
     _lx_case("c512_default", 5, 1000, None, True, False, wide=True)
-    _lx_case("c1024_strong", 2, 1000, None, True, False, wide="tall")        # ... on 128-frame x 256-row tiles
-    _lx_case("c512_default", 5, 1000, None, True, False, wide="tall")

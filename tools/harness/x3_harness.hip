@@ -1,5 +1,7 @@
-// Diagnostic harness (GPU box): lynx_x3.hip's pw1 on 64-frame tiles - the first build (lx_x3_kernel<.., 4>) against the second
-// (lx_x3w_kernel) on the same random buffers; prints where they differ (u channel, frame) and whether each is repeatable.
+// Diagnostic harness (GPU box): lynx_x3.hip's pw1 on 32-frame against 64-frame tiles on the same random buffers; prints where
+// they differ (u channel, frame: by frame tile, row tile, frame in tile, channel mod 16) and whether each is repeatable.  (Written
+// to find why an experimental build of the 64-frame kernel gave different results from run to run: only the ODD frames of a
+// tile did - the build formed its hi / lo split with v_pk_add_f32 ... op_sel on register pairs assembled by v_mov)
 //   hipcc -O2 --offload-arch=gfx950 -I diffsinger_amd/csrc -I include tools/harness/x3_harness.hip diffsinger_amd/csrc/lynx_x3.o -o tools/harness/x3_harness.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -51,10 +53,11 @@ int main(int argc, char** argv) {
     LxLayerP p{};
     p.A1 = reinterpret_cast<const float*>(w); p.bias1 = bias; p.xin = x; p.lnpart_in = part; p.lnpart_ts = lts; p.u = u;
     p.x_bstride = (long)xs; p.u_bstride = (long)us; p.inner = inner; p.Ts = Ts; p.T = T;
-    p.tiles_per_b = (T + 63) / 64; p.inv_tiles_per_b = 1.f / p.tiles_per_b; p.nft = B * p.tiles_per_b; p.inv_nft = 1.f / p.nft;
     std::vector<std::vector<float>> res;
-    for (int ncb : {5, 4, 4, 4, 5}) {
+    for (int ncb : {2, 4, 4, 4, 2}) {
         hipMemset(u, 0, (B * us + 1024) * 4);
+        const int bn = 16 * ncb;
+        p.tiles_per_b = (T + bn - 1) / bn; p.inv_tiles_per_b = 1.f / p.tiles_per_b; p.nft = B * p.tiles_per_b; p.inv_nft = 1.f / p.nft;
         hipError_t e = launch_lx_x3(p, 0, C, ncb, nullptr);
         hipError_t e2 = hipDeviceSynchronize();
         if (e != hipSuccess || e2 != hipSuccess) { printf("launch ncb %d: %s / %s\n", ncb, hipGetErrorString(e), hipGetErrorString(e2)); return 1; }
@@ -71,23 +74,23 @@ int main(int argc, char** argv) {
                     const size_t i = bi * us + (size_t)ch * Ts + t;
                     const double d = fabs((double)res[a][i] - res[b][i]);
                     if (d > 1e-5 * (1 + fabs(res[a][i]))) {
-                        ++bad; per_tile[bi * p.tiles_per_b + t / 64]++; per_rt[ch / 256]++; per_col[t % 64]++; per_row16[ch % 16]++;
+                        ++bad; per_tile[bi * ((T + 63) / 64) + t / 64]++; per_rt[ch / 256]++; per_col[t % 64]++; per_row16[ch % 16]++;
                         if (d > worst) { worst = d; wi = i; }
                     }
                 }
         printf("%s: %zu of %zu differ (> 1e-5 rel), worst %.3e at item %zu ch %zu frame %zu (%g vs %g)\n", what, bad, (size_t)B * inner * T, worst,
                wi / us, wi % us / Ts, wi % Ts, res[a][wi], res[b][wi]);
         if (bad) {
-            printf("   by frame tile:"); for (int i = 0; i < B * p.tiles_per_b; ++i) printf(" %d", per_tile[i]);
+            printf("   by frame tile:"); for (int i = 0; i < B * ((T + 63) / 64); ++i) printf(" %d", per_tile[i]);
             printf("\n   by row tile:"); for (int i = 0; i < 8; ++i) printf(" %d", per_rt[i]);
             printf("\n   by frame in tile:"); for (int i = 0; i < 64; ++i) printf(" %d", per_col[i]);
             printf("\n   by channel mod 16:"); for (int i = 0; i < 16; ++i) printf(" %d", per_row16[i]);
             printf("\n");
         }
     };
-    cmp(0, 4, "first build, run 1 vs 2");
-    cmp(1, 2, "second build, run 1 vs 2");
-    cmp(1, 3, "second build, run 1 vs 3");
-    cmp(0, 1, "first vs second build");
+    cmp(0, 4, "32-frame tiles, run 1 vs 2");
+    cmp(1, 2, "64-frame tiles, run 1 vs 2");
+    cmp(1, 3, "64-frame tiles, run 1 vs 3");
+    cmp(0, 1, "32- vs 64-frame tiles");
     return 0;
 }

@@ -1,5 +1,6 @@
+"""Diagnostic (GPU box): one LYNXNet evaluation in split-bf16 mode run four times on the same inputs - prints which kernels ran and,\nper 16-frame group, how far the runs differ (0 everywhere = repeatable).  Usage: python tools/rerun_probe.py [DSD_X3_WIDE] [T]"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import numpy as np, torch
 from diffsinger_amd import synth
 from gpu_util import dev, make_backbone, set_hp
