@@ -60,6 +60,7 @@ void refresh_path_opts() {
     o.film_t = geti("DSD_FILM_T", -1);
     o.dwconv_rows = geti("DSD_DWCONV_ROWS", -1);
     o.precision = geti("DSD_PRECISION", -1);
+    o.fused16 = geti("DSD_FUSED16", -1);
     o.x3_wide = geti("DSD_X3_WIDE", -1);
     const char* nb = getenv("DSD_NB2_MIN_WG");
     o.nb2_min = nb && *nb ? atol(nb) : 512;
@@ -1393,6 +1394,12 @@ inline long wn_tiles32(const dsd_handle* h) {
     for (int v : h->lens_host) tiles += (v + 31) / 32;
     return tiles;
 }
+inline long wn_tiles16(const dsd_handle* h) {
+    if (h->lens_host.empty()) return (long)h->B * ((h->T + 15) / 16);
+    long tiles = 0;
+    for (int v : h->lens_host) tiles += (v + 15) / 16;
+    return tiles;
+}
 
 // Cost of the two-launch path over `tiles` 32-frame tiles by rows per workgroup, in fused rounds (one round = 256 tiles on
 // wn_layer.hip, ~67 us at C = 256); RATIOS measured on one box at T = 1000 (profiles/r03_rows_sweep.txt):
@@ -1438,11 +1445,45 @@ bool wn_plan_for(const dsd_handle* h, std::vector<WnSeg>& segs) {
         segs.push_back({fused_kind, 32, 0, (int)tiles, 0});
         return true;
     }
+    // the fused kernel on 16-frame tiles (wn_layer16_kernel): a round of one tile per CU takes kRound16 of a 32-frame round (half the
+    // MFMAs against the same 2 MB of weights per workgroup: profiles/r03_plan_sweep.txt); fp32 only, whole layers only
+    const long tiles16 = wn_tiles16(h);
+    const bool f16_ok = !x3 && wn_layer16_supported(C, max_dil) && tiles16 < (1L << 22);
+    if (o.fused16 == 1 && f16_ok) {                // forced
+        segs.push_back({WN_FUSED, 16, 0, (int)tiles16, 0});
+        return true;
+    }
     if (o.wn_plan == 2 && rs_ok && o.fused_layer != 0) {
         // test hook: a mixed plan at any size - the first half of the tiles fused, the rest on the two-launch path
         const int nfh = (int)(tiles / 2);
         if (nfh > 0) segs.push_back({fused_kind, 32, 0, nfh, 0});
         segs.push_back({WN_ROWSPLIT, 32, nfh, (int)tiles - nfh, wn_rows_for(tiles - nfh, true)});
+        return true;
+    }
+    if ((o.wn_plan == 3 || o.wn_plan == 4) && f16_ok && rs_ok && o.fused_layer != 0) {
+        // test hooks: plans with a 16-frame fused segment at any size - 3: the first half of the 32-frame tiles on 16-frame fused
+        // tiles, the rest on the two-launch path; 4: the first half on the 32-frame fused kernel, the rest on 16-frame tiles
+        const long nfh = tiles / 2;
+        auto m16 = [h](long n) -> long {
+            if (h->lens_host.empty()) {
+                const long tpb32 = (h->T + 31) / 32, tpb16 = (h->T + 15) / 16;
+                return (n / tpb32) * tpb16 + 2 * (n % tpb32);
+            }
+            long n32 = 0, n16 = 0;
+            for (int v : h->lens_host) {
+                const long t32 = (v + 31) / 32, t16 = (v + 15) / 16;
+                if (n < n32 + t32) return n16 + 2 * (n - n32);
+                n32 += t32; n16 += t16;
+            }
+            return n16;
+        };
+        if (o.wn_plan == 3) {
+            if (nfh > 0) segs.push_back({WN_FUSED, 16, 0, (int)m16(nfh), 0});
+            segs.push_back({WN_ROWSPLIT, 32, (int)nfh, (int)(tiles - nfh), wn_rows_for(tiles - nfh, true)});
+        } else {
+            if (nfh > 0) segs.push_back({WN_FUSED, 32, 0, (int)nfh, 0});
+            segs.push_back({WN_FUSED, 16, (int)m16(nfh), (int)(tiles16 - m16(nfh)), 0});
+        }
         return true;
     }
     const bool rows_forced = rs_ok && (o.rs_rows == 128 || o.rs_rows == 256);
@@ -1462,6 +1503,56 @@ bool wn_plan_for(const dsd_handle* h, std::vector<WnSeg>& segs) {
     const double split_all = wn_split_cost(eq(tiles), rows_all, false);
     double mixed = 1e30;
     if (plans && nf > 0 && rem > 0) mixed = round_cost * (double)(nf / cus) + wn_split_cost(eq(rem), wn_rows_for(eq(rem), true), true);
+    // ... and the 16-frame fused kernel as a whole layer, as the FIRST segment of a layer of up to ~1.5 rounds (one full round of
+    // 16-frame tiles, the rest on the two-launch path: B = 5 at T = 1000), or as the remainder behind whole 32-frame rounds
+    constexpr double kRound16 = 0.53;               // a round of 16-frame tiles / a round of 32-frame tiles (35.3 / 67.1 ms per loop)
+    const bool use16 = f16_ok && o.fused16 != 0;
+    // index in the 16-frame tile order of the first 16-frame tile of 32-frame tile n (of the dense order / the valid-tile list)
+    auto map16 = [h](long n) -> long {
+        if (h->lens_host.empty()) {
+            const long tpb32 = (h->T + 31) / 32, tpb16 = (h->T + 15) / 16;
+            return (n / tpb32) * tpb16 + 2 * (n % tpb32);
+        }
+        long n32 = 0, n16 = 0;
+        for (int v : h->lens_host) {
+            const long t32 = (v + 31) / 32, t16 = (v + 15) / 16;
+            if (n < n32 + t32) return n16 + 2 * (n - n32);
+            n32 += t32; n16 += t16;
+        }
+        return n16;
+    };
+    const double fused16_all = (use16 && 2 * tiles16 >= cus) ? kRound16 * (double)((tiles16 + cus - 1) / cus) : 1e30;
+    double head16 = 1e30, tail16 = 1e30;
+    long head_n32 = 0;
+    if (use16 && plans && tiles16 > cus) {          // one round of 16-frame tiles in front, the rest two launches
+        long lo = 0, hi = tiles;                    // the largest n with map16(n) <= cus
+        while (lo < hi) {
+            const long mid = (lo + hi + 1) / 2;
+            if (map16(mid) <= cus) lo = mid; else hi = mid - 1;
+        }
+        head_n32 = lo;
+        if (head_n32 > 0 && head_n32 < tiles)
+            head16 = kRound16 + wn_split_cost(eq(tiles - head_n32), wn_rows_for(eq(tiles - head_n32), true), true);
+    }
+    if (use16 && nf > 0 && rem > 0) {               // whole 32-frame rounds, the remainder as one round of 16-frame tiles
+        const long rem16 = tiles16 - map16(nf);
+        if (rem16 <= cus && 2 * rem16 >= cus) tail16 = round_cost * (double)(nf / cus) + kRound16;
+    }
+    const double best_other = std::min(std::min(mixed, fused_all), split_all);
+    if (fused16_all < best_other && fused16_all <= head16 && fused16_all <= tail16) {
+        segs.push_back({WN_FUSED, 16, 0, (int)tiles16, 0});
+        return true;
+    }
+    if (head16 < best_other && head16 <= tail16) {
+        segs.push_back({WN_FUSED, 16, 0, (int)map16(head_n32), 0});
+        segs.push_back({WN_ROWSPLIT, 32, (int)head_n32, (int)(tiles - head_n32), wn_rows_for(eq(tiles - head_n32), true)});
+        return true;
+    }
+    if (tail16 < best_other) {
+        segs.push_back({fused_kind, 32, 0, (int)nf, 0});
+        segs.push_back({WN_FUSED, 16, (int)map16(nf), (int)(tiles16 - map16(nf)), 0});
+        return true;
+    }
     if (mixed < fused_all && mixed < split_all) {
         segs.push_back({fused_kind, 32, 0, (int)nf, 0});
         segs.push_back({WN_ROWSPLIT, 32, (int)nf, (int)rem, wn_rows_for(eq(rem), true)});
@@ -1651,8 +1742,8 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                     layer_params(p, l, sg.bn);
                     p.xin = xi; p.xout = xo; p.z = h->hbuf;
                     p.tile0 = sg.t0; p.ntiles = sg.nt;
-                    if (ragged) { p.lens = h->lens_dev; p.cgmap = h->cg_dev[1] + sg.t0; p.ncg = sg.nt; }
-                    const int vkey = (int)k * 4 + (p.dil > 8 ? 2 : 0);
+                    if (ragged) { p.lens = h->lens_dev; p.cgmap = h->cg_dev[sg.bn == 16 ? 0 : 1] + sg.t0; p.ncg = sg.nt; }
+                    const int vkey = (int)k * 4 + (p.dil > 8 ? 2 : 0) + (sg.bn == 16 ? 1 : 0);
                     hipError_t le;
                     if (sg.kind == WN_FUSED_X3) {
                         p.Aconv = h->blob + h->x3_conv[l];
@@ -1663,7 +1754,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                         if (le != hipSuccess) return fail(h, DSD_EHIP, "bf16x3 fused WaveNet layer launch failed: %s", hipGetErrorString(le));
                     } else if (sg.kind == WN_FUSED) {
                         timed_begin(100 + vkey, (fl_conv + fl_out) * seg_fr[k], 24.0 * C * seg_fr[k]);
-                        le = launch_wn_layer(p, C, B, st);
+                        le = launch_wn_layer(p, C, B, st, sg.bn);
                         timed_end();
                         if (le != hipSuccess) return fail(h, DSD_EHIP, "fused WaveNet layer launch failed: %s", hipGetErrorString(le));
                     } else {

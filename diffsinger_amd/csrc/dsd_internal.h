@@ -42,6 +42,7 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU = 3, ACT_LRELU = 4
 // the hipGraph cache key (a captured graph is the launch sequence of ONE set of choices).  -1 = unset: the library's own rule.
 struct PathOpts {
     int fused_layer;        // DSD_FUSED_LAYER     0: never wn_layer.hip, 1: on every supported grid
+    int fused16;            // DSD_FUSED16         0: never wn_layer16_kernel (16-frame tiles of the fused layer), 1: every layer on it
     int wn_plan;            // DSD_WN_PLAN         0: one launch shape per layer (round 2), 1/unset: mixed plans (wn_plan_for)
     int rowsplit;           // DSD_ROWSPLIT        0: never wn_rowsplit.hip
     int rs_bn48;            // DSD_RS_BN48         0: no 48-frame tiles of the row-split pair
@@ -243,7 +244,8 @@ struct WnLayerP {
                             // order - a layer may run as several launches over disjoint tile ranges (api.hip, wn_plan_for)
     int ntiles;             // ... their number (0: all of batch * tiles_per_b; ragged: ncg)
 };
-hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st);
+hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st, int bn = 32);      // bn: 32, or 16 (wn_layer16_kernel)
+bool wn_layer16_supported(int C, int dil);
 bool wn_layer_supported(int C, int dil);
 hipError_t wn_layer_init_all();
 // wn_rowsplit.hip: the same layer as two launches with the 2C rows split over 2C / 64 workgroups per 32-frame tile, for

@@ -76,12 +76,18 @@ extern "C" int dsd_dbg_read_wn_stamps(unsigned long long* host_out) {
 // NCH = C / 64 (3: multi-variance nets, 4: acoustic / pitch nets, 2: C = 128 nets); SW = LDS row stride of the x tile in floats,
 // 48 (halo 8: dilation <= 8) or 80 (halo 16: dilation 16), both 16 (mod 32) so the 4 k-rows x 16 columns of a B
 // fragment read hit 64 distinct banks; RAG = 1: ragged batch (valid-tile list + per-item lengths, as in gemm.hip).
-template <int NCH, int SW, int RAG>
-__global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+//
+// NCB = 16-frame column blocks of the tile: 2 (32 frames, wn_layer_kernel) or 1 (16 frames, wn_layer16_kernel - round 3: for grids of
+// 65 ... 128 32-frame tiles, where the 32-frame kernel would leave half the CUs idle and the two-launch forms pay two boundaries:
+// B = 3, 4 at T = 1000, one utterance of 2100 ... 4096 frames.  Half the MFMAs per workgroup against the same 2 MB of weights:
+// 8 bytes per clock per wave, the most a CU's vector-memory path gives - see DESIGN 4.4b).
+template <int NCH, int SW, int RAG, int NCB>
+__device__ __forceinline__ void wn_layer_body(const WnLayerP& p, float* lds) {
     constexpr int C = 64 * NCH;
     constexpr int MBW = 2 * NCH;                    // 16-row blocks per wave, both GEMMs (2C rows / 4 waves / 16)
-    constexpr int BN = 32;
+    constexpr int BN = 16 * NCB;
+    constexpr int F4 = BN / 4;                      // float4 per row of a row-major tile
+    constexpr int RPM = 64 / F4;                    // rows a wave's 64 lanes cover per row-major float4 pass
     constexpr int HL = SW == 48 ? 8 : 16;           // staged halo columns on each side
     constexpr int W4 = (BN + 2 * HL) / 4;           // float4 per staged row
     constexpr int NU = C * W4 / 256;                // staged float4 per thread (exact for C = 192, 256)
@@ -203,60 +209,57 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     WN_STAMP(2);
 
     // ---------------- GEMM 1: dilated conv, K = 3 taps x C channels ----------------
-    f32x4 acc[MBW][2];
+    f32x4 acc[MBW][NCB];
 #pragma unroll
-    for (int k = 0; k < MBW; ++k) {
-        acc[k][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int k = 0; k < MBW; ++k)
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) acc[k][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     // B fragment of a k4 step: lane (lrow, lcol) holds stage(x)[channel 4j + lrow][column lcol (+16)] at the tap's shift;
     // one base register per tap, every other part of the address is an immediate
     const float* bt0 = xs + lrow * SW + HL + lcol - p.dil;
     const float* bt1 = bt0 + p.dil;
     const float* bt2 = bt1 + p.dil;
-    float bq[2][4][2];
-    auto read_b1 = [&](float (&bv)[4][2], int s) {               // s = k16 step: [64-channel chunk][tap][k16 in chunk]
+    float bq[2][4][NCB];
+    auto read_b1 = [&](float (&bv)[4][NCB], int s) {               // s = k16 step: [64-channel chunk][tap][k16 in chunk]
         const int c = s / 12, i = s % 12, tap = i >> 2;
         const float* base = (tap == 0 ? bt0 : (tap == 1 ? bt1 : bt2)) + (c * 64 + (i & 3) * 16) * SW;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bv[j][0] = base[j * 4 * SW];
-            bv[j][1] = base[j * 4 * SW + 16];
-        }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) bv[j][n] = base[j * 4 * SW + 16 * n];
     };
-    auto mfma_step = [&](const f32x4 (&w)[MBW], const float (&bv)[4][2]) {
+    auto mfma_step = [&](const f32x4 (&w)[MBW], const float (&bv)[4][NCB]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < MBW; ++k) {
-                acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k][j], bv[j][0], acc[k][0], 0, 0, 0);
-                acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k][j], bv[j][1], acc[k][1], 0, 0, 0);
-            }
+            for (int k = 0; k < MBW; ++k)
+#pragma unroll
+                for (int n = 0; n < NCB; ++n) acc[k][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k][j], bv[j][n], acc[k][n], 0, 0, 0);
     };
     // One k16 step = 8 * MBW MFMAs on the current weights / B fragments, with the loads of step s + 2 (and one extra
     // operand load on some steps) and the LDS reads of step s + 1 spread between them: an MFMA holds the issue port for 8
     // of its 32 cycles, so one load behind every 8 MFMAs costs nothing, MBW loads in a row cost their issue time.
 #define WN_SPREAD()                                                                  \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NCB, 0);                               \
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* the step's extra operand load, if it has one */ \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NCB, 0);                               \
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                               \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
     _Pragma("unroll") for (int g_ = 1; g_ < MBW; ++g_) {                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCB, 0);                           \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           \
     }                                                                                \
     __builtin_amdgcn_sched_barrier(0);
     // step 0 of a ramped ring issues TWO steps' weights (DSD_WN_RAMP): two loads behind every 8 MFMAs
 #define WN_SPREAD2()                                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NCB, 0);                               \
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                               \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NCB, 0);                               \
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                               \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
     _Pragma("unroll") for (int g_ = 1; g_ < MBW; ++g_) {                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCB, 0);                           \
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                           \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           \
     }                                                                                \
@@ -264,13 +267,13 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
 
     // a step with TWO extra operand loads (late x chunks of the 80-float tile): one behind each of the first two MFMA groups
 #define WN_SPREAD3()                                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NCB, 0);                               \
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                               \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NCB, 0);                               \
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                               \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
     _Pragma("unroll") for (int g_ = 1; g_ < MBW; ++g_) {                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCB, 0);                           \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           \
     }                                                                                \
@@ -279,9 +282,9 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     // operands fetched during GEMM 1: the hoisted conditioner projection (+ conv bias + its own bias) of this wave's rows
     // as row-major float4 (local row rl = idx >> 3: [0, 8 MBW) gate rows, [8 MBW, 16 MBW) filter rows), and the
     // output-projection bias in the accumulator layout
-    constexpr int NE = 16 * MBW * (BN / 4) / 64;                // float4 per lane over the wave's 16 * MBW rows: 16 / 12
+    constexpr int NE = 16 * MBW * F4 / 64;                      // float4 per lane over the wave's 16 * MBW rows: 16 / 12 (32 frames)
     const int orow0 = 16 * MBW * wave;                           // first output-projection row of this wave (of 2C)
-    const int ev0 = ((lane >> 3) * Ts + (lane & 7) * 4) * 4;    // lane's float4 of row (lane >> 3); + 8 rows per m
+    const int ev0 = ((lane / F4) * Ts + (lane % F4) * 4) * 4;   // lane's float4 of row lane / F4; + RPM rows per m
     const __amdgpu_buffer_rsrc_t r_c = rsrc(p.cp + (long)bu * p.cp_bstride + (long)(16 * NCH * wave) * Ts + t0u);
     const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias_out + orow0);
     f32x4 cpv[NE];
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
         } else if (!(EARLY_LATE && NDBL > 0) && s < NLATE)
             sv[NU0 + s] = ld4(r_x, x_voff(NU0 + s), 0);
         else if (s >= 12 && s < 12 + NE)          // (one chain of else-ifs: as separate ifs hipcc no longer folds the register arrays' indices)
-            cpv[s - 12] = ld4(r_c, ev0, (((s - 12) % (NE / 2)) * 8 + (s - 12 >= NE / 2 ? C : 0)) * Ts * 4);
+            cpv[s - 12] = ld4(r_c, ev0, (((s - 12) % (NE / 2)) * RPM + (s - 12 >= NE / 2 ? C : 0)) * Ts * 4);
         else if (s >= 12 + NE && s < 12 + NE + MBW)
             bo[s - 12 - NE] = ld4(r_b, rq * 4, (s - 12 - NE) * 64);
         if (EARLY_LATE || s != 11) read_b1(bq[(s + 1) & 1], s + 1 < NS1 ? s + 1 : 0);      // (after the last step: unused)
@@ -351,16 +354,16 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
 #pragma unroll
     for (int m = 0; m < NE; ++m) {
         const int idx = lane + 64 * m;
-        *reinterpret_cast<f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]) = cpv[m];
+        *reinterpret_cast<f32x4*>(&ew[(idx / F4) * ES + (idx % F4) * 4]) = cpv[m];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // same wave wrote what it reads: LDS is in order per wave
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float zr[NCH][2][4];
+    float zr[NCH][NCB][4];
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NCB; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float cg = ew[(i * 16 + rq + r) * ES + n * 16 + lcol];
@@ -372,17 +375,16 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NCB; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 zs[((NCH * wave + i) * 16 + rq + r) * SZ + n * 16 + lcol] = zr[i][n][r];
 #pragma unroll
     for (int k = 0; k < MBW; ++k)                                // GEMM 2 starts from its bias
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[k][0][r] = bo[k][r];
-            acc[k][1][r] = bo[k][r];
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) acc[k][n][r] = bo[k][r];
     __syncthreads();
     WN_STAMP(4);
 
@@ -397,12 +399,11 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
     const unsigned long long xa = (unsigned long long)p.xin, sa = (unsigned long long)p.skip;
     const __amdgpu_buffer_rsrc_t r_e = rsrc((const float*)(is_res ? xa : sa) + eoff);
     const float* zt = zs + lrow * SZ + lcol;
-    auto read_b2 = [&](float (&bv)[4][2], int s) {
+    auto read_b2 = [&](float (&bv)[4][NCB], int s) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bv[j][0] = zt[(s * 16 + j * 4) * SZ];
-            bv[j][1] = zt[(s * 16 + j * 4) * SZ + 16];
-        }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) bv[j][n] = zt[(s * 16 + j * 4) * SZ + 16 * n];
     };
     static_assert(NS1 % 3 == 0 && NE <= NS2, "buffer rotation continues across the two GEMMs; one operand load per step");
     read_b2(bq[0], 0);
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
 #pragma unroll
     for (int s = 0; s < NS2; ++s) {
         if (s + 2 < NS2) load_w2(W[(s + 2) % 3], s + 2);
-        if (s < NE) pre[s] = ld4(r_e, ev0, s * 8 * Ts * 4);
+        if (s < NE) pre[s] = ld4(r_e, ev0, s * RPM * Ts * 4);
         read_b2(bq[(s + 1) & 1], s + 1 < NS2 ? s + 1 : 0);
         mfma_step(W[s % 3], bq[s & 1]);
         WN_SPREAD()
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
 #pragma unroll
     for (int k = 0; k < MBW; ++k)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NCB; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ew[(k * 16 + rq + r) * ES + n * 16 + lcol] = acc[k][n][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -441,47 +442,72 @@ __global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
 #pragma unroll
         for (int m = 0; m < NE; ++m) {
             const int idx = lane + 64 * m;
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ew[(idx >> 3) * ES + (idx & 7) * 4]);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&ew[(idx / F4) * ES + (idx % F4) * 4]);
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ((add_pre ? pre[m][e] : 0.f) + a4[e]) * scale;
-            dsd_store_b128<DSD_ST_AUX>(__builtin_bit_cast(dsd_u32x4, o), w_o, ev0, m * 8 * Ts * 4);
+            dsd_store_b128<DSD_ST_AUX>(__builtin_bit_cast(dsd_u32x4, o), w_o, ev0, m * RPM * Ts * 4);
         }
     }
     WN_STAMP(6);
 }
 
-int wn_layer_lds_bytes(int nch, int sw) { return (64 * nch * sw + 4 * 16 * 2 * nch * 36) * 4; }
+template <int NCH, int SW, int RAG>
+__global__ __launch_bounds__(256, 1) void wn_layer_kernel(const WnLayerP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    wn_layer_body<NCH, SW, RAG, 2>(p, lds);
+}
+template <int NCH, int SW, int RAG>
+__global__ __launch_bounds__(256, 1) void wn_layer16_kernel(const WnLayerP p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    wn_layer_body<NCH, SW, RAG, 1>(p, lds);
+}
+
+int wn_layer_lds_bytes(int nch, int sw, int ncb) { return (64 * nch * sw + 4 * 16 * 2 * nch * (16 * ncb + 4)) * 4; }
 
 bool wn_layer_supported(int C, int dil) { return (C == 256 || C == 192 || C == 128) && dil >= 1 && dil <= 16; }
 
-template <int NCH, int SW, int RAG>
+template <int NCH, int SW, int RAG, int NCB>
 static hipError_t wn_launch(const WnLayerP& p, int ntiles, hipStream_t st) {
-    const int ldsb = wn_layer_lds_bytes(NCH, SW);
+    const int ldsb = wn_layer_lds_bytes(NCH, SW, NCB);
     static bool attr_done = false;       // per instantiation; set outside any capture by wn_layer_init_all
+    void (*kern)(const WnLayerP);
+    if constexpr (NCB == 2) kern = wn_layer_kernel<NCH, SW, RAG>;
+    else kern = wn_layer16_kernel<NCH, SW, RAG>;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wn_layer_kernel<NCH, SW, RAG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (ntiles == 0) return hipSuccess;
-    return launch_timed(wn_layer_kernel<NCH, SW, RAG>, dim3(ntiles), dim3(256), ldsb, st, p, "wn_layer_kernel<%d, %d, %d>", NCH, SW, RAG);
+    return launch_timed(kern, dim3(ntiles), dim3(256), ldsb, st, p, NCB == 2 ? "wn_layer_kernel<%d, %d, %d>" : "wn_layer16_kernel<%d, %d, %d>", NCH, SW, RAG);
 }
 
-hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st) {
+bool wn_layer16_supported(int C, int dil) { return (C == 256 || C == 192) && dil >= 1 && dil <= 16; }
+
+// bn = frames per tile: 32, or 16 (wn_layer16_kernel; p.tiles_per_b / tile0 / ntiles / cgmap count tiles of that width)
+hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st, int bn) {
     const int sw = p.dil <= 8 ? 48 : 80;
     const int ntiles = p.cgmap ? p.ncg : (p.ntiles > 0 ? p.ntiles : batch * p.tiles_per_b);
+    if (bn != 32 && !(bn == 16 && wn_layer16_supported(C, p.dil))) return hipErrorInvalidValue;
 #define WN_CASE(NCH_, SW_)                                                                                  \
-    if (C == 64 * NCH_ && sw == SW_)                                                                        \
-        return p.cgmap ? wn_launch<NCH_, SW_, 1>(p, ntiles, st) : wn_launch<NCH_, SW_, 0>(p, ntiles, st);
+    if (C == 64 * NCH_ && sw == SW_ && bn == 32)                                                            \
+        return p.cgmap ? wn_launch<NCH_, SW_, 1, 2>(p, ntiles, st) : wn_launch<NCH_, SW_, 0, 2>(p, ntiles, st);
+#define WN_CASE16(NCH_, SW_)                                                                                \
+    if (C == 64 * NCH_ && sw == SW_ && bn == 16)                                                            \
+        return p.cgmap ? wn_launch<NCH_, SW_, 1, 1>(p, ntiles, st) : wn_launch<NCH_, SW_, 0, 1>(p, ntiles, st);
     WN_CASE(4, 48)
     WN_CASE(4, 80)
     WN_CASE(3, 48)
     WN_CASE(3, 80)
     WN_CASE(2, 48)
     WN_CASE(2, 80)
+    WN_CASE16(4, 48)
+    WN_CASE16(4, 80)
+    WN_CASE16(3, 48)
+    WN_CASE16(3, 80)
 #undef WN_CASE
+#undef WN_CASE16
     return hipErrorInvalidValue;
 }
 
@@ -489,15 +515,19 @@ hipError_t launch_wn_layer(const WnLayerP& p, int C, int batch, hipStream_t st) 
 hipError_t wn_layer_init_all() {
     WnLayerP p{};
     hipError_t e;
-#define WN_INIT(NCH_, SW_)                                                                       \
-    if ((e = wn_launch<NCH_, SW_, 0>(p, 0, nullptr)) != hipSuccess) return e;  \
-    if ((e = wn_launch<NCH_, SW_, 1>(p, 0, nullptr)) != hipSuccess) return e;
-    WN_INIT(4, 48)
-    WN_INIT(4, 80)
-    WN_INIT(3, 48)
-    WN_INIT(3, 80)
-    WN_INIT(2, 48)
-    WN_INIT(2, 80)
+#define WN_INIT(NCH_, SW_, NCB_)                                                                  \
+    if ((e = wn_launch<NCH_, SW_, 0, NCB_>(p, 0, nullptr)) != hipSuccess) return e;               \
+    if ((e = wn_launch<NCH_, SW_, 1, NCB_>(p, 0, nullptr)) != hipSuccess) return e;
+    WN_INIT(4, 48, 2)
+    WN_INIT(4, 80, 2)
+    WN_INIT(3, 48, 2)
+    WN_INIT(3, 80, 2)
+    WN_INIT(2, 48, 2)
+    WN_INIT(2, 80, 2)
+    WN_INIT(4, 48, 1)
+    WN_INIT(4, 80, 1)
+    WN_INIT(3, 48, 1)
+    WN_INIT(3, 80, 1)
 #undef WN_INIT
     return hipSuccess;
 }

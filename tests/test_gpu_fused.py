@@ -27,7 +27,7 @@ from oracle import diffusion as od  # noqa: E402
 
 TOL_NFE = 2e-5
 TOL_SAMPLER = 1.5e-5
-SWITCHES = ("DSD_FUSED_LAYER", "DSD_WN_PLAN", "DSD_ROWSPLIT", "DSD_EDGE")
+SWITCHES = ("DSD_FUSED_LAYER", "DSD_WN_PLAN", "DSD_ROWSPLIT", "DSD_EDGE", "DSD_FUSED16")
 
 
 @pytest.fixture(autouse=True)
@@ -115,6 +115,87 @@ def test_fused_layer_forced_vs_oracle(net_name, grid):
     else:
         for b, n in enumerate(lengths):
             check(out[b:b + 1, :, :, :n], out2[b:b + 1, :, :, :n], 8e-6, what=("fused vs two launches", net_name, grid, b))
+    net.release_native()
+
+
+@pytest.mark.parametrize("grid", sorted(GRIDS))
+@pytest.mark.parametrize("net_name", ["c256_cyc4", "c256_cyc5", "c192_cyc4", "c192_cyc5"])
+def test_fused_layer_16_frame_tiles_forced_vs_oracle(net_name, grid):
+    """wn_layer16_kernel (the fused layer on 16-frame tiles: the plan for 65 ... 128 32-frame tiles) forced on the small grids: tiles cut
+    inside their 16 frames, T < dilation, ragged lists on the 16-frame tile list; against the oracle and against the 32-frame kernel"""
+    in_dims, n_feats, args = NETS[net_name]
+    bsz, t_len, lengths = GRIDS[grid]
+    os.environ["DSD_FUSED16"] = "1"
+    net, params = make_backbone("wavenet", in_dims, n_feats, args, 42)
+    x, t, cond = _inputs(in_dims, n_feats, bsz, t_len, 23)
+    out = _forward(net, x, t, cond, lengths)
+    st = net.stats()
+    tiles = sum((n + 15) // 16 for n in lengths) if lengths else bsz * ((t_len + 15) // 16)
+    assert st["layer_launches"] == 1 and st["fused_tiles"] == tiles and st["split_tiles"] == 0, st
+    net.kernel_timing(True)
+    _forward(net, x, t, cond, lengths)
+    names = [k["name"] for k in net.kernel_classes()]
+    net.kernel_timing(False)
+    assert any(n.startswith("wn_layer16_kernel<") for n in names) and not any(n.startswith("wn_layer_kernel<") for n in names), names
+    _check_vs_oracle(out, params, x, t, cond, args["dilation_cycle_length"], lengths, ("fused 16-frame tiles forced", net_name, grid))
+    os.environ.pop("DSD_FUSED16")
+    os.environ["DSD_FUSED_LAYER"] = "1"
+    out2 = _forward(net, x, t, cond, lengths)
+    if lengths is None:
+        check(out, out2, 8e-6, what=("16- vs 32-frame fused tiles", net_name, grid))
+    else:
+        for b, n in enumerate(lengths):
+            check(out[b:b + 1, :, :, :n], out2[b:b + 1, :, :, :n], 8e-6, what=("16- vs 32-frame fused tiles", net_name, grid, b))
+    net.release_native()
+
+
+def test_fused_16_frame_tiles_natural_b4_vs_oracle():
+    """B = 4, T = 1000 (128 32-frame tiles = 252 16-frame tiles for 256 CUs): the plan the library picks by itself is one launch
+    per layer on 16-frame tiles; one evaluation against the oracle"""
+    in_dims, n_feats, args = NETS["c256_cyc4"]
+    net, params = make_backbone("wavenet", in_dims, n_feats, args, 42)
+    x, t, cond = _inputs(in_dims, n_feats, 4, 1000, 29)
+    out = _forward(net, x, t, cond, None)
+    st = net.stats()
+    assert st["layer_launches"] == 1 and st["fused_tiles"] == 4 * 63 and st["split_tiles"] == 0, st
+    check(out, ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=4), TOL_NFE, what="fused 16-frame tiles, natural plan at B = 4")
+    net.release_native()
+
+
+@pytest.mark.parametrize("hook", ["3", "4"])
+@pytest.mark.parametrize("grid", ["dense_T211_B2", "ragged_B3", "dense_T160_B3", "ragged_mid"])
+@pytest.mark.parametrize("net_name", ["c256_cyc4", "c256_cyc5"])
+def test_mixed_plan_with_16_frame_segment_forced_vs_oracle(net_name, grid, hook):
+    """Plans that put a 16-frame fused segment beside another launch shape, at any size (DSD_WN_PLAN=3: 16-frame fused tiles for the
+    first half of the 32-frame tile order, the two-launch path for the rest; 4: the 32-frame fused kernel first, 16-frame tiles for the
+    rest) - the segment boundary inside an item (dense_T160_B3, ragged_mid) and at item ends"""
+    in_dims, n_feats, args = NETS[net_name]
+    bsz, t_len, lengths = GRIDS[grid]
+    os.environ["DSD_WN_PLAN"] = hook
+    net, params = make_backbone("wavenet", in_dims, n_feats, args, 42)
+    x, t, cond = _inputs(in_dims, n_feats, bsz, t_len, 27)
+    out = _forward(net, x, t, cond, lengths)
+    st = net.stats()
+    assert st["layer_launches"] == (3 if hook == "3" else 2) and st["fused_tiles"] > 0, st
+    net.kernel_timing(True)
+    _forward(net, x, t, cond, lengths)
+    names = [k["name"] for k in net.kernel_classes()]
+    net.kernel_timing(False)
+    assert any(n.startswith("wn_layer16_kernel<") for n in names), names
+    _check_vs_oracle(out, params, x, t, cond, args["dilation_cycle_length"], lengths, ("mixed plan with a 16-frame segment", hook, net_name, grid))
+    net.release_native()
+
+
+def test_mixed_plan_16_frame_head_natural_b5_vs_oracle():
+    """B = 5, T = 1000 (160 32-frame tiles): the library's own plan is one round of 16-frame fused tiles (256 of them = the first
+    130 32-frame tiles) and the two-launch path for the other 30"""
+    in_dims, n_feats, args = NETS["c256_cyc4"]
+    net, params = make_backbone("wavenet", in_dims, n_feats, args, 42)
+    x, t, cond = _inputs(in_dims, n_feats, 5, 1000, 31)
+    out = _forward(net, x, t, cond, None)
+    st = net.stats()
+    assert st["layer_launches"] == 3 and st["fused_tiles"] == 256 and st["split_tiles"] == 30, st
+    check(out, ob.wavenet_forward(params, x, t, cond, dilation_cycle_length=4), TOL_NFE, what="16-frame head + two-launch rest, natural plan at B = 5")
     net.release_native()
 
 
