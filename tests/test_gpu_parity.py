@@ -581,7 +581,7 @@ def test_config4_per_gpu_share_all_50_steps_vs_oracle():
     want = o.forward(cond, noise, diff_accelerator="dpm-solver", diff_speedup=20, K_step_infer=1000)
     check(out, want, TOL_SAMPLER, what="8 x 1000 frames, 50 NFE, fused layers")
     one = d(dev(cond[3:4]), infer=True, noise=dev(noise[3:4]))
-    assert forced == "1" or d.denoise_fn.stats()["kernels_per_nfe"] in (2 * 20 + 1, 2 * 20 + 3)
+    assert forced == "1" or os.environ.get("DSD_FUSED16") == "1" or d.denoise_fn.stats()["kernels_per_nfe"] in (2 * 20 + 1, 2 * 20 + 3)
     check(one, want[3:4], TOL_SAMPLER, what="utterance 3 alone, two GEMMs per layer")
     d.denoise_fn.release_native()
 
