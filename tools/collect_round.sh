@@ -1,13 +1,14 @@
 #!/bin/bash
 # Run in the BUILD container: the round's committed profile set - per configuration one gpurun call per profiler session
 # (plain run + kernel trace, then the three counter passes), condensed into profiles/<tag>_* and profiles/traffic.json.
-#   usage: tools/collect_round.sh r03 [config ...]     configs: wn_b1 wn_b8 wn_ragged lynx_b8 var_b8 wn_b8_x3 lynx_b8_x3
+#   usage: tools/collect_round.sh r03 [config ...]     configs: wn_b1 wn_b4 wn_b8 wn_ragged lynx_b8 var_b8 wn_b8_x3 lynx_b8_x3
 set -o pipefail
 rt=$1; shift
 cfgs=${@:-"wn_b1 wn_b8 wn_ragged lynx_b8 var_b8"}
 for c in $cfgs; do
   case $c in
     wn_b1)     tag=${rt}_wavenet_dpm50_b1;        key=wavenet_dpm50/B1/T1000;         args="--workload wavenet_dpm50 --batch 1 --steps 20 --warmup 3" ;;
+    wn_b4)     tag=${rt}_wavenet_dpm50_b4;        key=wavenet_dpm50/B4/T1000;         args="--workload wavenet_dpm50 --batch 4 --steps 8 --warmup 2" ;;
     wn_b8)     tag=${rt}_wavenet_dpm50_b8;        key=wavenet_dpm50/B8/T1000;         args="--workload wavenet_dpm50 --batch 8 --steps 6 --warmup 2" ;;
     wn_ragged) tag=${rt}_wavenet_dpm50_ragged_b8; key=wavenet_dpm50_ragged/B8/T1536;  args="--workload wavenet_dpm50 --batch 8 --ragged --steps 6 --warmup 2" ;;
     lynx_b8)   tag=${rt}_lynxnet_ddim100_b8;      key=lynxnet_ddim100/B8/T1000;       args="--workload lynxnet_ddim100 --batch 8 --steps 3 --warmup 1" ;;
