@@ -199,6 +199,20 @@ def test_mixed_plan_16_frame_head_natural_b5_vs_oracle():
     net.release_native()
 
 
+def test_mixed_plan_16_frame_head_natural_ragged_vs_oracle():
+    """A ragged batch of 5 utterances (157 32-frame tiles, 311 16-frame tiles): the library's own plan puts one round of 16-frame
+    fused tiles in front - its end falls inside item 4 - and the rest on the two-launch path; every item against the oracle run alone"""
+    in_dims, n_feats, args = NETS["c256_cyc5"]
+    lengths = [1000, 990, 1000, 1000, 1000 - 45]
+    net, params = make_backbone("wavenet", in_dims, n_feats, args, 42)
+    x, t, cond = _inputs(in_dims, n_feats, 5, 1000, 33)
+    out = _forward(net, x, t, cond, lengths)
+    st = net.stats()
+    assert st["layer_launches"] == 3 and st["fused_tiles"] == 255 and st["split_tiles"] == 157 - 129, st      # 251 + 2 * 2 16-frame tiles = 129 32-frame tiles
+    _check_vs_oracle(out, params, x, t, cond, args["dilation_cycle_length"], lengths, ("16-frame head, ragged natural plan",))
+    net.release_native()
+
+
 @pytest.mark.parametrize("grid", ["dense_T211_B2", "dense_T13_B3", "ragged_B3", "ragged_short", "dense_T160_B3", "ragged_mid"])
 @pytest.mark.parametrize("net_name", ["c256_cyc4", "c256_cyc5"])
 def test_mixed_plan_forced_vs_oracle(net_name, grid):
