@@ -1945,6 +1945,14 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                 if (lx_ragged) { q.cgmap = h->cg_dev[2]; q.ncg = h->cg_n[2]; }
                 q.inv_nft = 1.0f / (float)std::max(1, lx_ragged ? q.ncg : q.nft);
             };
+            // pw2, fp32: 512-row workgroups (lx_pw2d_kernel, ~130 us per round of one per CU) or 128-row ones (lx_pw2q_kernel, ~40 us
+            // per round) - by rounds: between whole rounds of the wide form the narrow one wins (B = 3, 5, 6 at T = 1000: 192 / 320 /
+            // 384 wide workgroups for 256 CUs).  DSD_LYNX_PW2Q=0/1 forces.
+            bool lx_q_over_d = path_opts().lynx_pw2q == 1;
+            if (lx_res2 && path_opts().lynx_pw2q < 0 && lx_pw2q_supported(C, inner)) {
+                const long rq = (lx_tiles * (C / 128) + h->cus - 1) / h->cus, rd = (lx_tiles * (C / 512) + h->cus - 1) / h->cus;
+                lx_q_over_d = 10 * rq < 33 * rd;
+            }
             hipError_t le;
             if (x3) {
                 LxLayerP q = p;
@@ -1971,7 +1979,7 @@ int run_backbone(dsd_handle* h, const float* xin_state, int film_col0, int film_
                 le = launch_lx_x3(q, 1, C, wide2 ? 4 : 2, st);
                 timed_end();
                 if (le != hipSuccess) return fail(h, DSD_EHIP, "LYNXNet pw2 (bf16x3) launch failed: %s", hipGetErrorString(le));
-            } else if (lx_res2 && path_opts().lynx_pw2q != 1) {
+            } else if (lx_res2 && !lx_q_over_d) {
                 timed_begin(610, lx_fl2 * lx_fr, lx_by2 * lx_fr);
                 le = launch_lx_layer(p, 1, C, st);
                 timed_end();
