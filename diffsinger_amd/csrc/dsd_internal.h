@@ -329,6 +329,7 @@ struct LxLayerP {
     float inv_tiles_per_b, inv_nft;     // inv_nft = 1 / (ragged ? ncg : nft)
     const int* cgmap;       // ragged batches: the (item, 32-frame tile) column groups that hold valid frames
     int ncg;
+    int rt_groups;          // lx_pw1p_kernel: workgroups per frame tile, each looping over (2 inner / 512) / rt_groups row tiles (0 / 1: one)
 };
 hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st);      // which: 0 = pw1, 1 = pw2
 bool lx_layer_supported(int C, int inner);

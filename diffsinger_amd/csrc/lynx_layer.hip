@@ -290,13 +290,20 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane >> 4, lcol = lane & 15, rq = lrow * 4;
-    const int ft = xcd_work();
+    // work item = (row-tile group g, frame tile ft), g slowest (an XCD walks one group's weights): the workgroup loops over the
+    // nmt / rt_groups row tiles of its group (rt_groups = 1: all of them)
+    const int work = xcd_work();
+    const int nft = RAG ? p.ncg : p.nft;
+    const int grp = p.rt_groups > 1 ? fdiv_floor(work, p.inv_nft) : 0;
+    const int ft = work - grp * nft;
     const int rest = RAG ? p.cgmap[ft] : ft;
     const int b = fdiv_floor(rest, p.inv_tiles_per_b);
     const int t0 = (rest - b * p.tiles_per_b) * BN;
     const int Ts = p.Ts;
     const int bu = __builtin_amdgcn_readfirstlane(b), t0u = __builtin_amdgcn_readfirstlane(t0);
-    const int nmt = (2 * p.inner) / 512;                          // row tiles of 256 u channels (512 packed rows)
+    const int nmt_all = (2 * p.inner) / 512;                      // row tiles of 256 u channels (512 packed rows)
+    const int nmt_g = p.rt_groups > 1 ? nmt_all / p.rt_groups : nmt_all;
+    const int mt0 = __builtin_amdgcn_readfirstlane(grp * nmt_g), nmt = mt0 + nmt_g;
 #ifdef DSD_STAMPS
     unsigned long long st0 = LX_T(), st1 = 0, swalk = 0, sepi = 0;
 #endif
@@ -311,7 +318,8 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
     f32x4 mean, rstd;
     lx_merge_stats<KT>(p, bu, t0u, c4, mean, rstd);
     const __amdgpu_buffer_rsrc_t r_x = rsrc(p.xin + (long)bu * p.x_bstride + t0u);
-    const __amdgpu_buffer_rsrc_t r_w0 = rsrc(p.A1 + (long)(MBW * wave) * NS * 256);
+    constexpr long kMtBlocks = (long)MBW * 4 * NS * 256;         // floats of packed weights per row tile
+    const __amdgpu_buffer_rsrc_t r_w0 = rsrc(p.A1 + mt0 * kMtBlocks + (long)(MBW * wave) * NS * 256);
     int wk[MBW];
 #pragma unroll
     for (int k = 0; k < MBW; ++k) wk[k] = lane * 16 + k * NS * 1024;
@@ -350,9 +358,8 @@ __global__ __launch_bounds__(256, 1) void lx_pw1p_kernel(const LxLayerP p) {
     const __amdgpu_buffer_rsrc_t r_b = rsrc(p.bias1);
     float* ew = lds + KT * BN + wave * (32 * ES);                // wave-private [32 channels][ES], behind the activation tile
     const int ev0 = ((lane >> 3) * Ts + (lane & 7) * 4) * 4;
-    constexpr long kMtBlocks = (long)MBW * 4 * NS * 256;         // floats of packed weights per row tile
 #pragma unroll 1
-    for (int mt = 0; mt < nmt; ++mt) {
+    for (int mt = mt0; mt < nmt; ++mt) {
         const __amdgpu_buffer_rsrc_t r_w = rsrc(p.A1 + mt * kMtBlocks + (long)(MBW * wave) * NS * 256);
         f32x4 acc[MBW][2];
 #pragma unroll
@@ -1104,20 +1111,32 @@ static hipError_t lx_launch_pw1p(const LxLayerP& p, int nwg, hipStream_t st) {
     return launch_timed(lx_pw1p_kernel<KT, RAG>, dim3(nwg), dim3(256), ldsb, st, p, "lx_pw1p_kernel<%d, %d>", KT, RAG);
 }
 
-// pw1 as one workgroup per frame tile when that costs no more rounds of the chip than one per (frame tile, row tile):
-// ceil(nft / CUs) * mtiles row-tile times against ceil(nft * mtiles / CUs).  DSD_LYNX_PW1P=0/1 forces the choice.
-static bool lx_use_pw1p(int nft, int mtiles) {
+// pw1 with the activation tile staged once per workgroup and a loop over row tiles: how many row-tile GROUPS (= workgroups per
+// frame tile) - 1: all row tiles in one workgroup (lx_pw1p_kernel as in round 2), 2 / 4: half / a quarter of them, 0: one
+// workgroup per (frame tile, row tile) = lx_pw1_kernel.  By rounds of the chip: a workgroup takes ~11 us of prologue (statistics
+// merge, 128 KiB staging, launch ramp) + ~60 us per row tile (484 us at B = 8 for 8 row tiles, 254 for 4, 132 for 2); the
+// groups that fill whole rounds win - B = 2 / 4 / 6 at T = 1000: 4 / 2 / 4 groups.  DSD_LYNX_PW1P=0/1 forces none / one group.
+static int lx_pw1p_groups(int nft, int mtiles) {
     const int force = path_opts().lynx_pw1p;
-    if (force >= 0) return force != 0;
+    if (force >= 0) return force != 0 ? 1 : 0;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    const long per_ft = (long)((nft + cus - 1) / cus) * mtiles, per_wg = ((long)nft * mtiles + cus - 1) / cus;
-    return nft >= cus / 2 && per_ft <= per_wg;
+    int best = 0;
+    double best_t = 1e30;
+    for (int g = 1; g <= mtiles; g *= 2) {
+        if (mtiles % g) continue;
+        const long rounds = ((long)nft * g + cus - 1) / cus;
+        // (one row tile per workgroup = lx_pw1_kernel: 72 us alone, 67 per round when rounds follow each other)
+        const double t = g == mtiles ? 5.0 + 67.0 * (double)rounds : (double)rounds * (11.0 + 60.5 * (mtiles / g));
+        if (t < best_t * 0.995) { best_t = t; best = g; }       // (ties: fewer, longer workgroups)
+    }
+    return best == mtiles ? 0 : best;                            // one row tile per workgroup: lx_pw1_kernel
 }
+static bool lx_use_pw1p(int nft, int mtiles) { return lx_pw1p_groups(nft, mtiles) > 0; }
 
 template <int KT, int RAG>
 static hipError_t lx_launch(const LxLayerP& p, int which, int nwg, hipStream_t st) {
@@ -1156,8 +1175,11 @@ hipError_t launch_lx_layer(const LxLayerP& p, int which, int C, hipStream_t st) 
     const int mtiles = which == 0 ? (2 * p.inner) / 512 : C / 512;
     const int nwg = nft * mtiles;
     if (which == 0 && (nft == 0 || lx_use_pw1p(nft, mtiles))) {      // (nft == 0: attribute set-up of both forms at create)
-        hipError_t e = C == 1024 ? (p.cgmap ? lx_launch_pw1p<1024, 1>(p, nft, st) : lx_launch_pw1p<1024, 0>(p, nft, st))
-                     : C == 512 ? (p.cgmap ? lx_launch_pw1p<512, 1>(p, nft, st) : lx_launch_pw1p<512, 0>(p, nft, st))
+        LxLayerP q = p;
+        q.rt_groups = nft == 0 ? 1 : lx_pw1p_groups(nft, mtiles);
+        const int nwg1 = nft * q.rt_groups;
+        hipError_t e = C == 1024 ? (q.cgmap ? lx_launch_pw1p<1024, 1>(q, nwg1, st) : lx_launch_pw1p<1024, 0>(q, nwg1, st))
+                     : C == 512 ? (q.cgmap ? lx_launch_pw1p<512, 1>(q, nwg1, st) : lx_launch_pw1p<512, 0>(q, nwg1, st))
                                 : hipErrorInvalidValue;
         if (nft != 0 || e != hipSuccess) return e;
     }
