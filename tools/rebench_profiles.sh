@@ -12,3 +12,4 @@ run ${rt}_variance_reflow20_b8 --workload variance_reflow20 --batch 8 --steps 6 
 run ${rt}_wavenet_dpm50_bf16x3_b8 --workload wavenet_dpm50 --batch 8 --precision bf16x3 --steps 6 --warmup 2
 run ${rt}_lynxnet_ddim100_bf16x3_b8 --workload lynxnet_ddim100 --batch 8 --precision bf16x3 --steps 3 --warmup 1
 run ${rt}_wavenet_dpm50_b4 --workload wavenet_dpm50 --batch 4 --steps 8 --warmup 2
+run ${rt}_acoustic_default_b1 --workload acoustic_default --batch 1 --steps 10 --warmup 2
